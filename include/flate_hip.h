@@ -1,0 +1,158 @@
+/*
+ * flate_hip.h -- C ABI of libflate_hip.so: the MI355X (gfx950) DEFLATE engine that
+ * stands behind ianic/flate's compress / decompress / compressor / decompressor
+ * API (reference: /root/reference/src/flate.zig:9-71, src/gzip.zig:4-66,
+ * src/zlib.zig:4-66).
+ *
+ * The boundary is batch-shaped: one call processes n independent chunks
+ * ("chunk" = one complete deflate/gzip/zlib stream, i.e. what one
+ * `compress(reader, writer, options)` call of the reference produces, or what
+ * one `decompress(reader, writer)` call consumes).  Plain pointers and sizes
+ * only; no torch / HIP types in the signatures (hipStream_t travels as void*).
+ *
+ * What each entry point replaces in the reference:
+ *   flate_hip_compress_batch    deflate.compress            deflate.zig:56-60
+ *                               (= compressor + compress + finish, :138,304,344)
+ *                               deflate.huffman.compress    deflate.zig:402-406
+ *                               deflate.store.compress      deflate.zig:421-425
+ *                               via flate.zig:28-30,44-47,59-62 and the gzip /
+ *                               zlib twins (gzip.zig:23-25, zlib.zig:23-25)
+ *   flate_hip_decompress_batch  inflate.decompress          inflate.zig:14-17
+ *                               via flate.zig:10-12, gzip.zig:5-7, zlib.zig:5-7
+ *   flate_hip_compress_bound    (no reference twin: the Zig writer grows)
+ *   status codes                the reference's error set, 1:1
+ *                               (bit_reader.zig:29, container.zig:45-51,
+ *                               huffman_decoder.zig:35-40, inflate.zig:72-78)
+ *
+ * All work runs on the GPU.  There is no CPU fallback: if no HIP device is
+ * usable every call fails with FLATE_HIP_E_NO_DEVICE.
+ */
+#ifndef FLATE_HIP_H
+#define FLATE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flate_hip_ctx* flate_hip_handle;
+
+/* container tag -- container.zig:18-21 */
+enum { FLATE_HIP_RAW = 0, FLATE_HIP_GZIP = 1, FLATE_HIP_ZLIB = 2 };
+
+/* mode: 0 = store-only (deflate.zig:420-434), 1 = huffman-only (:401-415),
+ * 4..9 = Level.level_4 .. level_9 (:23-32; fast=4, default=6, best=9). */
+enum { FLATE_HIP_MODE_STORE = 0, FLATE_HIP_MODE_HUFFMAN = 1, FLATE_HIP_MODE_DEFAULT = 6 };
+
+/* where in / out / offsets / lengths / status live */
+enum { FLATE_HIP_MEM_HOST = 0, FLATE_HIP_MEM_DEVICE = 1 };
+
+/* call-level return codes */
+enum {
+    FLATE_HIP_OK = 0,
+    FLATE_HIP_E_NO_DEVICE = -1,   /* no usable HIP device / kernel image */
+    FLATE_HIP_E_INVALID_ARG = -2,
+    FLATE_HIP_E_ALLOC = -3,       /* workspace allocation failed */
+    FLATE_HIP_E_LAUNCH = -4,      /* a HIP call failed; see flate_hip_last_error */
+    FLATE_HIP_E_UNSUPPORTED = -5  /* e.g. a level 4..9 chunk longer than 65535 bytes */
+};
+
+/* per-chunk status: the reference's error names, same numbering as the oracle */
+enum {
+    FLATE_HIP_ST_OK = 0,
+    FLATE_HIP_ST_END_OF_STREAM = 1,
+    FLATE_HIP_ST_BAD_GZIP_HEADER = 2,
+    FLATE_HIP_ST_BAD_ZLIB_HEADER = 3,
+    FLATE_HIP_ST_WRONG_GZIP_CHECKSUM = 4,
+    FLATE_HIP_ST_WRONG_GZIP_SIZE = 5,
+    FLATE_HIP_ST_WRONG_ZLIB_CHECKSUM = 6,
+    FLATE_HIP_ST_INVALID_CODE = 7,
+    FLATE_HIP_ST_OVERSUBSCRIBED_HUFFMAN_TREE = 8,
+    FLATE_HIP_ST_INCOMPLETE_HUFFMAN_TREE = 9,
+    FLATE_HIP_ST_MISSING_END_OF_BLOCK_CODE = 10,
+    FLATE_HIP_ST_INVALID_MATCH = 11,
+    FLATE_HIP_ST_INVALID_BLOCK_TYPE = 12,
+    FLATE_HIP_ST_WRONG_STORED_BLOCK_NLEN = 13,
+    FLATE_HIP_ST_INVALID_DYNAMIC_BLOCK_HEADER = 14,
+    FLATE_HIP_ST_OUTPUT_TOO_SMALL = 100,
+    FLATE_HIP_ST_CHUNK_TOO_LARGE = 101 /* level 4..9 chunk > 65535 bytes (whole-stream mode: next round) */
+};
+
+/* decompress flags.  bit0: reference-strict dynamic block header (quirk Q6,
+ * inflate.zig:161-180: a code-length repeat that crosses the HLIT/HDIST
+ * boundary is rejected, although RFC 1951 3.2.7 allows it and the reference's
+ * own encoder emits it).  Default 0: such a header is accepted when valid. */
+enum { FLATE_HIP_INFLATE_STRICT_Q6 = 1 };
+
+/* largest level-4..9 chunk this build compresses (no window slide inside a chunk) */
+#define FLATE_HIP_MAX_LZ_CHUNK 65535u
+
+int flate_hip_create(int device, flate_hip_handle* h);
+int flate_hip_destroy(flate_hip_handle h);
+
+/* run on this hipStream_t (NULL = the handle's own stream).  All calls are
+ * synchronous on return for FLATE_HIP_MEM_HOST; for FLATE_HIP_MEM_DEVICE the
+ * work is enqueued on the stream and the call returns without a device sync
+ * unless flate_hip_set_sync(h, 1) (default 1). */
+int flate_hip_set_stream(flate_hip_handle h, void* hip_stream);
+int flate_hip_set_sync(flate_hip_handle h, int sync_on_return);
+
+/* upper bound of one chunk's output for n input bytes */
+size_t flate_hip_compress_bound(size_t n, int container, int mode);
+
+/*
+ * Compress n_chunks independent chunks.
+ *   in       all input bytes; chunk i is in[in_off[i] .. in_off[i+1])
+ *   in_off   n_chunks+1 offsets (bytes)
+ *   out      output buffer; chunk i owns the slot out[out_off[i] .. out_off[i+1])
+ *   out_off  n_chunks+1 slot starts (bytes), ascending; the slots must not
+ *            overlap and `out` must be 4-byte aligned
+ *   out_len  n_chunks produced lengths (bytes)
+ *   status   n_chunks FLATE_HIP_ST_* codes
+ * The bytes of chunk i are exactly what the reference writes for the same
+ * input with the same container and level/mode.
+ */
+int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
+                             uint32_t n_chunks, int container, int mode, uint8_t* out,
+                             const uint64_t* out_off, uint64_t* out_len, int32_t* status,
+                             int memkind);
+
+/*
+ * Decompress n_chunks independent streams (same argument shape).  out_len[i] is the
+ * number of bytes produced; status[i] the reference's error name for a bad stream.
+ * consumed (optional, may be NULL) receives the input bytes used by each stream, so a
+ * caller can walk concatenated members the way Inflate.reset() does (inflate.zig:301-309).
+ */
+int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
+                               uint32_t n_chunks, int container, int flags, uint8_t* out,
+                               const uint64_t* out_off, uint64_t* out_len, int32_t* status,
+                               uint64_t* consumed, int memkind);
+
+const char* flate_hip_status_name(int status);
+const char* flate_hip_last_error(flate_hip_handle h);
+const char* flate_hip_version(void);
+
+/* ---- measurement hooks (bench.py / tests) ---- */
+/* When enabled every kernel launch is bracketed by hipEvents on the launch stream.
+ * flate_hip_profile_read synchronises, folds the pending events into per-kernel
+ * totals and returns them: names[i], total_ms[i], launches[i] for i < return value
+ * (at most cap).  flate_hip_profile_reset clears the totals. */
+int flate_hip_profile_enable(flate_hip_handle h, int enable);
+int flate_hip_profile_read(flate_hip_handle h, const char** names, double* total_ms,
+                           uint64_t* launches, int cap);
+int flate_hip_profile_reset(flate_hip_handle h);
+
+/* ---- test seam (the reference's own seam is the BlockWriterType parameter of
+ * Deflate, deflate.zig:118-121: "so we can change that in test to test just
+ * tokenization part").  After a level 4..9 compress_batch call, copies the token
+ * list the tokenizer kernels produced for chunk `chunk` (same 32-bit token
+ * encoding as the oracle: bit23 kind, bits15-22 len-3 / literal, bits0-14
+ * dist-1) into host memory.  Returns the token count or a negative error. */
+int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tokens, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
