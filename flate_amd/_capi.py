@@ -1,0 +1,73 @@
+"""ctypes binding of libflate_hip.so (the C ABI declared in include/flate_hip.h).
+
+The product path.  It never imports the CPU oracle and has no CPU fallback: if the
+library is missing or no HIP device is usable, calls raise FlateHipError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflate_hip.so")
+
+RAW, GZIP, ZLIB = 0, 1, 2
+MODE_STORE, MODE_HUFFMAN = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MAX_LZ_CHUNK = 65535
+INFLATE_STRICT_Q6 = 1
+
+# every symbol include/flate_hip.h declares
+SYMBOLS = [
+    "flate_hip_create", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_set_sync",
+    "flate_hip_compress_bound", "flate_hip_compress_batch", "flate_hip_decompress_batch",
+    "flate_hip_status_name", "flate_hip_last_error", "flate_hip_version",
+    "flate_hip_profile_enable", "flate_hip_profile_read", "flate_hip_profile_reset",
+    "flate_hip_debug_tokens",
+]
+
+
+class FlateHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (pure dlopen: no GPU needed until flate_hip_create)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlateHipError("libflate_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C flate_amd/csrc` (%s)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64p, i32p = C.c_void_p, C.c_void_p, C.c_void_p
+    L.flate_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.flate_hip_create.restype = C.c_int
+    L.flate_hip_destroy.argtypes = [vp]
+    L.flate_hip_set_stream.argtypes = [vp, vp]
+    L.flate_hip_set_sync.argtypes = [vp, C.c_int]
+    L.flate_hip_compress_bound.argtypes = [C.c_size_t, C.c_int, C.c_int]
+    L.flate_hip_compress_bound.restype = C.c_size_t
+    L.flate_hip_compress_batch.argtypes = [vp, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp, u64p, u64p, i32p, C.c_int]
+    L.flate_hip_compress_batch.restype = C.c_int
+    L.flate_hip_decompress_batch.argtypes = [vp, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp, u64p, u64p, i32p, u64p,
+                                             C.c_int]
+    L.flate_hip_decompress_batch.restype = C.c_int
+    L.flate_hip_status_name.argtypes = [C.c_int]
+    L.flate_hip_status_name.restype = C.c_char_p
+    L.flate_hip_last_error.argtypes = [vp]
+    L.flate_hip_last_error.restype = C.c_char_p
+    L.flate_hip_version.restype = C.c_char_p
+    L.flate_hip_profile_enable.argtypes = [vp, C.c_int]
+    L.flate_hip_profile_reset.argtypes = [vp]
+    L.flate_hip_profile_read.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.flate_hip_profile_read.restype = C.c_int
+    L.flate_hip_debug_tokens.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    L.flate_hip_debug_tokens.restype = C.c_int64
+    _lib = L
+    return L
+
+
+def status_name(code):
+    return lib().flate_hip_status_name(int(code)).decode()

@@ -1,0 +1,248 @@
+"""Host-side mirror of the reference's public interface (src/flate.zig:9-71,
+src/gzip.zig:4-66, src/zlib.zig:4-66): the same names, argument meaning and error
+behaviour, over the C ABI of libflate_hip.so.
+
+  compress(reader, writer, options)     flate.zig:28-30   (one-shot: compressor + compress + finish)
+  Compressor / compressor(writer, opt)  flate.zig:33-40   (write / compress / finish; flush: see below)
+  decompress(reader, writer)            flate.zig:10-12
+  Decompressor / decompressor(reader)   flate.zig:15-22   (decompress / next / read / reader / reset / set_reader)
+  huffman.{compress,Compressor,compressor}   flate.zig:44-56
+  store.{compress,Compressor,compressor}     flate.zig:59-71
+  Options(level=Level.default), Level   deflate.zig:15-32
+
+`reader` is anything with .read() (or a bytes-like), `writer` anything with .write().
+Errors are FlateError subclasses named after the reference's error set
+(inflate.zig:72-78, huffman_decoder.zig:35-40, container.zig:45-51, bit_reader.zig:29).
+
+Scope of this round: one-shot streams.  Levels 4..9 take inputs of at
+most 65535 bytes per stream (larger inputs raise ChunkTooLarge -- whole-stream mode
+is SURVEY.md 8f-2); huffman-only and store-only streams have no size limit.  The
+history-preserving sync flush of Compressor.flush (deflate.zig:335-337) is not on
+the GPU path yet and raises NotImplementedError.
+"""
+import enum
+import io
+
+from . import _capi
+from .engine import default_engine
+
+
+class Level(enum.IntEnum):  # deflate.zig:23-32
+    fast = 4
+    level_4 = 4
+    level_5 = 5
+    default = 6
+    level_6 = 6
+    level_7 = 7
+    level_8 = 8
+    best = 9
+    level_9 = 9
+
+
+class Options:  # deflate.zig:15-17
+    def __init__(self, level=Level.default):
+        self.level = Level(level)
+
+
+class FlateError(Exception):
+    status = None
+
+
+def _mk(name, code):
+    return type(name, (FlateError,), {"status": code})
+
+
+EndOfStream = _mk("EndOfStream", 1)
+BadGzipHeader = _mk("BadGzipHeader", 2)
+BadZlibHeader = _mk("BadZlibHeader", 3)
+WrongGzipChecksum = _mk("WrongGzipChecksum", 4)
+WrongGzipSize = _mk("WrongGzipSize", 5)
+WrongZlibChecksum = _mk("WrongZlibChecksum", 6)
+InvalidCode = _mk("InvalidCode", 7)
+OversubscribedHuffmanTree = _mk("OversubscribedHuffmanTree", 8)
+IncompleteHuffmanTree = _mk("IncompleteHuffmanTree", 9)
+MissingEndOfBlockCode = _mk("MissingEndOfBlockCode", 10)
+InvalidMatch = _mk("InvalidMatch", 11)
+InvalidBlockType = _mk("InvalidBlockType", 12)
+WrongStoredBlockNlen = _mk("WrongStoredBlockNlen", 13)
+InvalidDynamicBlockHeader = _mk("InvalidDynamicBlockHeader", 14)
+OutputTooSmall = _mk("OutputTooSmall", 100)
+ChunkTooLarge = _mk("ChunkTooLarge", 101)
+InvalidState = _mk("InvalidState", 102)  # inflate.zig:303
+
+_ERRORS = {e.status: e for e in (
+    EndOfStream, BadGzipHeader, BadZlibHeader, WrongGzipChecksum, WrongGzipSize, WrongZlibChecksum, InvalidCode,
+    OversubscribedHuffmanTree, IncompleteHuffmanTree, MissingEndOfBlockCode, InvalidMatch, InvalidBlockType,
+    WrongStoredBlockNlen, InvalidDynamicBlockHeader, OutputTooSmall, ChunkTooLarge)}
+
+
+def raise_for_status(code):
+    if code:
+        raise _ERRORS.get(code, FlateError)(_capi.status_name(code))
+
+
+def _read_all(reader):
+    if isinstance(reader, (bytes, bytearray, memoryview)):
+        return bytes(reader)
+    return reader.read()
+
+
+class _Compressor:
+    """Deflate (deflate.zig:121-373) / SimpleCompressor (:449-529) seen from the caller."""
+
+    def __init__(self, container, mode, writer, engine=None):
+        self._container, self._mode, self._wrt = container, int(mode), writer
+        self._eng = engine or default_engine()
+        self._buf = bytearray()
+        self._done = False
+
+    def write(self, data):  # deflate.zig:363-367
+        self._buf += data
+        return len(data)
+
+    def compress(self, reader):  # deflate.zig:304-321
+        self._buf += _read_all(reader)
+
+    def writer(self):  # deflate.zig:369-371
+        return self
+
+    def flush(self):  # deflate.zig:335-337
+        raise NotImplementedError("sync flush keeps LZ history across calls; not on the GPU path in this round "
+                                  "(SURVEY.md 8f-1)")
+
+    def set_writer(self, new_writer):  # deflate.zig:351-354
+        self._wrt = new_writer
+
+    def finish(self):  # deflate.zig:344-347
+        if self._done:
+            return
+        outs, st = self._eng.compress_many([bytes(self._buf)], self._container, self._mode)
+        raise_for_status(st[0])
+        self._wrt.write(outs[0])
+        self._done = True
+
+
+class _Decompressor:
+    """Inflate (inflate.zig:43-355) seen from the caller."""
+
+    CHUNK = 65536  # the reference hands out at most its 64 KiB ring per next() (inflate.zig:322-336)
+
+    def __init__(self, container, reader, engine=None, flags=0):
+        self._container, self._flags = container, flags
+        self._eng = engine or default_engine()
+        self._in = _read_all(reader)
+        self._pos = 0      # start of the current stream in the input
+        self._out = None   # decoded bytes of the current stream
+        self._rp = 0
+        self._ended = False
+
+    def _decode(self):
+        if self._out is not None:
+            return
+        data = self._in[self._pos:]
+        cap = max(1 << 16, len(data) * 64)
+        while True:
+            outs, st, used = self._eng.decompress_many([data], self._container, self._flags, caps=[cap])
+            if st[0] == 100 and cap < (1 << 34):
+                cap *= 8
+                continue
+            break
+        raise_for_status(st[0])
+        self._out, self._used = outs[0], used[0]
+
+    def get(self, limit=0):  # inflate.zig:326-336
+        self._decode()
+        n = len(self._out) - self._rp
+        n = min(n, limit if limit else self.CHUNK)
+        buf = self._out[self._rp:self._rp + n]
+        self._rp += n
+        if n == 0:
+            self._ended = True
+        return buf
+
+    def next(self):  # inflate.zig:315-319
+        buf = self.get(0)
+        return buf if buf else None
+
+    def read(self, n=-1):  # inflate.zig:343-347 (n < 0: read to the end, Python convention)
+        if n is None or n < 0:
+            self._decode()
+            buf = self._out[self._rp:]
+            self._rp = len(self._out)
+            self._ended = True
+            return buf
+        return self.get(n) if n else b""
+
+    def reader(self):  # inflate.zig:349-351
+        return self
+
+    def decompress(self, writer):  # inflate.zig:292-296
+        while True:
+            buf = self.next()
+            if buf is None:
+                break
+            writer.write(buf)
+
+    def reset(self):  # inflate.zig:301-309: next stream of the same reader
+        if not self._ended:
+            raise InvalidState("reset() before the end of the stream")
+        self._pos += self._used
+        self._out, self._rp, self._ended = None, 0, False
+
+    def set_reader(self, new_reader):  # inflate.zig:283-288
+        self._in, self._pos = _read_all(new_reader), 0
+        self._out, self._rp, self._ended = None, 0, False
+
+
+class _Simple:
+    """huffman / store namespaces (flate.zig:44-71)."""
+
+    def __init__(self, container, mode):
+        self._container, self._mode = container, mode
+
+    def compress(self, reader, writer, engine=None):
+        c = self.compressor(writer, engine)
+        c.compress(reader)
+        c.finish()
+
+    def compressor(self, writer, engine=None):
+        return _Compressor(self._container, self._mode, writer, engine)
+
+    Compressor = compressor
+
+
+class ContainerModule:
+    """One of flate (raw) / gzip / zlib: identical function set (readme.md:104-124)."""
+
+    def __init__(self, container):
+        self._container = container
+        self.huffman = _Simple(container, _capi.MODE_HUFFMAN)
+        self.store = _Simple(container, _capi.MODE_STORE)
+        self.Options, self.Level = Options, Level
+
+    def compress(self, reader, writer, options=None, engine=None):
+        c = self.compressor(writer, options, engine)
+        c.compress(reader)
+        c.finish()
+
+    def compressor(self, writer, options=None, engine=None):
+        level = (options or Options()).level
+        return _Compressor(self._container, int(level), writer, engine)
+
+    Compressor = compressor
+
+    def decompress(self, reader, writer, engine=None):
+        self.decompressor(reader, engine).decompress(writer)
+
+    def decompressor(self, reader, engine=None):
+        return _Decompressor(self._container, reader, engine)
+
+    Decompressor = decompressor
+
+
+def compress_bytes(data, container=_capi.RAW, mode=6, engine=None):
+    w = io.BytesIO()
+    c = _Compressor(container, mode, w, engine)
+    c.compress(data)
+    c.finish()
+    return w.getvalue()

@@ -1,0 +1,565 @@
+// flate_hip.hip -- host side of libflate_hip.so: the C ABI of include/flate_hip.h.
+// Owns the device workspace, builds the chunk / block tables, launches the
+// kernels on the caller's HIP stream.  There is no CPU execution path: without a
+// usable gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flate_hip.h"
+#include "kernels_block.h"
+#include "kernels_common.h"
+#include "kernels_inflate.h"
+#include "kernels_lz.h"
+
+namespace {
+
+enum KernelId {
+    K_MEMSET = 0,
+    K_BYTE_HIST,
+    K_CHECKSUM,
+    K_LZ_SORT,
+    K_LZ_MATCH,
+    K_LZ_PARSE,
+    K_PLAN,
+    K_OFFSETS,
+    K_ENCODE,
+    K_INFLATE,
+    K_COUNT
+};
+const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
+                                           "k_lz_parse", "k_plan",      "k_offsets",  "k_encode",  "k_inflate"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct flate_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool sync = true;
+    std::string last_error;
+    fl_crc_consts crc{};
+    // device workspace (grown on demand, reused across calls)
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, SH, rec, desc, tokens, ntok;
+    DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
+    // last level 4..9 call, for the debug seam
+    uint32_t dbg_pass_chunks = 0;
+    uint32_t dbg_first_chunk = 0;
+    // profiling
+    bool prof = false;
+    struct Pending {
+        int kid;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[K_COUNT] = {0};
+    uint64_t prof_n[K_COUNT] = {0};
+};
+
+namespace {
+
+#define HIP_OK(h, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            (h)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return FLATE_HIP_E_LAUNCH;                                                                   \
+        }                                                                                                \
+    } while (0)
+
+int ensure(flate_hip_ctx* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return FLATE_HIP_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) {
+        h->last_error = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        b.p = nullptr;
+        return FLATE_HIP_E_ALLOC;
+    }
+    b.cap = want;
+    return FLATE_HIP_OK;
+}
+
+hipEvent_t get_event(flate_hip_ctx* h) {
+    if (!h->free_events.empty()) {
+        hipEvent_t e = h->free_events.back();
+        h->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    flate_hip_ctx* h;
+    int kid;
+    hipEvent_t a{}, b{};
+    ProfScope(flate_hip_ctx* h_, int kid_) : h(h_), kid(kid_) {
+        if (h->prof) {
+            a = get_event(h);
+            b = get_event(h);
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (h->prof) {
+            (void)hipEventRecord(b, h->stream);
+            h->pending.push_back({kid, a, b});
+        }
+    }
+};
+
+void fold_profile(flate_hip_ctx* h) {
+    if (h->pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->prof_ms[p.kid] += ms;
+            h->prof_n[p.kid] += 1;
+        }
+        h->free_events.push_back(p.a);
+        h->free_events.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+void init_crc_consts(fl_crc_consts& cc) {
+    cc.xpow8[0] = 0x00800000u;  // x^8 in the reflected representation (x^0 = 0x80000000)
+    for (int j = 1; j < 32; j++) cc.xpow8[j] = fl_crc_mulmod(cc.xpow8[j - 1], cc.xpow8[j - 1]);
+    for (int m = 0; m < 64; m++) cc.pow1024[m] = fl_crc_xpow8n(cc.xpow8, 1024ull * m);
+    cc.pow65535 = fl_crc_xpow8n(cc.xpow8, 65535);
+}
+
+bool level_args(int mode, fl_params& p) {  // deflate.zig:41-52
+    switch (mode) {
+        case 4: p.good = 4; p.lazy = 4; p.nice = 16; p.chain = 16; return true;
+        case 5: p.good = 8; p.lazy = 16; p.nice = 32; p.chain = 32; return true;
+        case 6: p.good = 8; p.lazy = 16; p.nice = 128; p.chain = 128; return true;
+        case 7: p.good = 8; p.lazy = 32; p.nice = 128; p.chain = 256; return true;
+        case 8: p.good = 32; p.lazy = 128; p.nice = 258; p.chain = 1024; return true;
+        case 9: p.good = 32; p.lazy = 258; p.nice = 258; p.chain = 4096; return true;
+        default: p.good = p.lazy = p.nice = p.chain = 0; return mode == 0 || mode == 1;
+    }
+}
+
+size_t pass_chunk_limit() {
+    const char* e = getenv("FLATE_HIP_MAX_PASS_CHUNKS");
+    if (e && atoi(e) > 0) return (size_t)atoi(e);
+    return 32768;
+}
+
+// Fetch the n+1 offsets to the host (the block tables are built there).
+int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind, std::vector<uint64_t>& host) {
+    host.resize((size_t)n + 1);
+    if (memkind == FLATE_HIP_MEM_HOST) {
+        memcpy(host.data(), off, sizeof(uint64_t) * ((size_t)n + 1));
+    } else {
+        HIP_OK(h, hipMemcpyAsync(host.data(), off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost,
+                                 h->stream));
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+    }
+    for (uint32_t i = 0; i < n; i++)
+        if (host[i + 1] < host[i]) return FLATE_HIP_E_INVALID_ARG;
+    return FLATE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* flate_hip_version(void) { return "flate_hip 0.1 (gfx950)"; }
+
+const char* flate_hip_status_name(int s) {
+    switch (s) {
+        case 0: return "Ok";
+        case 1: return "EndOfStream";
+        case 2: return "BadGzipHeader";
+        case 3: return "BadZlibHeader";
+        case 4: return "WrongGzipChecksum";
+        case 5: return "WrongGzipSize";
+        case 6: return "WrongZlibChecksum";
+        case 7: return "InvalidCode";
+        case 8: return "OversubscribedHuffmanTree";
+        case 9: return "IncompleteHuffmanTree";
+        case 10: return "MissingEndOfBlockCode";
+        case 11: return "InvalidMatch";
+        case 12: return "InvalidBlockType";
+        case 13: return "WrongStoredBlockNlen";
+        case 14: return "InvalidDynamicBlockHeader";
+        case 100: return "OutputTooSmall";
+        case 101: return "ChunkTooLarge";
+        default: return "Unknown";
+    }
+}
+
+int flate_hip_create(int device, flate_hip_handle* out) {
+    if (!out) return FLATE_HIP_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return FLATE_HIP_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    flate_hip_ctx* h = new flate_hip_ctx();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return FLATE_HIP_E_NO_DEVICE;
+    }
+    h->stream = h->own_stream;
+    init_crc_consts(h->crc);
+    *out = h;
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_destroy(flate_hip_handle h) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    fold_profile(h);
+    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->SH, &h->rec, &h->desc,
+                      &h->tokens, &h->ntok, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
+                      &h->st_consumed})
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_set_stream(flate_hip_handle h, void* hip_stream) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return FLATE_HIP_OK;
+}
+int flate_hip_set_sync(flate_hip_handle h, int s) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    h->sync = s != 0;
+    return FLATE_HIP_OK;
+}
+const char* flate_hip_last_error(flate_hip_handle h) { return h ? h->last_error.c_str() : "null handle"; }
+
+size_t flate_hip_compress_bound(size_t n, int container, int mode) {
+    (void)mode;
+    const size_t hdr = container == 1 ? 18 : (container == 2 ? 6 : 0);
+    // stored blocks: 5 bytes per 65535 (+ a possibly empty trailing one); a Huffman block never
+    // beats that bound by more than its header; slack for the Q1 seam.
+    return n + (n / 32768 + 2) * 16 + hdr + 64 + n / 64;
+}
+
+int flate_hip_profile_enable(flate_hip_handle h, int enable) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    h->prof = enable != 0;
+    return FLATE_HIP_OK;
+}
+int flate_hip_profile_reset(flate_hip_handle h) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    fold_profile(h);
+    for (int i = 0; i < K_COUNT; i++) {
+        h->prof_ms[i] = 0;
+        h->prof_n[i] = 0;
+    }
+    return FLATE_HIP_OK;
+}
+int flate_hip_profile_read(flate_hip_handle h, const char** names, double* total_ms, uint64_t* launches, int cap) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    fold_profile(h);
+    int n = 0;
+    for (int i = 0; i < K_COUNT && n < cap; i++) {
+        if (!h->prof_n[i]) continue;
+        names[n] = kKernelNames[i];
+        total_ms[n] = h->prof_ms[i];
+        launches[n] = h->prof_n[i];
+        n++;
+    }
+    return n;
+}
+
+int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
+                             int container, int mode, uint8_t* out, const uint64_t* out_off, uint64_t* out_len,
+                             int32_t* status, int memkind) {
+    if (!h || !in_off || !out_off || !out_len || !status) return FLATE_HIP_E_INVALID_ARG;
+    if (container < 0 || container > 2) return FLATE_HIP_E_INVALID_ARG;
+    fl_params prm{};
+    if (!level_args(mode, prm)) return FLATE_HIP_E_INVALID_ARG;
+    if (memkind != FLATE_HIP_MEM_HOST && memkind != FLATE_HIP_MEM_DEVICE) return FLATE_HIP_E_INVALID_ARG;
+    if (n_chunks == 0) return FLATE_HIP_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    prm.container = container;
+    prm.mode = mode;
+    hipStream_t st = h->stream;
+
+    std::vector<uint64_t> hin, hout;
+    int rc = fetch_offsets(h, in_off, n_chunks, memkind, hin);
+    if (rc) return rc;
+    rc = fetch_offsets(h, out_off, n_chunks, memkind, hout);
+    if (rc) return rc;
+    const uint64_t in_lo = hin[0], in_hi = hin[n_chunks];
+    const uint64_t out_lo = hout[0], out_hi = hout[n_chunks];
+
+    // device views of the caller's buffers
+    const uint8_t* d_in = in;
+    uint8_t* d_out = out;
+    uint64_t* d_outlen = out_len;
+    int32_t* d_status = status;
+    uint64_t in_shift = 0, out_shift = 0;  // subtracted from offsets when staging host buffers
+    if (memkind == FLATE_HIP_MEM_HOST) {
+        if ((rc = ensure(h, h->st_in, (in_hi - in_lo) + 16))) return rc;
+        if ((rc = ensure(h, h->st_out, (out_hi - out_lo) + 16))) return rc;
+        if ((rc = ensure(h, h->st_outlen, sizeof(uint64_t) * n_chunks))) return rc;
+        if ((rc = ensure(h, h->st_status, sizeof(int32_t) * n_chunks))) return rc;
+        if (in_hi > in_lo)
+            HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
+        d_in = (const uint8_t*)h->st_in.p;
+        d_out = (uint8_t*)h->st_out.p;
+        d_outlen = (uint64_t*)h->st_outlen.p;
+        d_status = (int32_t*)h->st_status.p;
+        in_shift = in_lo;
+        out_shift = out_lo;
+    } else if (((uintptr_t)out & 3) != 0) {
+        return FLATE_HIP_E_INVALID_ARG;
+    }
+
+    // chunk table + initial status
+    std::vector<fl_chunk> chunks(n_chunks);
+    std::vector<uint64_t> init_len(n_chunks, 0);
+    std::vector<int32_t> init_status(n_chunks, 0);
+    for (uint32_t i = 0; i < n_chunks; i++) {
+        fl_chunk& c = chunks[i];
+        const uint64_t len = hin[i + 1] - hin[i];
+        c.in_off = hin[i] - in_shift;
+        c.out_off = hout[i] - out_shift;
+        c.out_cap = hout[i + 1] - hout[i];
+        c.skip = 0;
+        if (len > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+        c.in_len = (uint32_t)len;
+        if (mode >= 4 && len > FLATE_HIP_MAX_LZ_CHUNK) {
+            c.skip = 1;
+            init_status[i] = FLATE_HIP_ST_CHUNK_TOO_LARGE;
+        }
+    }
+    HIP_OK(h, hipMemcpyAsync(d_outlen, init_len.data(), sizeof(uint64_t) * n_chunks, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(d_status, init_status.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
+
+    // the bit packer ORs into the output: clear the slots first
+    if (out_hi > out_lo) {
+        ProfScope ps(h, K_MEMSET);
+        HIP_OK(h, hipMemsetAsync(d_out + (out_lo - out_shift), 0, out_hi - out_lo, st));
+    }
+
+    const size_t pass_limit = pass_chunk_limit();
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += (uint32_t)pass_limit) {
+        const uint32_t nc = (uint32_t)std::min<size_t>(pass_limit, n_chunks - c0);
+        // block table of this pass
+        std::vector<uint32_t> blk_chunk;
+        uint32_t nb = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            fl_chunk& c = chunks[c0 + i];
+            c.first_block = nb;
+            c.n_blocks = mode >= 4 ? 2u : (uint32_t)(c.in_len / FL_BLOCK_BYTES + 1);  // deflate.zig:498-511, 480-484
+            for (uint32_t k = 0; k < c.n_blocks; k++) blk_chunk.push_back(i);
+            nb += c.n_blocks;
+        }
+        prm.n_chunks = nc;
+        prm.n_blocks = nb;
+        if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * nc))) return rc;
+        if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * nb))) return rc;
+        if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)nb))) return rc;
+        if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320 * (size_t)nb))) return rc;
+        if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
+        HIP_OK(h, hipMemcpyAsync(h->chunks.p, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, st));
+        HIP_OK(h, hipMemcpyAsync(h->blk_chunk.p, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));
+        // the host vectors must outlive the async copies
+        HIP_OK(h, hipStreamSynchronize(st));
+
+        const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
+        const uint32_t* dbc = (const uint32_t*)h->blk_chunk.p;
+        fl_block_plan* dpl = (fl_block_plan*)h->plans.p;
+        uint32_t* dhist = (uint32_t*)h->hist.p;
+        uint32_t* dcks = (uint32_t*)h->cks.p;
+
+        if (container != 0) {
+            ProfScope ps(h, K_CHECKSUM);
+            hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, prm, h->crc, dcks);
+        }
+        if (mode >= 4) {
+            const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
+            if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
+            if ((rc = ensure(h, h->SH, per * sizeof(uint16_t)))) return rc;
+            if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
+            {
+                ProfScope ps(h, K_LZ_SORT);
+                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p,
+                                   (uint16_t*)h->SH.p, (uint32_t*)h->rec.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_MATCH);
+                hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(64 * FL_MATCH_WAVES), 0, st, d_in, dch, prm,
+                                   (const uint16_t*)h->S.p, (const uint16_t*)h->SH.p, (uint32_t*)h->rec.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_PARSE);
+                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->tokens.p, dhist, dpl,
+                                   (uint32_t*)h->ntok.p);
+            }
+            h->dbg_pass_chunks = nc;
+            h->dbg_first_chunk = c0;
+        } else if (mode == 1) {
+            ProfScope ps(h, K_BYTE_HIST);
+            hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dhist);
+        }
+        {
+            ProfScope ps(h, K_PLAN);
+            if (mode == 0)
+                hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, nb, dpl);
+            else
+                hipLaunchKernelGGL(k_plan, dim3(nb), dim3(64), 0, st, dch, dbc, prm, (const uint32_t*)dhist, dpl);
+        }
+        {
+            ProfScope ps(h, K_OFFSETS);
+            hipLaunchKernelGGL(k_offsets, dim3(nc), dim3(64), 0, st, dch, prm, h->crc, dpl, (const uint32_t*)dcks,
+                               d_out, d_outlen + c0, d_status + c0);
+        }
+        {
+            ProfScope ps(h, K_ENCODE);
+            if (mode >= 4)
+                hipLaunchKernelGGL(k_encode<true>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
+                                   (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out);
+            else
+                hipLaunchKernelGGL(k_encode<false>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
+                                   (const fl_block_plan*)dpl, (const uint32_t*)nullptr, (uint32_t*)d_out);
+        }
+        HIP_OK(h, hipGetLastError());
+    }
+
+    if (memkind == FLATE_HIP_MEM_HOST) {
+        HIP_OK(h, hipMemcpyAsync(out_len, d_outlen, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
+        HIP_OK(h, hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_chunks, hipMemcpyDeviceToHost, st));
+        if (out_hi > out_lo)
+            HIP_OK(h, hipMemcpyAsync(out + out_lo, d_out, out_hi - out_lo, hipMemcpyDeviceToHost, st));
+        HIP_OK(h, hipStreamSynchronize(st));
+    } else if (h->sync) {
+        HIP_OK(h, hipStreamSynchronize(st));
+    }
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
+                               int container, int flags, uint8_t* out, const uint64_t* out_off, uint64_t* out_len,
+                               int32_t* status, uint64_t* consumed, int memkind) {
+    if (!h || !in_off || !out_off || !out_len || !status) return FLATE_HIP_E_INVALID_ARG;
+    if (container < 0 || container > 2) return FLATE_HIP_E_INVALID_ARG;
+    if (memkind != FLATE_HIP_MEM_HOST && memkind != FLATE_HIP_MEM_DEVICE) return FLATE_HIP_E_INVALID_ARG;
+    if (n_chunks == 0) return FLATE_HIP_OK;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    hipStream_t st = h->stream;
+
+    std::vector<uint64_t> hin, hout;
+    int rc = fetch_offsets(h, in_off, n_chunks, memkind, hin);
+    if (rc) return rc;
+    rc = fetch_offsets(h, out_off, n_chunks, memkind, hout);
+    if (rc) return rc;
+    const uint64_t in_lo = hin[0], in_hi = hin[n_chunks];
+    const uint64_t out_lo = hout[0], out_hi = hout[n_chunks];
+
+    const uint8_t* d_in = in;
+    uint8_t* d_out = out;
+    uint64_t* d_outlen = out_len;
+    int32_t* d_status = status;
+    uint64_t* d_consumed = consumed;
+    uint64_t in_shift = 0, out_shift = 0;
+    if (memkind == FLATE_HIP_MEM_HOST) {
+        if ((rc = ensure(h, h->st_in, (in_hi - in_lo) + 16))) return rc;
+        if ((rc = ensure(h, h->st_out, (out_hi - out_lo) + 16))) return rc;
+        if ((rc = ensure(h, h->st_outlen, sizeof(uint64_t) * n_chunks))) return rc;
+        if ((rc = ensure(h, h->st_status, sizeof(int32_t) * n_chunks))) return rc;
+        if ((rc = ensure(h, h->st_consumed, sizeof(uint64_t) * n_chunks))) return rc;
+        if (in_hi > in_lo)
+            HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
+        d_in = (const uint8_t*)h->st_in.p;
+        d_out = (uint8_t*)h->st_out.p;
+        d_outlen = (uint64_t*)h->st_outlen.p;
+        d_status = (int32_t*)h->st_status.p;
+        d_consumed = (uint64_t*)h->st_consumed.p;
+        in_shift = in_lo;
+        out_shift = out_lo;
+    }
+    std::vector<fl_chunk> chunks(n_chunks);
+    for (uint32_t i = 0; i < n_chunks; i++) {
+        fl_chunk& c = chunks[i];
+        const uint64_t len = hin[i + 1] - hin[i];
+        if (len > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+        c.in_off = hin[i] - in_shift;
+        c.out_off = hout[i] - out_shift;
+        c.out_cap = hout[i + 1] - hout[i];
+        c.in_len = (uint32_t)len;
+        c.first_block = 0;
+        c.n_blocks = 0;
+        c.skip = 0;
+    }
+    if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * n_chunks))) return rc;
+    HIP_OK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), sizeof(fl_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipStreamSynchronize(st));
+    {
+        ProfScope ps(h, K_INFLATE);
+        hipLaunchKernelGGL(k_inflate, dim3(n_chunks), dim3(64), 0, st, d_in, (const fl_chunk*)h->chunks.p, container,
+                           flags, h->crc, d_out, d_outlen, d_status, d_consumed);
+    }
+    HIP_OK(h, hipGetLastError());
+    if (memkind == FLATE_HIP_MEM_HOST) {
+        HIP_OK(h, hipMemcpyAsync(out_len, d_outlen, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
+        HIP_OK(h, hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_chunks, hipMemcpyDeviceToHost, st));
+        if (consumed)
+            HIP_OK(h, hipMemcpyAsync(consumed, d_consumed, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
+        if (out_hi > out_lo)
+            HIP_OK(h, hipMemcpyAsync(out + out_lo, d_out, out_hi - out_lo, hipMemcpyDeviceToHost, st));
+        HIP_OK(h, hipStreamSynchronize(st));
+    } else if (h->sync) {
+        HIP_OK(h, hipStreamSynchronize(st));
+    }
+    return FLATE_HIP_OK;
+}
+
+int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tokens, uint64_t cap) {
+    if (!h || !tokens) return FLATE_HIP_E_INVALID_ARG;
+    if (chunk < h->dbg_first_chunk || chunk >= h->dbg_first_chunk + h->dbg_pass_chunks) return FLATE_HIP_E_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    const uint32_t local = chunk - h->dbg_first_chunk;
+    uint32_t n = 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return FLATE_HIP_E_LAUNCH;
+    if (hipMemcpy(&n, (uint32_t*)h->ntok.p + local, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+        return FLATE_HIP_E_LAUNCH;
+    const uint64_t k = std::min<uint64_t>(n, cap);
+    if (k && hipMemcpy(tokens, (uint32_t*)h->tokens.p + (size_t)local * FL_CHUNK_STRIDE, k * sizeof(uint32_t),
+                       hipMemcpyDeviceToHost) != hipSuccess)
+        return FLATE_HIP_E_LAUNCH;
+    return (int64_t)n;
+}
+
+}  // extern "C"

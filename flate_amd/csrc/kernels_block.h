@@ -1,0 +1,532 @@
+// kernels_block.h -- the Huffman block writer on the GPU: symbol histograms,
+// block planning (one lane per block runs the serial planner of flate_common.h),
+// output bit-offset scan, and the wave-parallel bit packer.
+//
+// Reference path: BlockWriter.write / huffmanBlock / storedBlock
+// (block_writer.zig:307-388, 524-585), SimpleCompressor (deflate.zig:449-529),
+// container header/footer + hasher (container.zig:53-109, 168-206).
+//
+// Bound: HBM (read every input byte / token once, write every output byte once);
+// the bit packer stages bits in LDS and emits whole dwords, coalesced.
+#pragma once
+#include "kernels_common.h"
+
+// ------------------------------------------------------------------ histograms
+// huffman-only mode: 256-bin byte histogram of each 65535-byte block
+// (block_writer.zig:575-585).  One workgroup (256 threads) per block; per-wave
+// LDS sub-histograms reduced at the end.
+__global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ in,
+                                                   const fl_chunk* __restrict__ chunks,
+                                                   const uint32_t* __restrict__ blk_chunk,
+                                                   uint32_t* __restrict__ hist /* [n_blocks][320] */) {
+    __shared__ uint32_t sh[4][256];
+    const uint32_t b = blockIdx.x;
+    const fl_chunk ck = chunks[blk_chunk[b]];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    for (uint32_t i = tid; i < 4 * 256; i += 256) (&sh[0][0])[i] = 0;
+    __syncthreads();
+    if (!ck.skip) {
+        const uint32_t j = b - ck.first_block;
+        const uint64_t start = (uint64_t)j * FL_BLOCK_BYTES;
+        const uint32_t len = (uint32_t)min((uint64_t)FL_BLOCK_BYTES, (uint64_t)ck.in_len - min((uint64_t)ck.in_len, start));
+        const uint8_t* src = in + ck.in_off + start;
+        // head bytes up to 4-byte alignment, then dword loads
+        const uint32_t mis = (uint32_t)((4 - ((uintptr_t)src & 3)) & 3);
+        const uint32_t head = mis < len ? mis : len;
+        if (tid < head) atomicAdd(&sh[wave][src[tid]], 1u);
+        const uint32_t body = (len - head) >> 2;
+        const uint32_t* src32 = (const uint32_t*)(src + head);
+        for (uint32_t i = tid; i < body; i += 256) {
+            const uint32_t w = src32[i];
+            atomicAdd(&sh[wave][w & 0xff], 1u);
+            atomicAdd(&sh[wave][(w >> 8) & 0xff], 1u);
+            atomicAdd(&sh[wave][(w >> 16) & 0xff], 1u);
+            atomicAdd(&sh[wave][w >> 24], 1u);
+        }
+        const uint32_t tail0 = head + (body << 2);
+        if (tail0 + tid < len) atomicAdd(&sh[wave][src[tail0 + tid]], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)b * 320 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+}
+
+// ------------------------------------------------------------------ checksums
+// Per-block CRC-32 (gzip) or Adler-32 partial sums (zlib) of the raw input
+// (deflate.zig:314,507 -> container.zig:168-206).  One wave per 65535-byte block,
+// lane i owns bytes [1024 i, 1024 (i+1)); partial CRCs are folded with
+// crc(A||B) = crc(A) * x^(8|B|) + crc(B).
+__global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
+                                                 const fl_chunk* __restrict__ chunks,
+                                                 const uint32_t* __restrict__ blk_chunk, fl_params prm,
+                                                 fl_crc_consts cc, uint32_t* __restrict__ part /* [n_blocks][2] */) {
+    __shared__ uint32_t tab[4][256];
+    const uint32_t b = blockIdx.x;
+    const fl_chunk ck = chunks[blk_chunk[b]];
+    const uint32_t lane = threadIdx.x;
+    if (ck.skip) return;
+    uint32_t start, len;
+    if (prm.mode >= 4) {
+        if (b != ck.first_block) return;  // level 4..9: the chunk (<= 65535 bytes) is one checksum unit
+        start = 0;
+        len = ck.in_len;
+    } else {
+        const uint32_t j = b - ck.first_block;
+        const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
+        start = (uint32_t)min(s, (uint64_t)ck.in_len);
+        len = min(FL_BLOCK_BYTES, ck.in_len - start);
+    }
+    const uint8_t* src = in + ck.in_off + start;
+    const uint32_t lo = min(len, lane * 1024u), hi = min(len, lane * 1024u + 1024u);
+    if (prm.container == 1) {
+        for (uint32_t t = lane; t < 256; t += 64) {
+            uint32_t c = t;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (FL_CRC_POLY ^ (c >> 1)) : (c >> 1);
+            tab[0][t] = c;
+        }
+        fl_wave_lds_sync();
+        for (int k = 1; k < 4; k++) {
+            for (uint32_t t = lane; t < 256; t += 64) {
+                const uint32_t c = tab[k - 1][t];
+                tab[k][t] = tab[0][c & 0xff] ^ (c >> 8);
+            }
+            fl_wave_lds_sync();
+        }
+        uint32_t c = 0xffffffffu;
+        uint32_t i = lo;
+        while (i < hi && (((uintptr_t)(src + i)) & 3)) c = tab[0][(c ^ src[i++]) & 0xff] ^ (c >> 8);
+        for (; i + 4 <= hi; i += 4) {
+            c ^= *(const uint32_t*)(src + i);
+            c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+        }
+        for (; i < hi; i++) c = tab[0][(c ^ src[i]) & 0xff] ^ (c >> 8);
+        c = (hi > lo) ? ~c : 0u;  // crc of an empty slice is 0
+        // bytes of the block after this lane's slice
+        const uint32_t after = len - hi;
+        const uint32_t full = after >> 10, tail = after & 1023u;
+        uint32_t tpow = 0x80000000u;
+        for (int j = 0; j < 10; j++)
+            if (tail & (1u << j)) tpow = fl_crc_mulmod(cc.xpow8[j], tpow);
+        c = fl_crc_mulmod(fl_crc_mulmod(c, cc.pow1024[full]), tpow);
+        c = fl_wave_xor(c);
+        if (lane == 0) {
+            part[2 * (uint64_t)b] = c;
+            part[2 * (uint64_t)b + 1] = len;
+        }
+    } else if (prm.container == 2) {
+        // Adler-32 pieces with a = b = 0 start: A = sum d_k, B = sum (n - k) d_k
+        uint32_t A = 0, B = 0;
+        for (uint32_t i = lo; i < hi; i++) {  // <= 1024 bytes: B < 2^28, no overflow
+            A += src[i];
+            B += A;
+        }
+        // combine lanes in order: B_tot = sum_i (B_i + A_i * bytes_after_i), all mod 65521
+        const uint32_t after = len - hi;
+        uint64_t bb = (uint64_t)B + (uint64_t)A * after;
+        uint32_t Bm = (uint32_t)(bb % 65521u);
+        uint32_t Am = fl_wave_sum(A) % 65521u;  // <= 65535*255 fits
+        // sum of 64 values < 65521 fits in 32 bits
+        Bm = fl_wave_sum(Bm) % 65521u;
+        if (lane == 0) {
+            part[2 * (uint64_t)b] = Am | (Bm << 16);
+            part[2 * (uint64_t)b + 1] = len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ planning
+// One wave per block; lane 0 runs the serial planner (flate_common.h) with its
+// scratch in LDS.  mode 1: huffmanBlock; mode >= 4: BlockWriter.write.
+__global__ __launch_bounds__(64) void k_plan(const fl_chunk* __restrict__ chunks,
+                                             const uint32_t* __restrict__ blk_chunk, fl_params prm,
+                                             const uint32_t* __restrict__ hist, fl_block_plan* __restrict__ plans) {
+    __shared__ fl_plan_ws ws;
+    const uint32_t b = blockIdx.x;
+    const fl_chunk ck = chunks[blk_chunk[b]];
+    const uint32_t lane = threadIdx.x;
+    fl_block_plan* plan = &plans[b];
+    if (ck.skip) {
+        if (lane == 0) plan->valid = 0;
+        return;
+    }
+    if (prm.mode == 1) {
+        const uint32_t j = b - ck.first_block;
+        const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
+        const uint32_t start = (uint32_t)min(s, (uint64_t)ck.in_len);
+        const uint32_t len = min(FL_BLOCK_BYTES, ck.in_len - start);
+        for (uint32_t i = lane; i < 256; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
+        fl_wave_lds_sync();
+        if (lane == 0) {
+            plan->valid = 1;
+            plan->in_start = start;
+            plan->tok_start = start;
+            plan->tok_count = len;
+            fl_plan_huffman_block(&ws, plan, len, j + 1 == ck.n_blocks);
+        }
+    } else {
+        // token block: metadata (valid, tok_*, in_*, final_block) was written by the parse kernel
+        if (!plan->valid) return;
+        for (uint32_t i = lane; i < FL_NUM_LIT; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
+        if (lane < FL_NUM_DIST) ws.dist_freq[lane] = (uint16_t)hist[(uint64_t)b * 320 + 286 + lane];
+        fl_wave_lds_sync();
+        if (lane == 0) fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);
+    }
+}
+
+// store-only mode: every block is a stored block (deflate.zig:486-493)
+__global__ __launch_bounds__(256) void k_plan_store(const fl_chunk* __restrict__ chunks,
+                                                    const uint32_t* __restrict__ blk_chunk, uint32_t n_blocks,
+                                                    fl_block_plan* __restrict__ plans) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    const fl_chunk ck = chunks[blk_chunk[b]];
+    fl_block_plan* plan = &plans[b];
+    const uint32_t j = b - ck.first_block;
+    const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
+    const uint32_t start = (uint32_t)min(s, (uint64_t)ck.in_len);
+    const uint32_t len = min(FL_BLOCK_BYTES, ck.in_len - start);
+    plan->valid = ck.skip ? 0 : 1;
+    plan->type = FL_BLOCK_STORED;
+    plan->size_bits = 0;
+    plan->hdr_nbits = 0;
+    plan->final_block = (j + 1 == ck.n_blocks);
+    plan->in_start = start;
+    plan->in_len = len;
+    plan->tok_start = start;
+    plan->tok_count = len;
+}
+
+// ------------------------------------------------------------------ offsets
+// Bit offset of every block inside its chunk's stream.  A Huffman block moves the
+// offset by its exact size; a stored block first pads to a byte boundary
+// (block_writer.zig:283-291).  Both are maps off -> (has ? ceil8(off + a) + c : off + a);
+// they compose associatively, so a chunk with thousands of blocks is a wave scan.
+struct fl_offmap {
+    uint64_t a, c;
+    uint32_t has;
+};
+__device__ __forceinline__ fl_offmap fl_offmap_compose(fl_offmap f, fl_offmap g) {  // f first, then g
+    fl_offmap r;
+    if (!f.has) {
+        r.a = f.a + g.a;
+        r.c = g.c;
+        r.has = g.has;
+    } else if (!g.has) {
+        r.a = f.a;
+        r.c = f.c + g.a;
+        r.has = 1;
+    } else {
+        r.a = f.a;
+        r.c = ((f.c + g.a + 7) & ~7ull) + g.c;
+        r.has = 1;
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t fl_offmap_apply(fl_offmap f, uint64_t off) {
+    return f.has ? (((off + f.a + 7) & ~7ull) + f.c) : off + f.a;
+}
+
+// One wave per chunk: block offsets, container header / footer bytes, out_len, status.
+__global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                fl_crc_consts cc, fl_block_plan* __restrict__ plans,
+                                                const uint32_t* __restrict__ cks_part,
+                                                uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
+                                                int32_t* __restrict__ status) {
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    const uint32_t lane = threadIdx.x;
+    if (ck.skip) return;  // host already wrote status / out_len
+    const uint32_t hdr_bytes = prm.container == 1 ? 10u : (prm.container == 2 ? 2u : 0u);
+    const uint32_t ftr_bytes = prm.container == 1 ? 8u : (prm.container == 2 ? 4u : 0u);
+    const uint64_t base = (ck.out_off + hdr_bytes) * 8;
+
+    fl_offmap run;  // composition of all blocks before the current batch
+    run.a = 0;
+    run.c = 0;
+    run.has = 0;
+    for (uint32_t b0 = 0; b0 < ck.n_blocks; b0 += 64) {
+        const uint32_t j = b0 + lane;
+        fl_offmap m;
+        m.a = 0;
+        m.c = 0;
+        m.has = 0;
+        fl_block_plan* plan = nullptr;
+        if (j < ck.n_blocks) {
+            plan = &plans[ck.first_block + j];
+            if (plan->valid) {
+                if (plan->type == FL_BLOCK_STORED) {
+                    m.a = 3;
+                    m.c = 32 + 8ull * plan->in_len;
+                    m.has = 1;
+                } else {
+                    m.a = plan->size_bits;
+                }
+            }
+        }
+        // inclusive scan of the composition across lanes
+        fl_offmap inc = m;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            fl_offmap o;
+            o.a = __shfl_up(inc.a, d, 64);
+            o.c = __shfl_up(inc.c, d, 64);
+            o.has = __shfl_up(inc.has, d, 64);
+            if (lane >= (uint32_t)d) inc = fl_offmap_compose(o, inc);
+        }
+        // exclusive = inclusive of the previous lane
+        fl_offmap exc;
+        exc.a = __shfl_up(inc.a, 1, 64);
+        exc.c = __shfl_up(inc.c, 1, 64);
+        exc.has = __shfl_up(inc.has, 1, 64);
+        if (lane == 0) {
+            exc.a = 0;
+            exc.c = 0;
+            exc.has = 0;
+        }
+        if (plan && plan->valid) plan->bit_off = fl_offmap_apply(fl_offmap_compose(run, exc), base);
+        fl_offmap last;
+        last.a = __shfl(inc.a, 63, 64);
+        last.c = __shfl(inc.c, 63, 64);
+        last.has = __shfl(inc.has, 63, 64);
+        run = fl_offmap_compose(run, last);
+    }
+    const uint64_t end_bits = fl_offmap_apply(run, base);
+    const uint64_t body_end = (end_bits + 7) >> 3;  // bit_writer.flush pads the last byte (bit_writer.zig:46-61)
+    const uint64_t total = body_end + ftr_bytes - ck.out_off;
+    const bool fits = total <= ck.out_cap;
+
+    // checksum over the whole chunk: fold the per-block parts (lane 0, serial Horner)
+    uint32_t cks = 0;
+    if (prm.container != 0 && lane == 0) {
+        if (prm.mode >= 4) {
+            cks = cks_part[2 * (uint64_t)ck.first_block];
+            if (prm.container == 2) {
+                const uint32_t A = cks & 0xffff, B = cks >> 16, n = ck.in_len;
+                const uint32_t a = (1 + A) % 65521u;
+                const uint32_t bsum = (uint32_t)(((uint64_t)n + B) % 65521u);  // b = 0 + 1*n + B
+                cks = a | (bsum << 16);
+            }
+        } else if (prm.container == 1) {
+            uint32_t crc = 0;
+            for (uint32_t j = 0; j < ck.n_blocks; j++) {
+                const uint32_t pc = cks_part[2 * (uint64_t)(ck.first_block + j)];
+                const uint32_t pl = cks_part[2 * (uint64_t)(ck.first_block + j) + 1];
+                const uint32_t sh = pl == FL_BLOCK_BYTES ? cc.pow65535 : fl_crc_xpow8n(cc.xpow8, pl);
+                crc = fl_crc_mulmod(crc, sh) ^ pc;
+            }
+            cks = crc;
+        } else {
+            uint32_t a = 1, bsum = 0;
+            for (uint32_t j = 0; j < ck.n_blocks; j++) {
+                const uint32_t pc = cks_part[2 * (uint64_t)(ck.first_block + j)];
+                const uint32_t pl = cks_part[2 * (uint64_t)(ck.first_block + j) + 1];
+                bsum = (uint32_t)(((uint64_t)bsum + (uint64_t)a * pl + (pc >> 16)) % 65521u);
+                a = (a + (pc & 0xffff)) % 65521u;
+            }
+            cks = a | (bsum << 16);
+        }
+    }
+    if (lane == 0) {
+        out_len[c] = fits ? total : 0;
+        status[c] = fits ? 0 : 100;  // FLATE_HIP_ST_OUTPUT_TOO_SMALL
+        if (!fits) {
+            for (uint32_t j = 0; j < ck.n_blocks; j++) plans[ck.first_block + j].valid = 0;
+        } else {
+            uint8_t* o = out + ck.out_off;
+            if (prm.container == 1) {  // container.zig:64
+                const uint8_t h[10] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0x03};
+                for (int i = 0; i < 10; i++) o[i] = h[i];
+                uint8_t* f = out + body_end;  // container.zig:92-96
+                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks >> (8 * i));
+                for (int i = 0; i < 4; i++) f[4 + i] = (uint8_t)(ck.in_len >> (8 * i));
+            } else if (prm.container == 2) {  // container.zig:78, 104
+                o[0] = 0x78;
+                o[1] = 0x9c;
+                uint8_t* f = out + body_end;
+                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks >> (8 * (3 - i)));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ encode
+// Wave-parallel bit packer.  A block is a sequence of "items": the header bytes
+// the planner produced, then one item per token (levels 4..9) or per input byte
+// (huffman-only), then the end-of-block code (block_writer.zig:492-520, 563-571).
+// The workgroup's 4 waves own contiguous quarters of the item sequence; a first
+// pass sums the bit lengths so each wave knows where its bits start, the second
+// pass packs 64 items at a time: wave prefix sum of lengths, ds_or into an LDS
+// staging window, then whole dwords go out coalesced.  Only the first and last
+// dword of a wave's range can be shared with a neighbour; those are atomic ORs
+// into the pre-zeroed output.
+#define FL_ENC_WAVES 4
+#define FL_STG_DW 112
+
+struct fl_item {
+    uint64_t v;
+    uint32_t n;
+};
+
+template <bool TOKENS>
+__device__ __forceinline__ fl_item fl_block_item(uint32_t i, uint32_t n_hdr, uint32_t hdr_nbits, uint32_t n_sym,
+                                                 const uint8_t* __restrict__ hdr,
+                                                 const uint8_t* __restrict__ bytes,
+                                                 const uint32_t* __restrict__ toks, const uint32_t* lit_lds,
+                                                 const uint32_t* dist_lds) {
+    fl_item it;
+    it.v = 0;
+    it.n = 0;
+    if (i < n_hdr) {
+        const uint32_t rem = hdr_nbits - 8 * i;
+        it.n = rem < 8 ? rem : 8;
+        it.v = hdr[i] & ((1u << it.n) - 1);
+    } else if (i < n_hdr + n_sym) {
+        const uint32_t k = i - n_hdr;
+        if (!TOKENS) {
+            const uint32_t e = lit_lds[bytes[k]];
+            it.v = e & 0xffff;
+            it.n = e >> 16;
+        } else {
+            const uint32_t t = toks[k];
+            if (!FL_TOK_IS_MATCH(t)) {
+                const uint32_t e = lit_lds[FL_TOK_LENLIT(t)];
+                it.v = e & 0xffff;
+                it.n = e >> 16;
+            } else {
+                const uint32_t ll = FL_TOK_LENLIT(t);
+                const uint32_t li = fl_len_index(ll);
+                const uint32_t le = lit_lds[257 + li];
+                uint64_t v = le & 0xffff;
+                uint32_t n = le >> 16;
+                const uint32_t leb = fl_len_extra_bits(li);
+                v |= (uint64_t)(ll - fl_len_base_scaled(li)) << n;
+                n += leb;
+                const uint32_t d = FL_TOK_DIST0(t);
+                const uint32_t dc = fl_dist_code(d);
+                const uint32_t de = dist_lds[dc];
+                v |= (uint64_t)(de & 0xffff) << n;
+                n += de >> 16;
+                const uint32_t deb = fl_dist_extra_bits(dc);
+                v |= (uint64_t)(d - fl_dist_base_scaled(dc)) << n;
+                n += deb;
+                it.v = v;
+                it.n = n;
+            }
+        }
+    } else if (i == n_hdr + n_sym) {
+        const uint32_t e = lit_lds[FL_EOB];
+        it.v = e & 0xffff;
+        it.n = e >> 16;
+    }
+    return it;
+}
+
+template <bool TOKENS>
+__global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __restrict__ in,
+                                                              const fl_chunk* __restrict__ chunks,
+                                                              const uint32_t* __restrict__ blk_chunk,
+                                                              const fl_block_plan* __restrict__ plans,
+                                                              const uint32_t* __restrict__ tokens /* [chunk][65536] */,
+                                                              uint32_t* __restrict__ out32) {
+    __shared__ uint32_t lit_lds[FL_NUM_LIT + 2];
+    __shared__ uint32_t dist_lds[FL_NUM_DIST + 2];
+    __shared__ uint32_t wave_bits[FL_ENC_WAVES];
+    __shared__ uint32_t stg[FL_ENC_WAVES][FL_STG_DW];
+
+    const uint32_t b = blockIdx.x;
+    const fl_block_plan* plan = &plans[b];
+    if (!plan->valid) return;
+    const uint32_t cidx = blk_chunk[b];
+    const fl_chunk ck = chunks[cidx];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t bit_off = plan->bit_off;
+    const uint8_t* src = in + ck.in_off;
+
+    if (plan->type == FL_BLOCK_STORED) {
+        // storedHeader + bytes (block_writer.zig:283-291, 385-388)
+        const uint32_t len = plan->in_len;
+        const uint64_t p = (bit_off + 3 + 7) >> 3;
+        if (tid == 0) {
+            if (plan->final_block) fl_atomic_or_bits(out32, bit_off, 1, 1);
+            const uint32_t lw = (len & 0xffff) | ((~len & 0xffff) << 16);
+            fl_atomic_or_bits(out32, p * 8, lw, 32);
+        }
+        fl_copy_bytes(out32, p + 4, src + plan->in_start, len, tid, 64 * FL_ENC_WAVES);
+        return;
+    }
+
+    for (uint32_t i = tid; i < FL_NUM_LIT; i += 64 * FL_ENC_WAVES)
+        lit_lds[i] = (uint32_t)plan->lit[i].code | ((uint32_t)plan->lit[i].len << 16);
+    if (tid < FL_NUM_DIST) dist_lds[tid] = (uint32_t)plan->dist[tid].code | ((uint32_t)plan->dist[tid].len << 16);
+    for (uint32_t i = lane; i < FL_STG_DW; i += 64) stg[wave][i] = 0;
+    __syncthreads();
+
+    const uint32_t hdr_nbits = plan->hdr_nbits;
+    const uint32_t n_hdr = (hdr_nbits + 7) >> 3;
+    const uint32_t n_sym = plan->tok_count;
+    const uint32_t n_items = n_hdr + n_sym + 1;
+    const uint8_t* bytes = src + plan->tok_start;
+    const uint32_t* toks = TOKENS ? tokens + (uint64_t)cidx * FL_CHUNK_STRIDE + plan->tok_start : nullptr;
+    const uint8_t* hdr = plan->hdr;
+
+    // contiguous item range of this wave, a multiple of 64 items
+    uint32_t per = (n_items + FL_ENC_WAVES - 1) / FL_ENC_WAVES;
+    per = (per + 63) & ~63u;
+    const uint32_t i0 = min(n_items, wave * per), i1 = min(n_items, i0 + per);
+
+    // pass 1: bits per wave
+    uint32_t nb = 0;
+    for (uint32_t i = i0 + lane; i < i1; i += 64)
+        nb += fl_block_item<TOKENS>(i, n_hdr, hdr_nbits, n_sym, hdr, bytes, toks, lit_lds, dist_lds).n;
+    nb = fl_wave_sum(nb);
+    if (lane == 0) wave_bits[wave] = nb;
+    __syncthreads();
+    uint64_t cur = bit_off;
+    for (uint32_t w = 0; w < wave; w++) cur += wave_bits[w];
+    if (i0 >= i1) return;
+
+    // pass 2: pack
+    const uint64_t first_dw = cur >> 5;
+    uint32_t* sw = stg[wave];
+    for (uint32_t ib = i0; ib < i1; ib += 64) {
+        const uint32_t i = ib + lane;
+        fl_item it;
+        it.v = 0;
+        it.n = 0;
+        if (i < i1) it = fl_block_item<TOKENS>(i, n_hdr, hdr_nbits, n_sym, hdr, bytes, toks, lit_lds, dist_lds);
+        const uint32_t incl = fl_wave_incl_scan(it.n, lane);
+        const uint32_t total = __shfl(incl, 63, 64);
+        const uint64_t base_dw = cur >> 5;
+        if (it.n) {
+            const uint32_t rel = (uint32_t)(cur - (base_dw << 5)) + (incl - it.n);
+            const uint32_t dw = rel >> 5, sh = rel & 31;
+            const uint64_t a = it.v << sh;
+            const uint32_t hi = sh ? (uint32_t)(it.v >> (64 - sh)) : 0u;
+            if ((uint32_t)a) atomicOr(&sw[dw], (uint32_t)a);
+            if ((uint32_t)(a >> 32)) atomicOr(&sw[dw + 1], (uint32_t)(a >> 32));
+            if (hi) atomicOr(&sw[dw + 2], hi);
+        }
+        fl_wave_lds_sync();
+        const uint64_t end = cur + total;
+        const uint32_t nd = (uint32_t)((end >> 5) - base_dw);  // complete dwords
+        for (uint32_t k = lane; k < nd; k += 64) {
+            const uint32_t v = sw[k];
+            if (base_dw + k == first_dw) {
+                if (v) atomicOr(&out32[base_dw + k], v);
+            } else {
+                out32[base_dw + k] = v;
+            }
+        }
+        const uint32_t carry = sw[nd];
+        fl_wave_lds_sync();
+        // clear the window, keep the partial dword as the new first one
+        for (uint32_t k = lane; k <= nd + 2 && k < FL_STG_DW; k += 64) sw[k] = 0;
+        fl_wave_lds_sync();
+        if (lane == 0) sw[0] = carry;
+        fl_wave_lds_sync();
+        cur = end;
+    }
+    if ((cur & 31) && lane == 0) {
+        const uint32_t v = sw[0];
+        if (v) atomicOr(&out32[cur >> 5], v);
+    }
+}

@@ -1,0 +1,520 @@
+// kernels_inflate.h -- batched inflate: one wavefront per independent stream.
+//
+// Reference path: Inflate.step / dynamicBlockHeader / dynamicBlock / fixedBlock /
+// storedBlock (inflate.zig:89-280), HuffmanDecoder (huffman_decoder.zig:71-175),
+// BitReader (bit_reader.zig:46-217), CircularBuffer.writeMatch (CircularBuffer.zig:44-75),
+// container parse (container.zig:111-166).  The status returned for a bad stream is
+// the error name the reference returns (pinned by its 40-case table, inflate.zig:487-527).
+//
+// The symbol decode of one stream is inherently serial: every lane of the wave runs
+// it in lock step (wave-uniform control flow), lane 0 owns the literal stores, and
+// the LZ77 copies and the checksum are spread over the 64 lanes.  Throughput comes
+// from many streams in flight (one per wave, several waves per CU).  Output goes
+// straight to the caller's buffer -- no 64 KiB ring as in the reference.
+#pragma once
+#include "kernels_common.h"
+
+struct fl_hdec {
+    uint16_t count[16];
+    uint16_t symbol[288];
+};
+
+struct fl_inflate_ws {
+    fl_hdec lit, dst, cl;
+    uint8_t lens[320];
+    uint8_t cl_lens[20];
+};
+
+struct fl_bitr {
+    const uint8_t* data;
+    uint64_t nbytes;
+    uint64_t total_bits;
+    uint64_t pos;   // bits consumed
+    uint64_t buf;   // bits [pos, pos + have), zero beyond the end of the stream
+    uint32_t have;
+};
+
+__device__ __forceinline__ void fl_br_refill(fl_bitr& r) {
+    while (r.have <= 56) {
+        const uint64_t byte = (r.pos + r.have) >> 3;
+        const uint64_t v = byte < r.nbytes ? r.data[byte] : 0;
+        r.buf |= v << r.have;
+        r.have += 8;
+    }
+}
+// bit_reader.zig:46-68: fill() fails only when no bit at all is left
+__device__ __forceinline__ int fl_br_fill(const fl_bitr& r, uint32_t nice) {
+    return (nice > 0 && r.pos >= r.total_bits) ? 1 : 0;  // EndOfStream
+}
+__device__ __forceinline__ uint32_t fl_br_peek(fl_bitr& r, uint32_t n) {  // n <= 32
+    fl_br_refill(r);
+    return (uint32_t)(r.buf & ((1ull << n) - 1));
+}
+// bit_reader.zig:159-163
+__device__ __forceinline__ int fl_br_shift(fl_bitr& r, uint32_t n) {
+    if (n > r.total_bits - r.pos) return 1;
+    fl_br_refill(r);
+    r.pos += n;
+    r.buf >>= n;
+    r.have -= n;
+    return 0;
+}
+__device__ __forceinline__ int fl_br_read(fl_bitr& r, uint32_t n, uint32_t& v) {  // readF(U, 0)
+    if (fl_br_fill(r, n)) return 1;
+    v = fl_br_peek(r, n);
+    return fl_br_shift(r, n);
+}
+__device__ __forceinline__ void fl_br_align(fl_bitr& r) {  // bit_reader.zig:189-192
+    const uint32_t k = (uint32_t)((8 - (r.pos & 7)) & 7);
+    if (k) {
+        fl_br_refill(r);
+        r.pos += k;
+        r.buf >>= k;
+        r.have -= k;
+    }
+}
+
+// huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order).  Runs on all
+// lanes redundantly except the LDS writes (lane 0).
+__device__ int fl_hdec_generate(fl_hdec* d, const uint8_t* lens, int n, int alphabet, int max_code_bits,
+                                uint32_t lane) {
+    if (alphabet == 286 && lens[256] == 0) return 10;  // MissingEndOfBlockCode
+    uint32_t cnt[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) cnt[i] = 0;
+    int mx = 0;
+    for (int i = 0; i < n; i++) {
+        const int l = lens[i];
+        if (l == 0) continue;
+        if (l > mx) mx = l;
+#pragma unroll
+        for (int k = 1; k < 16; k++)
+            if (k == l) cnt[k]++;
+    }
+    if (mx != 0) {
+        int left = 1;
+        for (int len = 1; len <= max_code_bits; len++) {
+            left <<= 1;
+            uint32_t cl = 0;
+#pragma unroll
+            for (int k = 1; k < 16; k++)
+                if (k == len) cl = cnt[k];
+            if ((int)cl > left) return 8;  // OversubscribedHuffmanTree
+            left -= (int)cl;
+        }
+        if (left > 0) {
+            if (!(max_code_bits > 7 && mx == (int)cnt[1])) return 9;  // IncompleteHuffmanTree
+        }
+    }
+    fl_wave_lds_sync();
+    if (lane == 0) {
+        uint16_t offs[17];
+        offs[1] = 0;
+        d->count[0] = 0;
+        for (int len = 1; len < 16; len++) {
+            uint32_t cl = 0;
+#pragma unroll
+            for (int k = 1; k < 16; k++)
+                if (k == len) cl = cnt[k];
+            d->count[len] = (uint16_t)cl;
+            offs[len + 1] = (uint16_t)(offs[len] + cl);
+        }
+        for (int i = 0; i < n; i++)
+            if (lens[i] != 0) d->symbol[offs[lens[i]]++] = (uint16_t)i;
+    }
+    fl_wave_lds_sync();
+    return 0;
+}
+
+// huffman_decoder.zig:156-175: the symbol whose code is a prefix of `peek`
+// (stream bit order), or InvalidCode.
+__device__ __forceinline__ int fl_hdec_find(const fl_hdec* d, uint32_t peek, int max_code_bits, uint32_t& sym,
+                                            uint32_t& code_bits) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= max_code_bits; len++) {
+        code |= (int)(peek & 1);
+        peek >>= 1;
+        const int count = d->count[len];
+        if (code - count < first) {
+            sym = d->symbol[index + (code - first)];
+            code_bits = (uint32_t)len;
+            return 0;
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return 7;  // InvalidCode
+}
+
+__device__ __forceinline__ uint32_t fl_rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
+
+struct fl_inf_out {
+    uint8_t* out;
+    uint64_t cap;
+    uint64_t wp;
+};
+
+// CircularBuffer.zig:44-75, spread over the wave
+__device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint32_t distance, uint32_t lane) {
+    if (o.wp < distance || length < 3 || length > 258 || distance < 1 || distance > 32768) return 11;
+    if (o.wp + length > o.cap) return 100;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier stores of this wave are visible
+    const uint8_t* from = o.out + o.wp - distance;
+    uint8_t* to = o.out + o.wp;
+    for (uint32_t i = lane; i < length; i += 64) to[i] = from[distance >= length ? i : (i % distance)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    o.wp += length;
+    return 0;
+}
+
+#define FL_TRY(expr)            \
+    do {                        \
+        const int rc_ = (expr); \
+        if (rc_) return rc_;    \
+    } while (0)
+
+// inflate.zig:123-140 (the caller has already filled)
+__device__ __forceinline__ int fl_inf_length(fl_bitr& r, uint32_t code, uint32_t& length) {
+    if (code > 28) return 7;
+    const uint32_t eb = fl_len_extra_bits(code);
+    length = fl_len_base_scaled(code) + 3;
+    if (eb) {
+        length += fl_br_peek(r, eb);
+        return fl_br_shift(r, eb);
+    }
+    return 0;
+}
+__device__ __forceinline__ int fl_inf_distance(fl_bitr& r, uint32_t code, uint32_t& distance) {
+    if (code > 29) return 7;
+    const uint32_t eb = fl_dist_extra_bits(code);
+    distance = fl_dist_base_scaled(code) + 1;
+    if (eb) {
+        distance += fl_br_peek(r, eb);
+        return fl_br_shift(r, eb);
+    }
+    return 0;
+}
+
+// inflate.zig:89-102
+__device__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
+    fl_br_align(r);
+    uint32_t len, nlen;
+    FL_TRY(fl_br_read(r, 16, len));
+    FL_TRY(fl_br_read(r, 16, nlen));
+    if (len != ((~nlen) & 0xffff)) return 13;
+    if ((uint64_t)len * 8 > r.total_bits - r.pos) return 1;
+    if (o.wp + len > o.cap) return 100;
+    const uint8_t* s = r.data + (r.pos >> 3);
+    for (uint32_t i = lane; i < len; i += 64) o.out[o.wp + i] = s[i];
+    o.wp += len;
+    r.pos += (uint64_t)len * 8;
+    r.buf = 0;
+    r.have = 0;
+    return 0;
+}
+
+// bit_reader.zig:205-217 + inflate.zig:104-121
+__device__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
+    for (;;) {
+        FL_TRY(fl_br_fill(r, 9));
+        const uint32_t code7 = fl_rev_bits(fl_br_peek(r, 7), 7);
+        FL_TRY(fl_br_shift(r, 7));
+        uint32_t code;
+        if (code7 <= 0x17) {
+            code = code7 + 256;
+        } else if (code7 <= 0x5f) {
+            const uint32_t e = fl_br_peek(r, 1);
+            FL_TRY(fl_br_shift(r, 1));
+            code = (code7 << 1) + e - 0x30;
+        } else if (code7 <= 0x63) {
+            const uint32_t e = fl_br_peek(r, 1);
+            FL_TRY(fl_br_shift(r, 1));
+            code = ((code7 - 0x60) << 1) + e + 280;
+        } else {
+            const uint32_t e = fl_rev_bits(fl_br_peek(r, 2), 2);
+            FL_TRY(fl_br_shift(r, 2));
+            code = ((code7 - 0x64) << 2) + e + 144;
+        }
+        if (code <= 255) {
+            if (o.wp >= o.cap) return 100;
+            if (lane == 0) o.out[o.wp] = (uint8_t)code;
+            o.wp++;
+        } else if (code == 256) {
+            return 0;
+        } else if (code <= 285) {
+            FL_TRY(fl_br_fill(r, 5 + 5 + 13));
+            uint32_t length, distance;
+            FL_TRY(fl_inf_length(r, code - 257, length));
+            const uint32_t dcode = fl_rev_bits(fl_br_peek(r, 5), 5);
+            FL_TRY(fl_br_shift(r, 5));
+            FL_TRY(fl_inf_distance(r, dcode, distance));
+            FL_TRY(fl_inf_match(o, length, distance, lane));
+        } else {
+            return 7;
+        }
+    }
+}
+
+// inflate.zig:188-216 + the read loops of :161-180
+__device__ int fl_inf_read_lens(fl_bitr& r, fl_inflate_ws* ws, uint32_t base, uint32_t lens_len, uint32_t want,
+                                uint32_t boundary, bool& crossed, uint32_t lane) {
+    uint32_t pos = 0;
+    uint8_t* lens = ws->lens + base;
+    while (pos < want) {
+        FL_TRY(fl_br_fill(r, 7));
+        uint32_t sym, cb;
+        FL_TRY(fl_hdec_find(&ws->cl, fl_br_peek(r, 7), 7, sym, cb));
+        FL_TRY(fl_br_shift(r, cb));
+        if (boundary && sym == 16 && pos == boundary) crossed = true;
+        if (pos >= lens_len) return 14;
+        uint32_t adv, v;
+        if (sym == 16) {
+            FL_TRY(fl_br_read(r, 2, v));
+            adv = v + 3;
+            if (pos == 0 || pos + adv > lens_len) return 14;
+            fl_wave_lds_sync();
+            const uint8_t prev = lens[pos - 1];
+            fl_wave_lds_sync();
+            if (lane == 0)
+                for (uint32_t i = 0; i < adv; i++) lens[pos + i] = prev;
+        } else if (sym == 17) {
+            FL_TRY(fl_br_read(r, 3, v));
+            adv = v + 3;
+        } else if (sym == 18) {
+            FL_TRY(fl_br_read(r, 7, v));
+            adv = v + 11;
+        } else {
+            if (lane == 0) lens[pos] = (uint8_t)sym;
+            adv = 1;
+        }
+        if (boundary && pos < boundary && pos + adv > boundary) crossed = true;
+        pos += adv;
+    }
+    if (pos > want) return 14;
+    return 0;
+}
+
+// inflate.zig:144-184.  flags bit0: reference-strict Q6 (two separate length lists).
+__device__ int fl_inf_dynamic_header(fl_bitr& r, fl_inflate_ws* ws, int flags, uint32_t lane) {
+    uint32_t v;
+    FL_TRY(fl_br_read(r, 5, v));
+    const uint32_t hlit = v + 257;
+    FL_TRY(fl_br_read(r, 5, v));
+    const uint32_t hdist = v + 1;
+    FL_TRY(fl_br_read(r, 4, v));
+    const uint32_t hclen = v + 4;
+    if (hlit > 286 || hdist > 30) return 14;
+    fl_wave_lds_sync();
+    if (lane < 20) ws->cl_lens[lane] = 0;
+    for (uint32_t i = lane; i < 320; i += 64) ws->lens[i] = 0;
+    fl_wave_lds_sync();
+    for (uint32_t i = 0; i < hclen; i++) {
+        FL_TRY(fl_br_read(r, 3, v));
+        if (lane == 0) ws->cl_lens[fl_codegen_order(i)] = (uint8_t)v;
+    }
+    fl_wave_lds_sync();
+    FL_TRY(fl_hdec_generate(&ws->cl, ws->cl_lens, 19, 19, 7, lane));
+    bool crossed = false;
+    int rc;
+    if (flags & 1) {
+        // literal lengths live at lens[0..286), distance lengths at lens[288..318)
+        FL_TRY(fl_inf_read_lens(r, ws, 0, 286, hlit, 0, crossed, lane));
+        FL_TRY(fl_inf_read_lens(r, ws, 288, 30, hdist, 0, crossed, lane));
+        fl_wave_lds_sync();
+        FL_TRY(fl_hdec_generate(&ws->lit, ws->lens, 286, 286, 15, lane));
+        FL_TRY(fl_hdec_generate(&ws->dst, ws->lens + 288, 30, 30, 15, lane));
+        return 0;
+    }
+    rc = fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane);
+    if (rc) return crossed ? 14 : rc;
+    fl_wave_lds_sync();
+    // split the single list: the literal decoder must see zeros in [hlit, 286)
+    uint8_t dl = 0;
+    if (lane < 30) dl = lane < hdist ? ws->lens[hlit + lane] : 0;
+    fl_wave_lds_sync();
+    for (uint32_t i = hlit + lane; i < 320; i += 64) ws->lens[i] = 0;
+    fl_wave_lds_sync();
+    if (lane < 30) ws->lens[288 + lane] = dl;
+    fl_wave_lds_sync();
+    rc = fl_hdec_generate(&ws->lit, ws->lens, 286, 286, 15, lane);
+    if (rc) return crossed ? 14 : rc;
+    rc = fl_hdec_generate(&ws->dst, ws->lens + 288, 30, 30, 15, lane);
+    if (rc) return crossed ? 14 : rc;
+    return 0;
+}
+
+// inflate.zig:220-249
+__device__ int fl_inf_dynamic(fl_bitr& r, fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+    for (;;) {
+        FL_TRY(fl_br_fill(r, 15));
+        uint32_t sym, cb;
+        FL_TRY(fl_hdec_find(&ws->lit, fl_br_peek(r, 15), 15, sym, cb));
+        FL_TRY(fl_br_shift(r, cb));
+        if (sym < 256) {
+            if (o.wp >= o.cap) return 100;
+            if (lane == 0) o.out[o.wp] = (uint8_t)sym;
+            o.wp++;
+        } else if (sym == 256) {
+            return 0;
+        } else {
+            FL_TRY(fl_br_fill(r, 5 + 15 + 13));
+            uint32_t length, distance, dsym;
+            FL_TRY(fl_inf_length(r, sym - 257, length));
+            FL_TRY(fl_hdec_find(&ws->dst, fl_br_peek(r, 15), 15, dsym, cb));
+            FL_TRY(fl_br_shift(r, cb));
+            FL_TRY(fl_inf_distance(r, dsym, distance));
+            FL_TRY(fl_inf_match(o, length, distance, lane));
+        }
+    }
+}
+
+// container.zig:119-152
+__device__ int fl_inf_header(fl_bitr& r, int container) {
+    uint32_t v;
+    if (container == 1) {
+        uint32_t m1, m2, method, flags;
+        FL_TRY(fl_br_read(r, 8, m1));
+        FL_TRY(fl_br_read(r, 8, m2));
+        FL_TRY(fl_br_read(r, 8, method));
+        FL_TRY(fl_br_read(r, 8, flags));
+        for (int i = 0; i < 6; i++) FL_TRY(fl_br_read(r, 8, v));
+        if (m1 != 0x1f || m2 != 0x8b || method != 0x08) return 2;
+        if (flags & 0x04) {
+            uint32_t xl;
+            FL_TRY(fl_br_read(r, 16, xl));
+            for (uint32_t i = 0; i < xl; i++) FL_TRY(fl_br_read(r, 8, v));
+        }
+        if (flags & 0x08) {
+            do {
+                FL_TRY(fl_br_read(r, 8, v));
+            } while (v != 0);
+        }
+        if (flags & 0x10) {
+            do {
+                FL_TRY(fl_br_read(r, 8, v));
+            } while (v != 0);
+        }
+        if (flags & 0x02) {
+            FL_TRY(fl_br_read(r, 8, v));
+            FL_TRY(fl_br_read(r, 8, v));
+        }
+    } else if (container == 2) {
+        uint32_t cm, cinfo;
+        FL_TRY(fl_br_read(r, 4, cm));
+        FL_TRY(fl_br_read(r, 4, cinfo));
+        FL_TRY(fl_br_read(r, 8, v));
+        if (cm != 8 || cinfo > 7) return 3;
+    }
+    return 0;
+}
+
+// CRC-32 of out[0..n) by the whole wave (container.zig:170, inflate.zig:330)
+__device__ uint32_t fl_wave_crc32(const uint8_t* p, uint64_t n, const fl_crc_consts& cc, uint32_t* tab /*256*/,
+                                  uint32_t lane) {
+    for (uint32_t t = lane; t < 256; t += 64) {
+        uint32_t c = t;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (FL_CRC_POLY ^ (c >> 1)) : (c >> 1);
+        tab[t] = c;
+    }
+    fl_wave_lds_sync();
+    const uint64_t per = (n + 63) / 64;
+    const uint64_t lo = min(n, lane * per), hi = min(n, lo + per);
+    uint32_t c = 0xffffffffu;
+    for (uint64_t i = lo; i < hi; i++) c = tab[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    c = hi > lo ? ~c : 0u;
+    c = fl_crc_mulmod(c, fl_crc_xpow8n(cc.xpow8, n - hi));
+    return fl_wave_xor(c);
+}
+// Adler-32 of out[0..n) by the whole wave
+__device__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n, uint32_t lane) {
+    const uint64_t per = (n + 63) / 64;
+    const uint64_t lo = min(n, lane * per), hi = min(n, lo + per);
+    uint32_t A = 0, B = 0;  // a = b = 0 start
+    uint64_t i = lo;
+    while (i < hi) {
+        const uint64_t e = min(hi, i + 5552);
+        for (; i < e; i++) {
+            A += p[i];
+            B += A;
+        }
+        A %= 65521u;
+        B %= 65521u;
+    }
+    const uint64_t after = (n - hi) % 65521u;
+    uint32_t Bm = (uint32_t)((B + (uint64_t)A * after) % 65521u);
+    const uint32_t Am = fl_wave_sum(A) % 65521u;
+    Bm = fl_wave_sum(Bm) % 65521u;
+    const uint32_t a = (1 + Am) % 65521u;
+    const uint32_t b = (uint32_t)((n % 65521u + Bm) % 65521u);
+    return a | (b << 16);
+}
+
+// One wave per stream.
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
+                                                int container, int flags, fl_crc_consts cc,
+                                                uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
+                                                int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
+    __shared__ fl_inflate_ws ws;
+    __shared__ uint32_t crc_tab[256];
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    const uint32_t lane = threadIdx.x;
+    if (ck.skip) return;
+    fl_bitr r;
+    r.data = in + ck.in_off;
+    r.nbytes = ck.in_len;
+    r.total_bits = (uint64_t)ck.in_len * 8;
+    r.pos = 0;
+    r.buf = 0;
+    r.have = 0;
+    fl_inf_out o;
+    o.out = out + ck.out_off;
+    o.cap = ck.out_cap;
+    o.wp = 0;
+
+    int rc = fl_inf_header(r, container);
+    while (rc == 0) {  // inflate.zig:251-280
+        uint32_t bfinal, btype;
+        if ((rc = fl_br_read(r, 1, bfinal))) break;
+        if ((rc = fl_br_read(r, 2, btype))) break;
+        if (btype == 2) {
+            if ((rc = fl_inf_dynamic_header(r, &ws, flags, lane))) break;
+            rc = fl_inf_dynamic(r, &ws, o, lane);
+        } else if (btype == 0) {
+            rc = fl_inf_stored(r, o, lane);
+        } else if (btype == 1) {
+            rc = fl_inf_fixed(r, o, lane);
+        } else {
+            rc = 12;  // InvalidBlockType
+        }
+        if (rc) break;
+        if (bfinal) {
+            fl_br_align(r);
+            // container.zig:154-166
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t v;
+            if (container == 1) {
+                const uint32_t crc = fl_wave_crc32(o.out, o.wp, cc, crc_tab, lane);
+                if ((rc = fl_br_read(r, 32, v))) break;
+                if (v != crc) {
+                    rc = 4;
+                    break;
+                }
+                if ((rc = fl_br_read(r, 32, v))) break;
+                if (v != (uint32_t)o.wp) rc = 5;
+            } else if (container == 2) {
+                const uint32_t ad = fl_wave_adler32(o.out, o.wp, lane);
+                if ((rc = fl_br_read(r, 32, v))) break;
+                if (v != __builtin_bswap32(ad)) rc = 6;
+            }
+            break;
+        }
+    }
+    if (lane == 0) {
+        out_len[c] = o.wp;
+        status[c] = rc;
+        if (consumed) consumed[c] = (r.pos + 7) >> 3;
+    }
+}

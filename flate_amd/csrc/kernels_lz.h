@@ -1,0 +1,441 @@
+// kernels_lz.h -- the LZ77 tokenizer of levels 4..9 on the GPU, for chunks of at
+// most 65535 bytes (no window slide inside a chunk: SlidingWindow.zig:36-44 is
+// never reached, deflate.zig:304-321 breaks out after the first short read).
+//
+// Reference path: Deflate.tokenize / findMatch (deflate.zig:154-266),
+// SlidingWindow.match (SlidingWindow.zig:81-104), Lookup (Lookup.zig:12-84).
+//
+// The reference walks a hash chain sequentially.  The chain content does not
+// depend on the parse: every position is inserted exactly once, in ascending
+// order (deflate.zig:207-211,236; Lookup.zig:55-72), so chain[p] is simply the
+// nearest earlier position with the same 15-bit hash.  That makes the whole
+// tokenizer data-parallel:
+//
+//   k_lz_sort   (1 wave / chunk)   stable LSD radix sort of the positions by hash:
+//                                  the candidates of a position are its predecessors
+//                                  in its bucket, nearest first.
+//   k_lz_match  (1 WG / chunk)     for EVERY position, the longest-match record the
+//                                  reference's findMatch would return, for the full
+//                                  chain budget and for chain >> 2 (deflate.zig:241-245),
+//                                  window staged in LDS.
+//   k_lz_parse  (1 WG / chunk)     the lazy-matching automaton (deflate.zig:154-205) as
+//                                  a function "anchor -> next anchor", resolved with
+//                                  pointer jumping instead of a serial walk; emits the
+//                                  token list, the per-block histograms and the block
+//                                  boundaries (32768 tokens, deflate.zig:227-230).
+//
+// Bounds: all three are latency/issue bound integer kernels over HBM-resident
+// scratch (the window itself is read once into LDS); no MFMA.
+#pragma once
+#include "kernels_common.h"
+
+// Lookup.zig:59-63,82-84: big-endian 4-byte word * 0x9E3779B1 >> 17
+__device__ __forceinline__ uint32_t fl_hash_le(uint32_t le_word) {
+    return (__builtin_bswap32(le_word) * 0x9E3779B1u) >> 17;
+}
+
+// peers of this lane: lanes (within `valid`) holding the same NB-bit digit
+template <int NB>
+__device__ __forceinline__ uint64_t fl_match_any(uint32_t d, uint64_t valid) {
+    uint64_t peers = valid;
+#pragma unroll
+    for (int bit = 0; bit < NB; bit++) {
+        const bool s = (d >> bit) & 1;
+        const uint64_t m = __ballot(s);
+        peers &= s ? m : ~m;
+    }
+    return peers;
+}
+
+// in-place exclusive scan of cnt[0..n) (n <= 256) by one wave
+__device__ __forceinline__ void fl_wave_excl_scan_lds(uint32_t* cnt, uint32_t n, uint32_t lane) {
+    const uint32_t per = (n + 63) / 64;  // <= 4
+    uint32_t v[4];
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = lane * per + k;
+        v[k] = i < n ? cnt[i] : 0;
+        s += v[k];
+    }
+    const uint32_t incl = fl_wave_incl_scan(s, lane);
+    uint32_t run = incl - s;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = lane * per + k;
+        if (i < n) cnt[i] = run;
+        run += v[k];
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_sort
+// S[c][0..M)  = positions 0..M-1 (M = in_len - 3: those with 4 bytes left,
+//               Lookup.zig:24) sorted by (hash, position)
+// SH[c][0..M) = their hashes.
+__global__ __launch_bounds__(64) void k_lz_sort(const uint8_t* __restrict__ in,
+                                                const fl_chunk* __restrict__ chunks, uint16_t* __restrict__ S,
+                                                uint16_t* __restrict__ SH, uint32_t* __restrict__ tmp_all) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t M = ck.in_len >= 4 ? ck.in_len - 3 : 0;
+    const uint8_t* src = in + ck.in_off;
+    uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint16_t* Ho = SH + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* tmp = tmp_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;  // aliases the chunk's record area
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+    // ---- pass 1: low 8 bits of the hash ----
+    for (uint32_t i = lane; i < 256; i += 64) cnt[i] = 0;
+    fl_wave_lds_sync();
+    for (uint32_t p = lane; p < M; p += 64) atomicAdd(&cnt[fl_hash_le(fl_load_u32_unaligned(src + p)) & 255], 1u);
+    fl_wave_lds_sync();
+    fl_wave_excl_scan_lds(cnt, 256, lane);
+    fl_wave_lds_sync();
+    for (uint32_t p0 = 0; p0 < M; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const bool valid = p < M;
+        const uint32_t h = valid ? fl_hash_le(fl_load_u32_unaligned(src + p)) : 0;
+        const uint32_t d = h & 255;
+        const uint64_t peers = fl_match_any<8>(d, __ballot(valid));
+        const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
+        if (valid) tmp[cnt[d] + rank] = (h << 16) | p;
+        fl_wave_lds_sync();
+        if (valid && rank == np - 1) cnt[d] += np;
+        fl_wave_lds_sync();
+    }
+    __threadfence_block();
+    // ---- pass 2: high 7 bits ----
+    for (uint32_t i = lane; i < 128; i += 64) cnt[i] = 0;
+    fl_wave_lds_sync();
+    for (uint32_t e = lane; e < M; e += 64) atomicAdd(&cnt[tmp[e] >> 24], 1u);
+    fl_wave_lds_sync();
+    fl_wave_excl_scan_lds(cnt, 128, lane);
+    fl_wave_lds_sync();
+    for (uint32_t e0 = 0; e0 < M; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool valid = e < M;
+        const uint32_t v = valid ? tmp[e] : 0;
+        const uint32_t h = v >> 16, d = h >> 8;
+        const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
+        const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
+        if (valid) {
+            const uint32_t dst = cnt[d] + rank;
+            So[dst] = (uint16_t)v;
+            Ho[dst] = (uint16_t)h;
+        }
+        fl_wave_lds_sync();
+        if (valid && rank == np - 1) cnt[d] += np;
+        fl_wave_lds_sync();
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_match
+#define FL_MATCH_WAVES 8
+#define FL_TILE 192  // 128 candidates back + 64 lanes
+
+__device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t off) {
+    const uint32_t i = off >> 2;
+    return __builtin_amdgcn_alignbyte(win32[i + 1], win32[i], off & 3);
+}
+
+// rec[c][2p]   = record for the full chain budget
+// rec[c][2p+1] = record for chain >> 2       (0 = no match, else len << 16 | dist-1)
+__global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t* __restrict__ in,
+                                                                  const fl_chunk* __restrict__ chunks,
+                                                                  fl_params prm, const uint16_t* __restrict__ S,
+                                                                  const uint16_t* __restrict__ SH,
+                                                                  uint32_t* __restrict__ rec_all) {
+    __shared__ uint32_t win32[16384 + 8];
+    __shared__ uint16_t tS[FL_MATCH_WAVES][FL_TILE];
+    __shared__ uint16_t tH[FL_MATCH_WAVES][FL_TILE];
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t N = ck.in_len;
+    const uint32_t M = N >= 4 ? N - 3 : 0;
+    const uint8_t* src = in + ck.in_off;
+    const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint16_t* Hc = SH + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
+
+    // stage the chunk in LDS (zero padded)
+    const uint32_t ndw = (N + 3) >> 2;
+    for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES) {
+        uint32_t w = 0;
+        if (i < ndw) {
+            w = fl_load_u32_unaligned(src + 4 * i);
+            const uint32_t rem = N - 4 * i;
+            if (rem < 4) w &= (1u << (8 * rem)) - 1;
+        }
+        win32[i] = w;
+    }
+    // positions without a hash entry never match (Lookup.zig:24)
+    for (uint32_t p = M + tid; p < N; p += 64 * FL_MATCH_WAVES) {
+        rec[2 * p] = 0;
+        rec[2 * p + 1] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
+    const uint32_t nbatch = (M + 63) >> 6;
+    uint16_t* ts = tS[wave];
+    uint16_t* th = tH[wave];
+    for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
+        const uint32_t i0 = batch << 6, i = i0 + lane;
+        const bool active = i < M;
+        const uint32_t p = active ? Sc[i] : 0;
+        const uint32_t h = active ? Hc[i] : 0xfffe;
+        const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
+        uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
+        bool done = !active;
+        for (uint32_t kb = 0; kb < chain; kb += 128) {
+            // tile = sorted entries [i0 - kb - 128, i0 - kb + 64)
+            for (uint32_t t = lane; t < FL_TILE; t += 64) {
+                const int32_t idx = (int32_t)i0 - (int32_t)kb - 128 + (int32_t)t;
+                const bool ok = idx >= 0 && idx < (int32_t)M;
+                ts[t] = ok ? Sc[idx] : 0;
+                th[t] = ok ? Hc[idx] : 0xffff;
+            }
+            fl_wave_lds_sync();
+            for (uint32_t kk = 1; kk <= 128; kk++) {
+                const uint32_t k = kb + kk;
+                if (k > chain) break;
+                if (!__any(!done)) break;
+                if (!done) {
+                    const uint32_t t = 128 + lane - kk;
+                    const uint32_t hq = th[t], q = ts[t];
+                    // end of the chain: other bucket, the null position 0 (deflate.zig:248), or
+                    // farther than the window (deflate.zig:250-251)
+                    if (hq != h || q == 0 || p - q > FL_MAX_DIST) {
+                        done = true;
+                    } else {
+                        bool cand = maxlen > best;
+                        if (cand && best >= 4)  // SlidingWindow.zig:91-98: the new byte must extend the best
+                            cand = fl_lds_load4(win32, p + best - 3) == fl_lds_load4(win32, q + best - 3);
+                        if (cand) {
+                            uint32_t len = 0;
+                            while (len < maxlen) {
+                                const uint32_t x = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
+                                if (x) {
+                                    len += (uint32_t)__builtin_ctz(x) >> 3;
+                                    break;
+                                }
+                                len += 4;
+                            }
+                            len = min(len, maxlen);
+                            if (len >= FL_MIN_MATCH && len > best) {  // deflate.zig:254
+                                best = len;
+                                bdist = p - q;
+                                if (k <= quarter) {
+                                    qbest = len;
+                                    qdist = bdist;
+                                }
+                                if (len >= nice) done = true;  // deflate.zig:256-258
+                            }
+                        }
+                    }
+                }
+            }
+            fl_wave_lds_sync();
+            if (!__any(!done)) break;
+        }
+        if (active) {
+            rec[2 * p] = best ? ((best << 16) | (bdist - 1)) : 0;
+            rec[2 * p + 1] = qbest ? ((qbest << 16) | (qdist - 1)) : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_parse
+// desc[p]: what an anchor at p emits.  0 = one literal, next anchor p + 1.
+// Otherwise bit31 | j << 23 | (len - 3) << 15 | dist - 1: j literals p .. p+j-1, then a
+// match (len, dist) at p + j; next anchor p + j + len.
+#define FL_PARSE_THREADS 1024
+
+__device__ __forceinline__ uint32_t fl_desc_next(uint32_t d, uint32_t p) {
+    if (!d) return p + 1;
+    return p + ((d >> 23) & 0xff) + ((d >> 15) & 0xff) + 3;
+}
+
+// deflate.zig:154-194 seen from a position visited with no pending match.
+__device__ __forceinline__ uint32_t fl_anchor_desc(const uint32_t* __restrict__ rec, uint32_t p, uint32_t good,
+                                                   uint32_t lazy) {
+    const uint32_t r = rec[2 * p];  // findMatch(pos, lh, 0): full budget
+    if (!r) return 0;
+    uint32_t len = r >> 16, dist0 = r & 0x7fff, j = 0, q = p;
+    while (len < lazy) {  // deflate.zig:171-178: keep the match, look one position further
+        const uint32_t r2 = rec[2 * (q + 1) + (len >= good ? 1 : 0)];  // deflate.zig:242-245
+        const uint32_t l2 = r2 >> 16;
+        if (l2 <= len) break;  // deflate.zig:182-184: no better match, the pending one goes out
+        len = l2;              // deflate.zig:166-168: better match, the pending one becomes a literal
+        dist0 = r2 & 0x7fff;
+        j++;
+        q++;
+    }
+    return 0x80000000u | (j << 23) | ((len - 3) << 15) | dist0;
+}
+
+struct fl_chunk_tok {
+    uint32_t ntok;
+};
+
+__global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ in,
+                                                                const fl_chunk* __restrict__ chunks,
+                                                                fl_params prm, const uint32_t* __restrict__ rec_all,
+                                                                uint32_t* __restrict__ desc_all,
+                                                                uint32_t* __restrict__ tokens_all,
+                                                                uint32_t* __restrict__ hist_all,
+                                                                fl_block_plan* __restrict__ plans,
+                                                                uint32_t* __restrict__ ntok_all) {
+    __shared__ uint16_t J[65536];
+    __shared__ uint32_t marks[2048];
+    __shared__ uint16_t entry[256];
+    __shared__ uint32_t hist[2][320];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t v1_sh;
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fl_block_plan* plan0 = &plans[ck.first_block];
+    fl_block_plan* plan1 = &plans[ck.first_block + 1];
+    if (ck.skip) {
+        if (tid == 0) {
+            plan0->valid = 0;
+            plan1->valid = 0;
+            ntok_all[c] = 0;
+        }
+        return;
+    }
+    const uint32_t N = ck.in_len;
+    const uint8_t* src = in + ck.in_off;
+    const uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
+    uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* tokens = tokens_all + (uint64_t)c * FL_CHUNK_STRIDE;
+
+    // (a) anchor function for every position
+    for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
+        const uint32_t d = fl_anchor_desc(rec, p, prm.good, prm.lazy);
+        desc[p] = d;
+        J[p] = (uint16_t)fl_desc_next(d, p);
+    }
+    for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) marks[i] = 0;
+    for (uint32_t i = tid; i < 640; i += FL_PARSE_THREADS) (&hist[0][0])[i] = 0;
+    if (tid < 256) entry[tid] = 0xffff;
+    if (tid == 0) v1_sh = N;
+    __syncthreads();
+    // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
+    // lies at or beyond the end of p's segment.  Racy reads only ever see a node further along
+    // the same path, so 8 rounds (2^8 = segment length) always suffice.
+    for (int round = 0; round < 8; round++) {
+        for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
+            const uint32_t seg_end = min((p | 255u) + 1u, N);
+            const uint32_t j = J[p];
+            if (j < seg_end) J[p] = J[j];
+        }
+        __syncthreads();
+    }
+    // (c) first anchor of every segment: at most 256 serial steps
+    if (tid == 0) {
+        uint32_t a = 0;
+        while (a < N) {
+            entry[a >> 8] = (uint16_t)a;
+            a = J[a];
+        }
+    }
+    __syncthreads();
+    // (d) restore the one-step pointers
+    for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) J[p] = (uint16_t)fl_desc_next(desc[p], p);
+    __syncthreads();
+    // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
+    if (tid < 256) {
+        uint32_t a = entry[tid];
+        const uint32_t end = min((tid + 1) << 8, N);
+        while (a < end) {
+            marks[a >> 5] |= 1u << (a & 31);
+            a = J[a];
+        }
+    }
+    __syncthreads();
+    // (f) token counts: thread t owns positions [64 t, 64 t + 64)
+    uint32_t cnt = 0;
+    for (int w = 0; w < 2; w++) {
+        uint32_t m = marks[2 * tid + w];
+        while (m) {
+            const uint32_t p = 64 * tid + 32 * w + (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t d = desc[p];
+            cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
+        }
+    }
+    const uint32_t incl = fl_wave_incl_scan(cnt, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - cnt;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+    }
+    // (g) emit tokens + histograms (block_writer.zig:455-462)
+    uint32_t idx = base;
+    for (int w = 0; w < 2; w++) {
+        uint32_t m = marks[2 * tid + w];
+        while (m) {
+            const uint32_t p = 64 * tid + 32 * w + (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t d = desc[p];
+            const uint32_t nl = d ? ((d >> 23) & 0xff) : 1;
+            for (uint32_t x = 0; x < nl; x++) {
+                const uint32_t byte = src[p + x];
+                tokens[idx] = FL_TOK_LIT(byte);
+                atomicAdd(&hist[idx >> 15][byte], 1u);
+                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
+                idx++;
+            }
+            if (d) {
+                const uint32_t ll = (d >> 15) & 0xff, d0 = d & 0x7fff;
+                tokens[idx] = (1u << 23) | (ll << 15) | d0;
+                atomicAdd(&hist[idx >> 15][257 + fl_len_index(ll)], 1u);
+                atomicAdd(&hist[idx >> 15][286 + fl_dist_code(d0)], 1u);
+                // a match of at least `lazy` goes out at its own visit, a shorter one at the next
+                // (deflate.zig:171-173 vs 182-184); rp at that moment decides the Q1 input slice
+                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+                idx++;
+            }
+        }
+    }
+    __syncthreads();
+    // (h) block boundaries (deflate.zig:227-230, 268-288) and histograms
+    const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
+    uint32_t* h0 = hist_all + (uint64_t)ck.first_block * 320;
+    for (uint32_t i = tid; i < 640; i += FL_PARSE_THREADS)
+        if (i < 320 * nblk) h0[i] = (&hist[0][0])[i];
+    if (tid == 0) {
+        ntok_all[c] = total;
+        const uint32_t v1 = v1_sh;
+        if (nblk == 1) {
+            plan0->valid = 1;
+            plan0->tok_start = 0;
+            plan0->tok_count = total;
+            plan0->in_start = 0;
+            plan0->in_len = N;
+            plan0->final_block = 1;
+            plan1->valid = 0;
+        } else {
+            plan0->valid = 1;
+            plan0->tok_start = 0;
+            plan0->tok_count = FL_MAX_TOKENS;
+            plan0->in_start = 0;
+            plan0->in_len = v1;
+            plan0->final_block = 0;
+            plan1->valid = 1;
+            plan1->tok_start = FL_MAX_TOKENS;
+            plan1->tok_count = total - FL_MAX_TOKENS;
+            plan1->in_start = v1;
+            plan1->in_len = N - v1;
+            plan1->final_block = 1;
+        }
+    }
+}

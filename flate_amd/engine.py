@@ -1,0 +1,149 @@
+"""Engine: one handle of the HIP DEFLATE engine on one device (one process per GPU).
+
+Host-buffer entry points (`compress_many`, `decompress_many`) take / return Python
+bytes; device entry points take raw device pointers (e.g. torch tensors'
+`data_ptr()`), keep everything resident in HBM and run on the caller's stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import FlateHipError, MEM_DEVICE, MEM_HOST
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._L = _capi.lib()
+        self._h = C.c_void_p()
+        rc = self._L.flate_hip_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise FlateHipError("flate_hip_create(device=%d) failed with %d: no usable MI355X / HIP device "
+                                "(there is no CPU fallback)" % (device, rc))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.flate_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            err = self._L.flate_hip_last_error(self._h).decode()
+            raise FlateHipError("%s failed with %d (%s)" % (what, rc, err))
+
+    # ---- configuration ----
+    def set_stream(self, stream_ptr):
+        self._L.flate_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0))
+
+    def set_sync(self, flag):
+        self._L.flate_hip_set_sync(self._h, int(bool(flag)))
+
+    def compress_bound(self, n, container=0, mode=6):
+        return self._L.flate_hip_compress_bound(int(n), container, mode)
+
+    # ---- host buffers ----
+    def compress_many(self, chunks, container=0, mode=6):
+        """chunks: sequence of bytes-like.  Returns (list of bytes, list of status codes)."""
+        n = len(chunks)
+        if n == 0:
+            return [], []
+        lens = np.array([len(c) for c in chunks], dtype=np.uint64)
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=in_off[1:])
+        blob = np.frombuffer(b"".join(bytes(c) for c in chunks), dtype=np.uint8)
+        if blob.size == 0:
+            blob = np.zeros(1, dtype=np.uint8)
+        caps = np.array([(self.compress_bound(int(l), container, mode) + 7) & ~7 for l in lens], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        out = np.zeros(int(out_off[-1]) + 8, dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        rc = self._L.flate_hip_compress_batch(self._h, blob.ctypes.data, in_off.ctypes.data, n, container, mode,
+                                              out.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                                              status.ctypes.data, MEM_HOST)
+        self._check(rc, "flate_hip_compress_batch")
+        res = [out[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
+        return res, [int(s) for s in status]
+
+    def decompress_many(self, streams, container=0, flags=0, caps=None):
+        """streams: sequence of bytes-like.  caps: output capacity per stream (default: generous guess).
+        Returns (list of bytes, list of status codes, list of consumed input bytes)."""
+        n = len(streams)
+        if n == 0:
+            return [], [], []
+        lens = np.array([len(c) for c in streams], dtype=np.uint64)
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=in_off[1:])
+        blob = np.frombuffer(b"".join(bytes(c) for c in streams), dtype=np.uint8)
+        if blob.size == 0:
+            blob = np.zeros(1, dtype=np.uint8)
+        if caps is None:
+            caps = [max(1 << 16, int(l) * 1100 + 1024) for l in lens]
+        caps = np.array([(int(c) + 7) & ~7 for c in caps], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        out = np.zeros(int(out_off[-1]) + 8, dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        consumed = np.zeros(n, dtype=np.uint64)
+        rc = self._L.flate_hip_decompress_batch(self._h, blob.ctypes.data, in_off.ctypes.data, n, container, flags,
+                                                out.ctypes.data, out_off.ctypes.data, out_len.ctypes.data,
+                                                status.ctypes.data, consumed.ctypes.data, MEM_HOST)
+        self._check(rc, "flate_hip_decompress_batch")
+        res = [out[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
+        return res, [int(s) for s in status], [int(c) for c in consumed]
+
+    # ---- device buffers (raw pointers; everything already in HBM) ----
+    def compress_device(self, in_ptr, in_off_ptr, n_chunks, container, mode, out_ptr, out_off_ptr, out_len_ptr,
+                        status_ptr):
+        rc = self._L.flate_hip_compress_batch(self._h, in_ptr, in_off_ptr, n_chunks, container, mode, out_ptr,
+                                              out_off_ptr, out_len_ptr, status_ptr, MEM_DEVICE)
+        self._check(rc, "flate_hip_compress_batch")
+
+    def decompress_device(self, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr, out_off_ptr, out_len_ptr,
+                          status_ptr, consumed_ptr=None):
+        rc = self._L.flate_hip_decompress_batch(self._h, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr,
+                                                out_off_ptr, out_len_ptr, status_ptr, consumed_ptr, MEM_DEVICE)
+        self._check(rc, "flate_hip_decompress_batch")
+
+    # ---- measurement / test seams ----
+    def profile_enable(self, flag=True):
+        self._L.flate_hip_profile_enable(self._h, int(bool(flag)))
+
+    def profile_reset(self):
+        self._L.flate_hip_profile_reset(self._h)
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)}"""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_uint64 * cap)()
+        n = self._L.flate_hip_profile_read(self._h, names, ms, cnt, cap)
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(max(n, 0))}
+
+    def debug_tokens(self, chunk):
+        """Token list the tokenizer kernels produced for `chunk` of the last level 4..9 call."""
+        buf = np.zeros(65536, dtype=np.uint32)
+        n = self._L.flate_hip_debug_tokens(self._h, int(chunk), buf.ctypes.data, buf.size)
+        if n < 0:
+            raise FlateHipError("flate_hip_debug_tokens failed with %d" % n)
+        return buf[:n].copy()
+
+
+_default = None
+
+
+def default_engine():
+    global _default
+    if _default is None:
+        _default = Engine(0)
+    return _default

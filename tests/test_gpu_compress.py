@@ -1,0 +1,191 @@
+"""GPU parity tests of the compress path: HIP output == CPU oracle output, byte for
+byte (integer/byte work: the bar is bit-exact), through the C ABI."""
+import io
+import json
+import os
+import zlib as pyzlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import GOLDEN, golden
+from gpu_util import engine
+
+pytestmark = pytest.mark.gpu
+
+WBITS = {0: -15, 1: 31, 2: 15}
+
+
+def _rng_cases():
+    rng = np.random.default_rng(2024)
+    from flate_amd import synth
+    cases = {
+        "empty": b"",
+        "one": b"a",
+        "three": b"abc",
+        "four": b"abcd",
+        "blah": b"Blah blah blah blah blah!",
+        "abcde": b"ABCDEABCD ABCDEABCD",
+        "zeros262": bytes(262),
+        "zeros263": bytes(263),
+        "zeros65535": bytes(65535),
+        "rfc": golden("rfc1951.txt"),
+        "text64k": synth.text(synth.SEED_TEXT, 65535).tobytes(),
+        "text_odd": synth.text(synth.SEED_TEXT + 1, 40001).tobytes(),
+        "rand1k": rng.integers(0, 256, 1000, dtype=np.uint8).tobytes(),
+        "rand65535": rng.integers(0, 256, 65535, dtype=np.uint8).tobytes(),
+        "noise4": rng.integers(97, 101, 65535, dtype=np.uint8).tobytes(),
+        "period16": (bytes(range(16)) * 5000)[:65535],
+        "sparse": bytes(b if (i % 97 == 0) else 0 for i, b in enumerate(rng.integers(0, 256, 50000, dtype=np.uint8))),
+        "pi": golden("block_writer", "huffman-pi.input"),
+        "shifts": golden("block_writer", "huffman-shifts.input"),
+    }
+    return cases
+
+
+CASES = _rng_cases()
+
+
+def test_tokenizer_matches_oracle_tokens():
+    eng = engine()
+    names = list(CASES)
+    for level in (4, 5, 6, 7, 8, 9):
+        outs, st = eng.compress_many([CASES[n] for n in names], O.RAW, level)
+        assert st == [0] * len(names)
+        for i, n in enumerate(names):
+            want = O.tokenize(CASES[n], level)
+            got = eng.debug_tokens(i)
+            assert len(got) == len(want), (n, level, len(got), len(want))
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (n, level, int(bad[0]), O.tok_decode(got[bad[0]]), O.tok_decode(want[bad[0]]))
+
+
+@pytest.mark.parametrize("container", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 4, 6, 9])
+def test_bytes_match_oracle(container, mode):
+    eng = engine()
+    names = list(CASES)
+    outs, st = eng.compress_many([CASES[n] for n in names], container, mode)
+    assert st == [0] * len(names)
+    for n, got in zip(names, outs):
+        want = O.compress(CASES[n], container, mode)
+        assert got == want, (n, container, mode, len(got), len(want))
+        assert pyzlib.decompress(got, WBITS[container]) == CASES[n]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_simple_modes_multi_block_streams(mode):
+    # huffman-only / store-only streams longer than one 65535-byte block, incl. the exact
+    # multiples that end with an empty final block (Q5, deflate.zig:498-511 + 480-484)
+    eng = engine()
+    from flate_amd import synth
+    base = synth.silesia_like(synth.SEED_SILESIA, 3 * 65535 + 777).tobytes()
+    datas = [base, base[:65535], base[:2 * 65535], base[:65536], base[100:100 + 200000]]
+    for container in (0, 1, 2):
+        outs, st = eng.compress_many(datas, container, mode)
+        assert st == [0] * len(datas)
+        for d, got in zip(datas, outs):
+            assert got == O.compress(d, container, mode)
+
+
+def test_reference_goldens_through_the_gpu():
+    # block_writer.zig:599-706: a chunk whose tokens / bytes are the golden case must yield the
+    # golden block (BFINAL set, the stream being a single final block)
+    eng = engine()
+    with open(os.path.join(GOLDEN, "block_writer_tokens.json")) as f:
+        cases = json.load(f)
+    names = [c["input"] for c in cases if c["input"]] + ["huffman-rand-max.input"]
+    datas = [golden("block_writer", n) for n in names]
+    outs, st = eng.compress_many(datas, 0, 1)
+    assert st == [0] * len(datas)
+    for n, got in zip(names, outs):
+        want = bytearray(golden("block_writer", n.replace(".input", ".huff.expect")))
+        want[0] |= 1
+        assert got == bytes(want), n
+
+
+def test_known_answer_sizes_and_config1_vector(rfc1951):
+    # flate.zig:101-124 (sizes) through the GPU; rfc1951.txt is 36944 bytes: one chunk
+    eng = engine()
+    sizes = {4: 11513, 5: 11217, 6: 11139, 7: 11126, 8: 11122, 9: 11119}
+    for level, gz in sizes.items():
+        outs, st = eng.compress_many([rfc1951], 1, level)
+        assert st == [0] and len(outs[0]) == gz
+    outs, _ = eng.compress_many([rfc1951], 1, 1)
+    assert len(outs[0]) == 20287
+    outs, _ = eng.compress_many([rfc1951], 1, 0)
+    assert len(outs[0]) == 36967
+    # deflate.zig:721-748
+    outs, _ = eng.compress_many([b"Hello world!", b"Hello world!"], 0, 0)
+    assert outs[0] == bytes([1, 0xC, 0, 0xF3, 0xFF]) + b"Hello world!"
+    outs, _ = eng.compress_many([b"Hello world!"], 0, 1)
+    assert outs[0] == bytes([1, 0xC, 0, 0xF3, 0xFF]) + b"Hello world!"
+
+
+def test_q1_token_flush_input_slice():
+    # 32768th token is a match -> the stored/huffman decision of the two
+    # blocks sees the reference's (shifted) input slices.  Whatever the reference does, we do.
+    eng = engine()
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 32767, dtype=np.uint8).tobytes()
+    rep = a[100:140]
+    tail = (b"compressible tail " * 2000)[:30000]
+    datas = [a + rep + tail, a + a[:20] + tail, a[:32766] + rep + tail, a[:32768] + tail]
+    for level in (4, 6, 9):
+        outs, st = eng.compress_many(datas, 0, level)
+        assert st == [0] * len(datas)
+        for d, got in zip(datas, outs):
+            assert got == O.compress(d, 0, level)
+
+
+def test_chunk_too_large_is_reported_not_hidden():
+    eng = engine()
+    outs, st = eng.compress_many([bytes(65536), b"ok"], 0, 6)
+    assert st[0] == 101 and outs[0] == b""
+    assert st[1] == 0 and outs[1] == O.compress(b"ok", 0, 6)
+
+
+def test_output_too_small_status():
+    import ctypes as C
+    eng = engine()
+    from flate_amd import _capi
+    data = np.frombuffer(os.urandom(5000), dtype=np.uint8)
+    in_off = np.array([0, 5000], dtype=np.uint64)
+    out_off = np.array([0, 100], dtype=np.uint64)
+    out = np.zeros(128, dtype=np.uint8)
+    out_len = np.zeros(1, dtype=np.uint64)
+    status = np.zeros(1, dtype=np.int32)
+    rc = _capi.lib().flate_hip_compress_batch(eng._h, data.ctypes.data, in_off.ctypes.data, 1, 0, 6, out.ctypes.data,
+                                              out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data, 0)
+    assert rc == 0 and status[0] == 100 and out_len[0] == 0
+
+
+def test_api_mirror_roundtrip():
+    # flate.zig:356-481 "public interface": the same calls, through the Python mirror
+    engine()
+    from flate_amd import flate, gzip, zlib
+    plain = b"Hello world\n"
+    block = bytes([0x01, 0x0C, 0x00, 0xF3, 0xFF]) + plain
+    gz = bytes([0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0x03]) + block + bytes([0xD5, 0xE0, 0x39, 0xB7, 0x0C, 0, 0, 0])
+    zl = bytes([0x78, 0x9C]) + block + bytes([0x1C, 0xF2, 0x04, 0x47])
+    for pkg, blob in ((gzip, gz), (zlib, zl), (flate, block)):
+        w = io.BytesIO()
+        pkg.decompress(io.BytesIO(blob), w)
+        assert w.getvalue() == plain
+        w = io.BytesIO()
+        pkg.store.compress(io.BytesIO(plain), w)
+        assert w.getvalue() == blob
+        for comp in (lambda r, w_: pkg.compress(r, w_, pkg.Options()), pkg.huffman.compress, pkg.store.compress):
+            c = io.BytesIO()
+            comp(io.BytesIO(plain), c)
+            w = io.BytesIO()
+            pkg.decompress(io.BytesIO(c.getvalue()), w)
+            assert w.getvalue() == plain
+        c = io.BytesIO()
+        cmp = pkg.compressor(c, pkg.Options(level=pkg.Level.best))
+        cmp.write(plain[:5])
+        cmp.write(plain[5:])
+        cmp.finish()
+        d = pkg.decompressor(io.BytesIO(c.getvalue()))
+        assert d.reader().read() == plain
