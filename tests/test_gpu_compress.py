@@ -99,10 +99,16 @@ def test_reference_goldens_through_the_gpu():
     datas = [golden("block_writer", n) for n in names]
     outs, st = eng.compress_many(datas, 0, 1)
     assert st == [0] * len(datas)
-    for n, got in zip(names, outs):
+    for n, d, got in zip(names, datas, outs):
         want = bytearray(golden("block_writer", n.replace(".input", ".huff.expect")))
-        want[0] |= 1
-        assert got == bytes(want), n
+        if len(d) % 65535 == 0:
+            # a full 65535-byte buffer is written as a non-final block and followed by an
+            # empty final block (Q5, deflate.zig:498-511 + 480-484)
+            assert got[:len(want) - 1] == bytes(want[:-1]), n
+            assert got == O.compress(d, 0, 1), n
+        else:
+            want[0] |= 1
+            assert got == bytes(want), n
 
 
 def test_known_answer_sizes_and_config1_vector(rfc1951):
