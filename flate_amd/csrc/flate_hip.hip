@@ -30,10 +30,12 @@ enum KernelId {
     K_OFFSETS,
     K_ENCODE,
     K_INFLATE,
+    K_GATHER,
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_parse", "k_plan",      "k_offsets",  "k_encode",  "k_inflate"};
+                                           "k_lz_parse", "k_plan",      "k_offsets",  "k_encode",  "k_inflate",
+                                           "k_gather"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -543,6 +545,23 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     } else if (h->sync) {
         HIP_OK(h, hipStreamSynchronize(st));
     }
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint64_t* out_off, const uint64_t* out_len,
+                             uint32_t n_chunks, uint8_t* dst, uint64_t* dst_off) {
+    if (!h || !out || !out_off || !out_len || !dst || !dst_off) return FLATE_HIP_E_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    hipStream_t st = h->stream;
+    {
+        ProfScope ps(h, K_GATHER);
+        hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, st, out_len, n_chunks, dst_off);
+        if (n_chunks)
+            hipLaunchKernelGGL(k_gather_copy, dim3(n_chunks), dim3(256), 0, st, out, out_off, out_len, dst,
+                               (const uint64_t*)dst_off);
+    }
+    HIP_OK(h, hipGetLastError());
+    if (h->sync) HIP_OK(h, hipStreamSynchronize(st));
     return FLATE_HIP_OK;
 }
 

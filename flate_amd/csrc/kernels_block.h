@@ -530,3 +530,52 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
         if (v) atomicOr(&out32[cur >> 5], v);
     }
 }
+
+// ------------------------------------------------------------------ packing
+// dst_off = exclusive scan of out_len (one workgroup; n is at most a few 100k)
+__global__ __launch_bounds__(1024) void k_scan_lens(const uint64_t* __restrict__ len, uint32_t n,
+                                                    uint64_t* __restrict__ dst_off) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint64_t v = i < n ? len[i] : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint64_t off = carry;
+        for (uint32_t w = 0; w < wave; w++) off += wsum[w];
+        if (i < n) dst_off[i] = off + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = off + inc;
+        __syncthreads();
+    }
+    if (tid == 0) dst_off[n] = carry;
+}
+
+// one workgroup per stream: interior destination dwords from unaligned source loads,
+// the (at most 3 + 3) edge bytes one by one -- neighbouring streams never share a byte.
+__global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__ out,
+                                                     const uint64_t* __restrict__ out_off,
+                                                     const uint64_t* __restrict__ out_len,
+                                                     uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off) {
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint64_t n = out_len[c];
+    const uint8_t* s = out + out_off[c];
+    uint8_t* d = dst + dst_off[c];
+    const uint64_t head = min(n, (uint64_t)((4 - ((uintptr_t)d & 3)) & 3));
+    if (tid < head) d[tid] = s[tid];
+    const uint64_t ndw = (n - head) >> 2;
+    uint32_t* d32 = (uint32_t*)(d + head);
+    for (uint64_t i = tid; i < ndw; i += 256) d32[i] = fl_load_u32_unaligned(s + head + 4 * i);
+    const uint64_t tail0 = head + 4 * ndw;
+    if (tail0 + tid < n) d[tail0 + tid] = s[tail0 + tid];
+}

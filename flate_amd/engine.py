@@ -114,6 +114,12 @@ class Engine:
                                                 out_off_ptr, out_len_ptr, status_ptr, consumed_ptr, MEM_DEVICE)
         self._check(rc, "flate_hip_decompress_batch")
 
+    def gather_streams_device(self, out_ptr, out_off_ptr, out_len_ptr, n_chunks, dst_ptr, dst_off_ptr):
+        """Pack the produced streams back to back in device memory (dst_off gets n_chunks + 1 entries)."""
+        rc = self._L.flate_hip_gather_streams(self._h, out_ptr, out_off_ptr, out_len_ptr, n_chunks, dst_ptr,
+                                              dst_off_ptr)
+        self._check(rc, "flate_hip_gather_streams")
+
     # ---- measurement / test seams ----
     def profile_enable(self, flag=True):
         self._L.flate_hip_profile_enable(self._h, int(bool(flag)))

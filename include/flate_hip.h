@@ -130,6 +130,17 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
                                const uint64_t* out_off, uint64_t* out_len, int32_t* status,
                                uint64_t* consumed, int memkind);
 
+/*
+ * Pack the n_chunks produced streams back to back (device memory only): copies
+ * out[out_off[i] .. out_off[i] + out_len[i]) to dst[dst_off[i] ..) with
+ * dst_off[i] = sum of out_len[k] for k < i; dst_off has n_chunks + 1 entries (the last
+ * one is the packed size).  This is the "reassemble the output bitstream" step that
+ * precedes the RCCL all-gather of a sharded job; the Zig writer of the reference does
+ * the same thing implicitly by writing streams one after another.
+ */
+int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint64_t* out_off,
+                             const uint64_t* out_len, uint32_t n_chunks, uint8_t* dst, uint64_t* dst_off);
+
 const char* flate_hip_status_name(int status);
 const char* flate_hip_last_error(flate_hip_handle h);
 const char* flate_hip_version(void);

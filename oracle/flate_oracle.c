@@ -184,25 +184,33 @@ typedef struct {
 static void bw_write_bits(bitw_t* w, uint32_t b, uint32_t nb) {
     w->bits |= (uint64_t)b << w->nbits;
     w->nbits += nb;
-    while (w->nbits >= 8) {
-        uint8_t byte = (uint8_t)w->bits;
-        sink_write(w->out, &byte, 1);
-        w->bits >>= 8;
-        w->nbits -= 8;
+    if (w->nbits >= 32) { /* spill 4 whole bytes at a time (the reference spills 6, :66-78) */
+        fo_sink* s = w->out;
+        if (s->len + 4 > s->cap) sink_reserve(s, 4);
+        uint32_t v = (uint32_t)w->bits;
+        s->data[s->len] = (uint8_t)v;
+        s->data[s->len + 1] = (uint8_t)(v >> 8);
+        s->data[s->len + 2] = (uint8_t)(v >> 16);
+        s->data[s->len + 3] = (uint8_t)(v >> 24);
+        s->len += 4;
+        w->bits >>= 32;
+        w->nbits -= 32;
     }
 }
 /* bit_writer.zig:46-61 */
 static void bw_flush(bitw_t* w) {
-    if (w->nbits != 0) {
+    while (w->nbits != 0) {
         uint8_t byte = (uint8_t)w->bits;
         sink_write(w->out, &byte, 1);
+        w->bits >>= 8;
+        w->nbits = w->nbits > 8 ? w->nbits - 8 : 0;
     }
     w->bits = 0;
-    w->nbits = 0;
 }
 /* bit_writer.zig:81-97 (UnfinishedBits cannot happen: callers flush first) */
 static void bw_write_bytes(bitw_t* w, const uint8_t* p, size_t n) {
     if (w->nbits & 7) abort();
+    bw_flush(w); /* whole buffered bytes first (bit_writer.zig:86-91) */
     sink_write(w->out, p, n);
 }
 
