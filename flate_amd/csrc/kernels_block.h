@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
             if ((uint32_t)(a >> 32)) atomicOr(&sw[dw + 1], (uint32_t)(a >> 32));
             if (hi) atomicOr(&sw[dw + 2], hi);
         }
-        fl_wave_lds_sync();
+        fl_lds_order();
         const uint64_t end = cur + total;
         const uint32_t nd = (uint32_t)((end >> 5) - base_dw);  // complete dwords
         for (uint32_t k = lane; k < nd; k += 64) {
@@ -517,12 +517,12 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
             }
         }
         const uint32_t carry = sw[nd];
-        fl_wave_lds_sync();
+        fl_lds_order();
         // clear the window, keep the partial dword as the new first one
         for (uint32_t k = lane; k <= nd + 2 && k < FL_STG_DW; k += 64) sw[k] = 0;
-        fl_wave_lds_sync();
+        fl_lds_order();
         if (lane == 0) sw[0] = carry;
-        fl_wave_lds_sync();
+        fl_lds_order();
         cur = end;
     }
     if ((cur & 31) && lane == 0) {

@@ -75,6 +75,15 @@ __device__ __forceinline__ void fl_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Order this wave's LDS accesses (cross-lane hand-off through LDS inside one wave).  The
+// LDS unit executes one wave's DS instructions in issue order, so no wait is needed --
+// only the compiler must not reorder across the hand-off.  Unlike fl_wave_lds_sync this
+// does not drain outstanding global stores.
+__device__ __forceinline__ void fl_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // little-endian 32-bit load from an arbitrarily aligned global address
 __device__ __forceinline__ uint32_t fl_load_u32_unaligned(const uint8_t* p) {
     const uintptr_t a = (uintptr_t)p;

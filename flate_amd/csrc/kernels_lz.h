@@ -67,72 +67,140 @@ __device__ __forceinline__ void fl_wave_excl_scan_lds(uint32_t* cnt, uint32_t n,
 }
 
 // ------------------------------------------------------------------ k_lz_sort
-// S[c][0..M)  = positions 0..M-1 (M = in_len - 3: those with 4 bytes left,
-//               Lookup.zig:24) sorted by (hash, position)
-// SH[c][0..M) = their hashes.
+// One wave per chunk.  Output, sorted by (hash, position):
+//   S[c][0..M)   positions 0..M-1 (M = in_len - 3: those with 4 bytes left, Lookup.zig:24)
+//   W0[c][0..M)  bytes p .. p+3 of each (little endian) -- the hash is a function of these
+//   W1[c][0..M)  bytes p+4 .. p+7, zero beyond the end of the chunk
+// The two prefix words let the match kernel settle most candidates (match length < 8)
+// without touching the window at all.
+#define FL_SORT_UNROLL 4
+
+__device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint32_t p, uint32_t N) {
+    // bytes p..p+3 of the chunk, zero beyond N.  Touches only aligned dwords that contain at
+    // least one valid byte: never another chunk's bytes in the key, never memory past the buffer.
+    if (p >= N) return 0;
+    const uint32_t nb = min(N - p, 4u);
+    const uintptr_t a = (uintptr_t)(src + p);
+    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t lo = w[0];
+    const uint32_t hi = (sh + nb > 4) ? w[1] : 0u;
+    uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    if (nb < 4) v &= (1u << (8 * nb)) - 1;
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_lz_sort(const uint8_t* __restrict__ in,
                                                 const fl_chunk* __restrict__ chunks, uint16_t* __restrict__ S,
-                                                uint16_t* __restrict__ SH, uint32_t* __restrict__ tmp_all) {
+                                                uint32_t* __restrict__ W0, uint32_t* __restrict__ W1,
+                                                uint32_t* __restrict__ tmp_all) {
     __shared__ uint32_t cnt[256];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
     const uint32_t lane = threadIdx.x;
-    const uint32_t M = ck.in_len >= 4 ? ck.in_len - 3 : 0;
+    const uint32_t N = ck.in_len;
+    const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint16_t* Ho = SH + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* W0o = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* W1o = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* tmp = tmp_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;  // aliases the chunk's record area
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
     // ---- pass 1: low 8 bits of the hash ----
     for (uint32_t i = lane; i < 256; i += 64) cnt[i] = 0;
-    fl_wave_lds_sync();
-    for (uint32_t p = lane; p < M; p += 64) atomicAdd(&cnt[fl_hash_le(fl_load_u32_unaligned(src + p)) & 255], 1u);
-    fl_wave_lds_sync();
-    fl_wave_excl_scan_lds(cnt, 256, lane);
-    fl_wave_lds_sync();
-    for (uint32_t p0 = 0; p0 < M; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        const bool valid = p < M;
-        const uint32_t h = valid ? fl_hash_le(fl_load_u32_unaligned(src + p)) : 0;
-        const uint32_t d = h & 255;
-        const uint64_t peers = fl_match_any<8>(d, __ballot(valid));
-        const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-        if (valid) tmp[cnt[d] + rank] = (h << 16) | p;
-        fl_wave_lds_sync();
-        if (valid && rank == np - 1) cnt[d] += np;
-        fl_wave_lds_sync();
+    fl_lds_order();
+    for (uint32_t p0 = 0; p0 < M; p0 += 64 * FL_SORT_UNROLL) {
+        uint32_t w[FL_SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++)
+            if (p0 + 64 * u + lane < M) atomicAdd(&cnt[fl_hash_le(w[u]) & 255], 1u);
     }
-    __threadfence_block();
+    fl_lds_order();
+    fl_wave_excl_scan_lds(cnt, 256, lane);
+    fl_lds_order();
+    for (uint32_t p0 = 0; p0 < M; p0 += 64 * FL_SORT_UNROLL) {
+        uint32_t w[FL_SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            const bool valid = p < M;
+            const uint32_t h = fl_hash_le(w[u]);
+            const uint32_t d = h & 255;
+            const uint64_t peers = fl_match_any<8>(d, __ballot(valid));
+            const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
+            if (valid) tmp[cnt[d] + rank] = (h << 16) | p;
+            fl_lds_order();
+            if (valid && rank == np - 1) cnt[d] += np;
+            fl_lds_order();
+        }
+    }
+    __threadfence_block();  // pass 2 reads what other lanes of this wave stored
     // ---- pass 2: high 7 bits ----
     for (uint32_t i = lane; i < 128; i += 64) cnt[i] = 0;
-    fl_wave_lds_sync();
-    for (uint32_t e = lane; e < M; e += 64) atomicAdd(&cnt[tmp[e] >> 24], 1u);
-    fl_wave_lds_sync();
-    fl_wave_excl_scan_lds(cnt, 128, lane);
-    fl_wave_lds_sync();
-    for (uint32_t e0 = 0; e0 < M; e0 += 64) {
-        const uint32_t e = e0 + lane;
-        const bool valid = e < M;
-        const uint32_t v = valid ? tmp[e] : 0;
-        const uint32_t h = v >> 16, d = h >> 8;
-        const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
-        const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-        if (valid) {
-            const uint32_t dst = cnt[d] + rank;
-            So[dst] = (uint16_t)v;
-            Ho[dst] = (uint16_t)h;
+    fl_lds_order();
+    for (uint32_t e0 = 0; e0 < M; e0 += 64 * FL_SORT_UNROLL) {
+        uint32_t v[FL_SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t e = e0 + 64 * u + lane;
+            v[u] = e < M ? tmp[e] : 0;
         }
-        fl_wave_lds_sync();
-        if (valid && rank == np - 1) cnt[d] += np;
-        fl_wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++)
+            if (e0 + 64 * u + lane < M) atomicAdd(&cnt[v[u] >> 24], 1u);
+    }
+    fl_lds_order();
+    fl_wave_excl_scan_lds(cnt, 128, lane);
+    fl_lds_order();
+    for (uint32_t e0 = 0; e0 < M; e0 += 64 * FL_SORT_UNROLL) {
+        uint32_t v[FL_SORT_UNROLL], a0[FL_SORT_UNROLL], a1[FL_SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t e = e0 + 64 * u + lane;
+            v[u] = e < M ? tmp[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t p = v[u] & 0xffff;
+            a0[u] = fl_load_u32_unaligned(src + p);  // p <= N - 4
+            a1[u] = fl_load_u32_clamped(src, p + 4, N);
+        }
+#pragma unroll
+        for (int u = 0; u < FL_SORT_UNROLL; u++) {
+            const uint32_t e = e0 + 64 * u + lane;
+            const bool valid = e < M;
+            const uint32_t d = v[u] >> 24;
+            const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
+            const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
+            if (valid) {
+                const uint32_t dst = cnt[d] + rank;
+                So[dst] = (uint16_t)v[u];
+                W0o[dst] = a0[u];
+                W1o[dst] = a1[u];
+            }
+            fl_lds_order();
+            if (valid && rank == np - 1) cnt[d] += np;
+            fl_lds_order();
+        }
     }
 }
 
 // ------------------------------------------------------------------ k_lz_match
 #define FL_MATCH_WAVES 8
-#define FL_TILE 192  // 128 candidates back + 64 lanes
+#define FL_KB 64                 // candidates per tile
+#define FL_TILE (FL_KB + 64)     // FL_KB back + 64 lanes
 
 __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t off) {
     const uint32_t i = off >> 2;
@@ -144,11 +212,13 @@ __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t
 __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks,
                                                                   fl_params prm, const uint16_t* __restrict__ S,
-                                                                  const uint16_t* __restrict__ SH,
+                                                                  const uint32_t* __restrict__ W0,
+                                                                  const uint32_t* __restrict__ W1,
                                                                   uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
+    __shared__ uint32_t tW0[FL_MATCH_WAVES][FL_TILE];
+    __shared__ uint32_t tW1[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint16_t tS[FL_MATCH_WAVES][FL_TILE];
-    __shared__ uint16_t tH[FL_MATCH_WAVES][FL_TILE];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
@@ -157,19 +227,14 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint16_t* Hc = SH + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t* W0c = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t* W1c = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
 
     // stage the chunk in LDS (zero padded)
     const uint32_t ndw = (N + 3) >> 2;
     for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES) {
-        uint32_t w = 0;
-        if (i < ndw) {
-            w = fl_load_u32_unaligned(src + 4 * i);
-            const uint32_t rem = N - 4 * i;
-            if (rem < 4) w &= (1u << (8 * rem)) - 1;
-        }
-        win32[i] = w;
+        win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
     }
     // positions without a hash entry never match (Lookup.zig:24)
     for (uint32_t p = M + tid; p < N; p += 64 * FL_MATCH_WAVES) {
@@ -181,64 +246,85 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
     const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
     const uint32_t nbatch = (M + 63) >> 6;
     uint16_t* ts = tS[wave];
-    uint16_t* th = tH[wave];
+    uint32_t* tw0 = tW0[wave];
+    uint32_t* tw1 = tW1[wave];
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const bool active = i < M;
         const uint32_t p = active ? Sc[i] : 0;
-        const uint32_t h = active ? Hc[i] : 0xfffe;
+        const uint32_t p0 = active ? W0c[i] : 0;
+        const uint32_t p1 = active ? W1c[i] : 0;
+        const uint32_t h = fl_hash_le(p0);
         const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
         uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
         bool done = !active;
-        for (uint32_t kb = 0; kb < chain; kb += 128) {
-            // tile = sorted entries [i0 - kb - 128, i0 - kb + 64)
+        for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
+            // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64)
+            fl_lds_order();
+#pragma unroll
             for (uint32_t t = lane; t < FL_TILE; t += 64) {
-                const int32_t idx = (int32_t)i0 - (int32_t)kb - 128 + (int32_t)t;
+                const int32_t idx = (int32_t)i0 - (int32_t)kb - FL_KB + (int32_t)t;
                 const bool ok = idx >= 0 && idx < (int32_t)M;
                 ts[t] = ok ? Sc[idx] : 0;
-                th[t] = ok ? Hc[idx] : 0xffff;
+                tw0[t] = ok ? W0c[idx] : 0;
+                tw1[t] = ok ? W1c[idx] : 0;
             }
-            fl_wave_lds_sync();
-            for (uint32_t kk = 1; kk <= 128; kk++) {
+            fl_lds_order();
+            uint32_t t = FL_KB + lane - 1;
+            uint32_t nq = ts[t], nw0 = tw0[t], nw1 = tw1[t];
+            for (uint32_t kk = 1; kk <= FL_KB; kk++) {
                 const uint32_t k = kb + kk;
                 if (k > chain) break;
                 if (!__any(!done)) break;
+                const uint32_t q = nq, w0 = nw0, w1 = nw1;
+                if (kk < FL_KB) {  // prefetch the next candidate of this lane
+                    t = FL_KB + lane - kk - 1;
+                    nq = ts[t];
+                    nw0 = tw0[t];
+                    nw1 = tw1[t];
+                }
                 if (!done) {
-                    const uint32_t t = 128 + lane - kk;
-                    const uint32_t hq = th[t], q = ts[t];
-                    // end of the chain: other bucket, the null position 0 (deflate.zig:248), or
+                    // end of the chain: another bucket, the null position 0 (deflate.zig:248), or
                     // farther than the window (deflate.zig:250-251)
-                    if (hq != h || q == 0 || p - q > FL_MAX_DIST) {
+                    if (fl_hash_le(w0) != h || q == 0 || p - q > FL_MAX_DIST) {
                         done = true;
-                    } else {
-                        bool cand = maxlen > best;
-                        if (cand && best >= 4)  // SlidingWindow.zig:91-98: the new byte must extend the best
-                            cand = fl_lds_load4(win32, p + best - 3) == fl_lds_load4(win32, q + best - 3);
-                        if (cand) {
-                            uint32_t len = 0;
-                            while (len < maxlen) {
-                                const uint32_t x = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
-                                if (x) {
-                                    len += (uint32_t)__builtin_ctz(x) >> 3;
-                                    break;
+                    } else if (w0 == p0 && maxlen > best) {
+                        uint32_t len;
+                        const uint32_t x = w1 ^ p1;
+                        if (x) {
+                            len = 4 + ((uint32_t)__builtin_ctz(x) >> 3);
+                        } else {
+                            // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
+                            // candidate that does not extend the best match is dropped on one compare
+                            len = 0;
+                            bool cand = true;
+                            if (best >= 8)
+                                cand = fl_lds_load4(win32, p + best - 3) == fl_lds_load4(win32, q + best - 3);
+                            if (cand) {
+                                len = 8;
+                                while (len < maxlen) {
+                                    const uint32_t y = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
+                                    if (y) {
+                                        len += (uint32_t)__builtin_ctz(y) >> 3;
+                                        break;
+                                    }
+                                    len += 4;
                                 }
-                                len += 4;
                             }
-                            len = min(len, maxlen);
-                            if (len >= FL_MIN_MATCH && len > best) {  // deflate.zig:254
-                                best = len;
-                                bdist = p - q;
-                                if (k <= quarter) {
-                                    qbest = len;
-                                    qdist = bdist;
-                                }
-                                if (len >= nice) done = true;  // deflate.zig:256-258
+                        }
+                        len = min(len, maxlen);
+                        if (len >= FL_MIN_MATCH && len > best) {  // deflate.zig:254
+                            best = len;
+                            bdist = p - q;
+                            if (k <= quarter) {
+                                qbest = len;
+                                qdist = bdist;
                             }
+                            if (len >= nice) done = true;  // deflate.zig:256-258
                         }
                     }
                 }
             }
-            fl_wave_lds_sync();
             if (!__any(!done)) break;
         }
         if (active) {
@@ -260,13 +346,17 @@ __device__ __forceinline__ uint32_t fl_desc_next(uint32_t d, uint32_t p) {
 }
 
 // deflate.zig:154-194 seen from a position visited with no pending match.
-__device__ __forceinline__ uint32_t fl_anchor_desc(const uint32_t* __restrict__ rec, uint32_t p, uint32_t good,
-                                                   uint32_t lazy) {
-    const uint32_t r = rec[2 * p];  // findMatch(pos, lh, 0): full budget
+__device__ __forceinline__ uint32_t fl_anchor_desc(const uint32_t* __restrict__ rec, uint32_t p, uint32_t N,
+                                                   uint32_t good, uint32_t lazy) {
+    const uint2* rec2 = (const uint2*)rec;
+    const uint2 ra = rec2[p];                                        // both budgets of p
+    const uint2 rb = p + 1 < N ? rec2[p + 1] : make_uint2(0u, 0u);  // ... and of p + 1 (one round trip)
+    const uint32_t r = ra.x;  // findMatch(pos, lh, 0): full budget
     if (!r) return 0;
     uint32_t len = r >> 16, dist0 = r & 0x7fff, j = 0, q = p;
     while (len < lazy) {  // deflate.zig:171-178: keep the match, look one position further
-        const uint32_t r2 = rec[2 * (q + 1) + (len >= good ? 1 : 0)];  // deflate.zig:242-245
+        const uint32_t sel = len >= good ? 1u : 0u;  // deflate.zig:242-245
+        const uint32_t r2 = j == 0 ? (sel ? rb.y : rb.x) : rec[2 * (q + 1) + sel];
         const uint32_t l2 = r2 >> 16;
         if (l2 <= len) break;  // deflate.zig:182-184: no better match, the pending one goes out
         len = l2;              // deflate.zig:166-168: better match, the pending one becomes a literal
@@ -316,7 +406,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
 
     // (a) anchor function for every position
     for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
-        const uint32_t d = fl_anchor_desc(rec, p, prm.good, prm.lazy);
+        const uint32_t d = fl_anchor_desc(rec, p, N, prm.good, prm.lazy);
         desc[p] = d;
         J[p] = (uint16_t)fl_desc_next(d, p);
     }
