@@ -52,7 +52,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, W0, W1, rec, desc, tokens, ntok;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, W0, W1, NC, rec, desc, tokens, ntok;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
@@ -241,7 +241,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
-    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->W0, &h->W1, &h->rec, &h->desc,
+    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->W0, &h->W1, &h->NC, &h->rec, &h->desc,
                       &h->tokens, &h->ntok, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
@@ -411,20 +411,21 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->W0, per * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->W1, per * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(h, h->NC, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
             {
                 ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p,
-                                   (uint32_t*)h->W0.p, (uint32_t*)h->W1.p, (uint32_t*)h->rec.p);
+                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch, (uint16_t*)h->S.p,
+                                   (uint32_t*)h->W0.p, (uint32_t*)h->W1.p, (uint16_t*)h->NC.p);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
                 hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(64 * FL_MATCH_WAVES), 0, st, d_in, dch, prm,
                                    (const uint16_t*)h->S.p, (const uint32_t*)h->W0.p, (const uint32_t*)h->W1.p,
-                                   (uint32_t*)h->rec.p);
+                                   (const uint16_t*)h->NC.p, (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);

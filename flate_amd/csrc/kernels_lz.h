@@ -67,13 +67,22 @@ __device__ __forceinline__ void fl_wave_excl_scan_lds(uint32_t* cnt, uint32_t n,
 }
 
 // ------------------------------------------------------------------ k_lz_sort
-// One wave per chunk.  Output, sorted by (hash, position):
+// One workgroup (16 waves) per chunk.  Output, sorted by (hash, position):
 //   S[c][0..M)   positions 0..M-1 (M = in_len - 3: those with 4 bytes left, Lookup.zig:24)
 //   W0[c][0..M)  bytes p .. p+3 of each (little endian) -- the hash is a function of these
 //   W1[c][0..M)  bytes p+4 .. p+7, zero beyond the end of the chunk
+//   NC[c][0..M)  offset of the entry inside its hash bucket = number of chain predecessors
 // The two prefix words let the match kernel settle most candidates (match length < 8)
 // without touching the window at all.
-#define FL_SORT_UNROLL 4
+//
+// Stable LSD radix sort, 8 + 7 bits.  Wave w owns elements [4096 w, 4096 (w+1)) of each
+// pass and keeps its own digit counters, so the scatter is stable without atomics on the
+// destination.  Pass 1 scatters 16-bit positions inside LDS (128 KiB); pass 2 scatters to
+// global memory as 128 sequential write streams per array, which the L2 merges into whole
+// lines because only one chunk per CU is in flight.
+#define FL_SORT_WAVES 16
+#define FL_SORT_THREADS (64 * FL_SORT_WAVES)
+#define FL_SORT_SLICE 4096u
 
 __device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint32_t p, uint32_t N) {
     // bytes p..p+3 of the chunk, zero beyond N.  Touches only aligned dwords that contain at
@@ -90,110 +99,166 @@ __device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_lz_sort(const uint8_t* __restrict__ in,
-                                                const fl_chunk* __restrict__ chunks, uint16_t* __restrict__ S,
-                                                uint32_t* __restrict__ W0, uint32_t* __restrict__ W1,
-                                                uint32_t* __restrict__ tmp_all) {
-    __shared__ uint32_t cnt[256];
+// Exclusive scan of a [waves][ndig] counter table in (digit major, wave minor) order, in
+// place, by the whole workgroup.  PER = entries per thread (ndig * 16 / 1024).
+template <int NDIG, int PER>
+__device__ __forceinline__ void fl_scan_counters(uint32_t (*cnt)[NDIG], uint32_t* wsum, uint32_t tid) {
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    uint32_t v[PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t e = tid * PER + k;  // e = d * 16 + w
+        v[k] = cnt[e & 15][e >> 4];
+        s += v[k];
+    }
+    const uint32_t incl = fl_wave_incl_scan(s, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (uint32_t w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t e = tid * PER + k;
+        cnt[e & 15][e >> 4] = run;
+        run += v[k];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ in,
+                                                              const fl_chunk* __restrict__ chunks,
+                                                              uint16_t* __restrict__ S, uint32_t* __restrict__ W0,
+                                                              uint32_t* __restrict__ W1, uint16_t* __restrict__ NC) {
+    __shared__ uint16_t tmp[65536];
+    __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
+    __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
+    __shared__ uint32_t wsum[FL_SORT_WAVES];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = ck.in_len;
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* W0o = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* W1o = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* tmp = tmp_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;  // aliases the chunk's record area
+    uint16_t* NCo = NC + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t slice0 = wave * FL_SORT_SLICE;
 
-    // ---- pass 1: low 8 bits of the hash ----
-    for (uint32_t i = lane; i < 256; i += 64) cnt[i] = 0;
-    fl_lds_order();
-    for (uint32_t p0 = 0; p0 < M; p0 += 64 * FL_SORT_UNROLL) {
-        uint32_t w[FL_SORT_UNROLL];
+    for (uint32_t i = tid; i < FL_SORT_WAVES * 256; i += FL_SORT_THREADS) (&cnt1[0][0])[i] = 0;
+    for (uint32_t i = tid; i < FL_SORT_WAVES * 128; i += FL_SORT_THREADS) (&cnt2[0][0])[i] = 0;
+    __syncthreads();
+    // ---- pass 1 count: low 8 bits of the hash ----
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
+        uint32_t w[4];
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t p = p0 + 64 * u + lane;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = slice0 + (r + u) * 64 + lane;
             w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++)
-            if (p0 + 64 * u + lane < M) atomicAdd(&cnt[fl_hash_le(w[u]) & 255], 1u);
+        for (int u = 0; u < 4; u++)
+            if (slice0 + (r + u) * 64 + lane < M) atomicAdd(&cnt1[wave][fl_hash_le(w[u]) & 255], 1u);
     }
-    fl_lds_order();
-    fl_wave_excl_scan_lds(cnt, 256, lane);
-    fl_lds_order();
-    for (uint32_t p0 = 0; p0 < M; p0 += 64 * FL_SORT_UNROLL) {
-        uint32_t w[FL_SORT_UNROLL];
+    __syncthreads();
+    fl_scan_counters<256, 4>(cnt1, wsum, tid);
+    // ---- pass 1 scatter into LDS; count pass 2's digits per destination slice ----
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
+        uint32_t w[4];
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t p = p0 + 64 * u + lane;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = slice0 + (r + u) * 64 + lane;
             w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t p = p0 + 64 * u + lane;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = slice0 + (r + u) * 64 + lane;
             const bool valid = p < M;
             const uint32_t h = fl_hash_le(w[u]);
             const uint32_t d = h & 255;
             const uint64_t peers = fl_match_any<8>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-            if (valid) tmp[cnt[d] + rank] = (h << 16) | p;
+            if (valid) {
+                const uint32_t dst = cnt1[wave][d] + rank;
+                tmp[dst] = (uint16_t)p;
+                atomicAdd(&cnt2[dst >> 12][h >> 8], 1u);
+            }
             fl_lds_order();
-            if (valid && rank == np - 1) cnt[d] += np;
+            if (valid && rank == np - 1) cnt1[wave][d] += np;
             fl_lds_order();
         }
     }
-    __threadfence_block();  // pass 2 reads what other lanes of this wave stored
-    // ---- pass 2: high 7 bits ----
-    for (uint32_t i = lane; i < 128; i += 64) cnt[i] = 0;
-    fl_lds_order();
-    for (uint32_t e0 = 0; e0 < M; e0 += 64 * FL_SORT_UNROLL) {
-        uint32_t v[FL_SORT_UNROLL];
+    __syncthreads();
+    fl_scan_counters<128, 2>(cnt2, wsum, tid);
+    // ---- pass 2 scatter: high 7 bits, to global memory ----
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
+        uint32_t pp[4], a0[4], a1[4];
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t e = e0 + 64 * u + lane;
-            v[u] = e < M ? tmp[e] : 0;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = slice0 + (r + u) * 64 + lane;
+            pp[u] = e < M ? tmp[e] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++)
-            if (e0 + 64 * u + lane < M) atomicAdd(&cnt[v[u] >> 24], 1u);
-    }
-    fl_lds_order();
-    fl_wave_excl_scan_lds(cnt, 128, lane);
-    fl_lds_order();
-    for (uint32_t e0 = 0; e0 < M; e0 += 64 * FL_SORT_UNROLL) {
-        uint32_t v[FL_SORT_UNROLL], a0[FL_SORT_UNROLL], a1[FL_SORT_UNROLL];
-#pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t e = e0 + 64 * u + lane;
-            v[u] = e < M ? tmp[e] : 0;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = slice0 + (r + u) * 64 + lane;
+            a0[u] = e < M ? fl_load_u32_unaligned(src + pp[u]) : 0;  // p <= N - 4
+            a1[u] = e < M ? fl_load_u32_clamped(src, pp[u] + 4, N) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t p = v[u] & 0xffff;
-            a0[u] = fl_load_u32_unaligned(src + p);  // p <= N - 4
-            a1[u] = fl_load_u32_clamped(src, p + 4, N);
-        }
-#pragma unroll
-        for (int u = 0; u < FL_SORT_UNROLL; u++) {
-            const uint32_t e = e0 + 64 * u + lane;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = slice0 + (r + u) * 64 + lane;
             const bool valid = e < M;
-            const uint32_t d = v[u] >> 24;
+            const uint32_t d = fl_hash_le(a0[u]) >> 8;
             const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
             if (valid) {
-                const uint32_t dst = cnt[d] + rank;
-                So[dst] = (uint16_t)v[u];
+                const uint32_t dst = cnt2[wave][d] + rank;
+                So[dst] = (uint16_t)pp[u];
                 W0o[dst] = a0[u];
                 W1o[dst] = a1[u];
             }
             fl_lds_order();
-            if (valid && rank == np - 1) cnt[d] += np;
+            if (valid && rank == np - 1) cnt2[wave][d] += np;
             fl_lds_order();
         }
+    }
+    __syncthreads();  // W0 of the whole chunk is complete and visible inside the workgroup
+    // ---- bucket offsets: NC[i] = i - (first sorted index with the same hash) ----
+    // sweep 1: last bucket start inside each wave's slice
+    uint32_t last_start = 0;
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
+        const uint32_t i = slice0 + r * 64 + lane;
+        const bool valid = i < M;
+        const uint32_t h = valid ? fl_hash_le(W0o[i]) : 0xffffffffu;
+        uint32_t hp = __shfl_up(h, 1, 64);
+        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(W0o[i - 1]) : 0xfffffffeu;
+        const uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;  // i + 1 so that 0 = none
+        last_start = max(last_start, fl_wave_max(st));
+    }
+    if (lane == 0) wsum[wave] = last_start;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < wave; w++) carry = max(carry, wsum[w]);
+    // sweep 2: offsets
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
+        const uint32_t i = slice0 + r * 64 + lane;
+        const bool valid = i < M;
+        const uint32_t h = valid ? fl_hash_le(W0o[i]) : 0xffffffffu;
+        uint32_t hp = __shfl_up(h, 1, 64);
+        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(W0o[i - 1]) : 0xfffffffeu;
+        uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
+        // inclusive prefix max across lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(st, d, 64);
+            if (lane >= (uint32_t)d) st = max(st, o);
+        }
+        st = max(st, carry);
+        if (valid) NCo[i] = (uint16_t)(i + 1 - st);
+        carry = __shfl(st, 63, 64);
     }
 }
 
@@ -207,13 +272,40 @@ __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t
     return __builtin_amdgcn_alignbyte(win32[i + 1], win32[i], off & 3);
 }
 
+// exact common prefix of the window at p and q, known to be >= 8, capped at maxlen
+__device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t maxlen) {
+    uint32_t len = 8;
+    while (len < maxlen) {
+        const uint32_t y0 = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
+        const uint32_t y1 = fl_lds_load4(win32, p + len + 4) ^ fl_lds_load4(win32, q + len + 4);
+        if (y0) {
+            len += (uint32_t)__builtin_ctz(y0) >> 3;
+            break;
+        }
+        if (y1) {
+            len += 4 + ((uint32_t)__builtin_ctz(y1) >> 3);
+            break;
+        }
+        len += 8;
+    }
+    return min(len, maxlen);
+}
+
 // rec[c][2p]   = record for the full chain budget
 // rec[c][2p+1] = record for chain >> 2       (0 = no match, else len << 16 | dist-1)
+//
+// Lane = one sorted entry, loop = its chain candidates (the preceding entries of its hash
+// bucket, nearest first).  `n` is the number of candidates the lane may still look at:
+// min(bucket offset, chain), and it drops to 0 at the null position / beyond the window /
+// once a match of `nice` is found.  Candidates whose first 8 bytes settle the comparison
+// (the common case) never leave the registers; the window in LDS is only read to extend a
+// match beyond 8 bytes.
 __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks,
                                                                   fl_params prm, const uint16_t* __restrict__ S,
                                                                   const uint32_t* __restrict__ W0,
                                                                   const uint32_t* __restrict__ W1,
+                                                                  const uint16_t* __restrict__ NC,
                                                                   uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
     __shared__ uint32_t tW0[FL_MATCH_WAVES][FL_TILE];
@@ -229,13 +321,13 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint32_t* W0c = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint32_t* W1c = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint16_t* NCc = NC + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
 
     // stage the chunk in LDS (zero padded)
     const uint32_t ndw = (N + 3) >> 2;
-    for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES) {
+    for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES)
         win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
-    }
     // positions without a hash entry never match (Lookup.zig:24)
     for (uint32_t p = M + tid; p < N; p += 64 * FL_MATCH_WAVES) {
         rec[2 * p] = 0;
@@ -254,11 +346,15 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
         const uint32_t p = active ? Sc[i] : 0;
         const uint32_t p0 = active ? W0c[i] : 0;
         const uint32_t p1 = active ? W1c[i] : 0;
-        const uint32_t h = fl_hash_le(p0);
+        uint32_t n = active ? min((uint32_t)NCc[i], chain) : 0;  // candidates left to look at
+        // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248) and
+        // p - q <= 32768 (deflate.zig:250-251); both end the walk
+        const uint32_t lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
         const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
         uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
-        bool done = !active;
+        uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
+            if (!__any(n > kb)) break;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64)
             fl_lds_order();
 #pragma unroll
@@ -270,62 +366,49 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
                 tw1[t] = ok ? W1c[idx] : 0;
             }
             fl_lds_order();
-            uint32_t t = FL_KB + lane - 1;
-            uint32_t nq = ts[t], nw0 = tw0[t], nw1 = tw1[t];
-            for (uint32_t kk = 1; kk <= FL_KB; kk++) {
-                const uint32_t k = kb + kk;
-                if (k > chain) break;
-                if (!__any(!done)) break;
-                const uint32_t q = nq, w0 = nw0, w1 = nw1;
-                if (kk < FL_KB) {  // prefetch the next candidate of this lane
-                    t = FL_KB + lane - kk - 1;
-                    nq = ts[t];
-                    nw0 = tw0[t];
-                    nw1 = tw1[t];
-                }
-                if (!done) {
-                    // end of the chain: another bucket, the null position 0 (deflate.zig:248), or
-                    // farther than the window (deflate.zig:250-251)
-                    if (fl_hash_le(w0) != h || q == 0 || p - q > FL_MAX_DIST) {
-                        done = true;
-                    } else if (w0 == p0 && maxlen > best) {
-                        uint32_t len;
-                        const uint32_t x = w1 ^ p1;
-                        if (x) {
-                            len = 4 + ((uint32_t)__builtin_ctz(x) >> 3);
-                        } else {
+            for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
+                if (!__any(n >= kb + kk0)) break;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t kk = kk0 + u;
+                    const uint32_t k = kb + kk;
+                    const uint32_t t = FL_KB + lane - kk;
+                    const uint32_t q = ts[t], w0 = tw0[t], w1 = tw1[t];
+                    const bool ok = (k <= n) && (q >= lo);
+                    n = ok ? n : min(n, k - 1);  // the walk ends here
+                    const uint32_t x = w1 ^ p1;
+                    uint32_t len = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+                    len = min(len, maxlen);
+                    const bool same4 = ok && (w0 == p0);
+                    bool better = same4 && (len > best);
+                    // all 8 prefix bytes agree and a longer match than the best is still possible
+                    const bool deep = same4 && (x == 0) && (maxlen > 8) && (maxlen > best);
+                    if (__any(deep)) {
+                        if (deep) {
                             // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
                             // candidate that does not extend the best match is dropped on one compare
-                            len = 0;
                             bool cand = true;
-                            if (best >= 8)
-                                cand = fl_lds_load4(win32, p + best - 3) == fl_lds_load4(win32, q + best - 3);
+                            if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
                             if (cand) {
-                                len = 8;
-                                while (len < maxlen) {
-                                    const uint32_t y = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
-                                    if (y) {
-                                        len += (uint32_t)__builtin_ctz(y) >> 3;
-                                        break;
-                                    }
-                                    len += 4;
-                                }
+                                len = fl_extend_match(win32, p, q, maxlen);
+                                better = len > best;
+                            } else {
+                                better = false;
                             }
                         }
-                        len = min(len, maxlen);
-                        if (len >= FL_MIN_MATCH && len > best) {  // deflate.zig:254
-                            best = len;
-                            bdist = p - q;
-                            if (k <= quarter) {
-                                qbest = len;
-                                qdist = bdist;
-                            }
-                            if (len >= nice) done = true;  // deflate.zig:256-258
+                    }
+                    if (better) {  // deflate.zig:254-261
+                        best = len;
+                        bdist = p - q;
+                        if (k <= quarter) {
+                            qbest = len;
+                            qdist = bdist;
                         }
+                        if (len >= nice) n = 0;
+                        if (len >= 8) pb = fl_lds_load4(win32, p + len - 3);
                     }
                 }
             }
-            if (!__any(!done)) break;
         }
         if (active) {
             rec[2 * p] = best ? ((best << 16) | (bdist - 1)) : 0;
