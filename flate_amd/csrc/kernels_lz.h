@@ -263,8 +263,8 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
 }
 
 // ------------------------------------------------------------------ k_lz_match
-#define FL_MATCH_WAVES 8
-#define FL_KB 64                 // candidates per tile
+#define FL_MATCH_WAVES 16
+#define FL_KB 32                 // candidates per tile
 #define FL_TILE (FL_KB + 64)     // FL_KB back + 64 lanes
 
 __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t off) {
@@ -296,17 +296,18 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 //
 // Lane = one sorted entry, loop = its chain candidates (the preceding entries of its hash
 // bucket, nearest first).  `n` is the number of candidates the lane may still look at:
-// min(bucket offset, chain), and it drops to 0 at the null position / beyond the window /
-// once a match of `nice` is found.  Candidates whose first 8 bytes settle the comparison
-// (the common case) never leave the registers; the window in LDS is only read to extend a
-// match beyond 8 bytes.
-__global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t* __restrict__ in,
-                                                                  const fl_chunk* __restrict__ chunks,
-                                                                  fl_params prm, const uint16_t* __restrict__ S,
-                                                                  const uint32_t* __restrict__ W0,
-                                                                  const uint32_t* __restrict__ W1,
-                                                                  const uint16_t* __restrict__ NC,
-                                                                  uint32_t* __restrict__ rec_all) {
+// min(bucket offset, chain); it drops to 0 at the null position / beyond the window / once
+// a match of `nice` is found.  Candidates whose first 8 bytes settle the comparison (the
+// common case) are handled with a handful of VALU ops on registers; the window in LDS is
+// only read to extend a match beyond 8 bytes.  The per-candidate predicates are kept in
+// integer form (few lane masks => little scalar-unit work, which is what bounds this loop).
+__global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8_t* __restrict__ in,
+                                                                     const fl_chunk* __restrict__ chunks,
+                                                                     fl_params prm, const uint16_t* __restrict__ S,
+                                                                     const uint32_t* __restrict__ W0,
+                                                                     const uint32_t* __restrict__ W1,
+                                                                     const uint16_t* __restrict__ NC,
+                                                                     uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
     __shared__ uint32_t tW0[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint32_t tW1[FL_MATCH_WAVES][FL_TILE];
@@ -340,19 +341,39 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
     uint16_t* ts = tS[wave];
     uint32_t* tw0 = tW0[wave];
     uint32_t* tw1 = tW1[wave];
+
+    // software pipeline: the next batch's own entries are fetched while this one is searched
+    uint32_t nx_p = 0, nx_p0 = 0, nx_p1 = 0, nx_n = 0;
+    {
+        const uint32_t i = (wave << 6) + lane;
+        if (wave < nbatch && i < M) {
+            nx_p = Sc[i];
+            nx_p0 = W0c[i];
+            nx_p1 = W1c[i];
+            nx_n = NCc[i];
+        }
+    }
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const bool active = i < M;
-        const uint32_t p = active ? Sc[i] : 0;
-        const uint32_t p0 = active ? W0c[i] : 0;
-        const uint32_t p1 = active ? W1c[i] : 0;
-        uint32_t n = active ? min((uint32_t)NCc[i], chain) : 0;  // candidates left to look at
+        const uint32_t p = nx_p, p0 = nx_p0, p1 = nx_p1;
+        uint32_t n = active ? min(nx_n, chain) : 0;  // candidates left to look at
+        {
+            const uint32_t bn = batch + FL_MATCH_WAVES;
+            const uint32_t in_ = (bn << 6) + lane;
+            const bool okn = bn < nbatch && in_ < M;
+            nx_p = okn ? Sc[in_] : 0;
+            nx_p0 = okn ? W0c[in_] : 0;
+            nx_p1 = okn ? W1c[in_] : 0;
+            nx_n = okn ? NCc[in_] : 0;
+        }
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248) and
         // p - q <= 32768 (deflate.zig:250-251); both end the walk
         const uint32_t lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
         const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
         uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
         uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
+        bool qsnap = false;
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64)
@@ -367,6 +388,13 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
             }
             fl_lds_order();
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
+                // the chain >> 2 budget (deflate.zig:241-245) ends after candidate `quarter`
+                // (a multiple of 4 at every level, deflate.zig:44-49)
+                if (kb + kk0 - 1 == quarter) {
+                    qbest = best;
+                    qdist = bdist;
+                    qsnap = true;
+                }
                 if (!__any(n >= kb + kk0)) break;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
@@ -374,41 +402,38 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES) void k_lz_match(const uint8_t*
                     const uint32_t k = kb + kk;
                     const uint32_t t = FL_KB + lane - kk;
                     const uint32_t q = ts[t], w0 = tw0[t], w1 = tw1[t];
-                    const bool ok = (k <= n) && (q >= lo);
-                    n = ok ? n : min(n, k - 1);  // the walk ends here
+                    // the walk ends at the first candidate below `lo`
+                    n = q >= lo ? n : min(n, k - 1);
                     const uint32_t x = w1 ^ p1;
-                    uint32_t len = x ? 4 + ((uint32_t)__builtin_ctz(x) >> 3) : 8;
+                    // common prefix from the two prefix words: 4..7, or 8 when they agree
+                    // (ffbl(0) = ~0 -> min(.., 4) = 4)
+                    uint32_t len = 4u + min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
                     len = min(len, maxlen);
-                    const bool same4 = ok && (w0 == p0);
-                    bool better = same4 && (len > best);
-                    // all 8 prefix bytes agree and a longer match than the best is still possible
-                    const bool deep = same4 && (x == 0) && (maxlen > 8) && (maxlen > best);
-                    if (__any(deep)) {
-                        if (deep) {
+                    // bad != 0: beyond the lane's candidates, or the first four bytes differ
+                    // (another 4-gram with the same hash)
+                    const uint32_t bad = (w0 ^ p0) | ((n - k) >> 31);
+                    len = bad ? 0u : len;
+                    if (__any((bad | x) == 0 && maxlen > max(best, 8u))) {
+                        if ((bad | x) == 0 && maxlen > max(best, 8u)) {
                             // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
                             // candidate that does not extend the best match is dropped on one compare
                             bool cand = true;
                             if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
-                            if (cand) {
-                                len = fl_extend_match(win32, p, q, maxlen);
-                                better = len > best;
-                            } else {
-                                better = false;
-                            }
+                            len = cand ? fl_extend_match(win32, p, q, maxlen) : 0u;
                         }
                     }
-                    if (better) {  // deflate.zig:254-261
+                    if (len > best) {  // deflate.zig:254-261
                         best = len;
                         bdist = p - q;
-                        if (k <= quarter) {
-                            qbest = len;
-                            qdist = bdist;
-                        }
                         if (len >= nice) n = 0;
                         if (len >= 8) pb = fl_lds_load4(win32, p + len - 3);
                     }
                 }
             }
+        }
+        if (!qsnap) {
+            qbest = best;
+            qdist = bdist;
         }
         if (active) {
             rec[2 * p] = best ? ((best << 16) | (bdist - 1)) : 0;
