@@ -52,7 +52,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, W0, W1, NC, rec, desc, tokens, ntok;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, W01, NC, rec, desc, tokens, ntok;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
@@ -241,7 +241,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
-    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->W0, &h->W1, &h->NC, &h->rec, &h->desc,
+    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->W01, &h->NC, &h->rec, &h->desc,
                       &h->tokens, &h->ntok, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
@@ -409,8 +409,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         if (mode >= 4) {
             const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
-            if ((rc = ensure(h, h->W0, per * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->W1, per * sizeof(uint32_t)))) return rc;
+            if ((rc = ensure(h, h->W01, per * sizeof(uint2)))) return rc;
             if ((rc = ensure(h, h->NC, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
@@ -419,13 +418,13 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             {
                 ProfScope ps(h, K_LZ_SORT);
                 hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch, (uint16_t*)h->S.p,
-                                   (uint32_t*)h->W0.p, (uint32_t*)h->W1.p, (uint16_t*)h->NC.p);
+                                   (uint2*)h->W01.p, (uint16_t*)h->NC.p);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
                 hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(64 * FL_MATCH_WAVES), 0, st, d_in, dch, prm,
-                                   (const uint16_t*)h->S.p, (const uint32_t*)h->W0.p, (const uint32_t*)h->W1.p,
-                                   (const uint16_t*)h->NC.p, (uint32_t*)h->rec.p);
+                                   (const uint16_t*)h->S.p, (const uint2*)h->W01.p, (const uint16_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);
@@ -565,6 +564,16 @@ int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint6
     }
     HIP_OK(h, hipGetLastError());
     if (h->sync) HIP_OK(h, hipStreamSynchronize(st));
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_debug_phase_cycles(flate_hip_handle h, uint64_t* out, int n) {
+    if (!h || !out || n <= 0) return FLATE_HIP_E_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return FLATE_HIP_E_LAUNCH;
+    uint64_t tmp[FL_PROF_SLOTS];
+    if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(g_fl_prof), sizeof tmp) != hipSuccess) return FLATE_HIP_E_LAUNCH;
+    for (int i = 0; i < n && i < FL_PROF_SLOTS; i++) out[i] = tmp[i];
     return FLATE_HIP_OK;
 }
 

@@ -38,6 +38,15 @@ struct fl_crc_consts {
     uint32_t pow65535;  // x^(8*65535)
 };
 
+// Phase timestamps (shader clock) of workgroup 0 of the tokenizer kernels: a debugging /
+// tuning aid read back through flate_hip_debug_phase_cycles.  One s_memtime + one store by
+// one thread per phase.
+#define FL_PROF_SLOTS 64
+__device__ uint64_t g_fl_prof[FL_PROF_SLOTS];
+__device__ __forceinline__ void fl_prof_mark(uint32_t slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] = __builtin_readcyclecounter();
+}
+
 __device__ __forceinline__ uint32_t fl_lane() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

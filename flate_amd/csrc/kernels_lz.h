@@ -99,6 +99,37 @@ __device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint
     return v;
 }
 
+// bytes p..p+3 and p+4..p+7 of the chunk (p <= N - 4), zero beyond N, with ONE 12-byte load
+// from the aligned dword below p (a scattered access costs the CU's memory pipe per
+// instruction, not per byte).  The third dword is only touched when it holds valid bytes.
+__device__ __forceinline__ void fl_load_prefix8(const uint8_t* src, uint32_t p, uint32_t N, bool ok, uint32_t& w0,
+                                                uint32_t& w1) {
+    w0 = 0;
+    w1 = 0;
+    if (!ok) return;
+    const uintptr_t a = (uintptr_t)(src + p);
+    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t nb = min(N - p, 8u);  // valid bytes from p (>= 4)
+    uint32_t d0, d1, d2;
+    if (sh + nb > 8) {
+        d0 = w[0];
+        d1 = w[1];
+        d2 = w[2];
+    } else if (sh + nb > 4) {
+        d0 = w[0];
+        d1 = w[1];
+        d2 = 0;
+    } else {
+        d0 = w[0];
+        d1 = 0;
+        d2 = 0;
+    }
+    w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    if (nb < 8) w1 &= nb > 4 ? ((1u << (8 * (nb - 4))) - 1) : 0u;
+}
+
 // Exclusive scan of a [waves][ndig] counter table in (digit major, wave minor) order, in
 // place, by the whole workgroup.  PER = entries per thread (ndig * 16 / 1024).
 template <int NDIG, int PER>
@@ -128,8 +159,8 @@ __device__ __forceinline__ void fl_scan_counters(uint32_t (*cnt)[NDIG], uint32_t
 
 __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
-                                                              uint16_t* __restrict__ S, uint32_t* __restrict__ W0,
-                                                              uint32_t* __restrict__ W1, uint16_t* __restrict__ NC) {
+                                                              uint16_t* __restrict__ S, uint2* __restrict__ W01,
+                                                              uint16_t* __restrict__ NC) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
@@ -142,12 +173,12 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* W0o = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* W1o = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint2* Wo = W01 + (uint64_t)c * FL_CHUNK_STRIDE;
     uint16_t* NCo = NC + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t slice0 = wave * FL_SORT_SLICE;
 
+    fl_prof_mark(0);
     for (uint32_t i = tid; i < FL_SORT_WAVES * 256; i += FL_SORT_THREADS) (&cnt1[0][0])[i] = 0;
     for (uint32_t i = tid; i < FL_SORT_WAVES * 128; i += FL_SORT_THREADS) (&cnt2[0][0])[i] = 0;
     __syncthreads();
@@ -164,14 +195,24 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             if (slice0 + (r + u) * 64 + lane < M) atomicAdd(&cnt1[wave][fl_hash_le(w[u]) & 255], 1u);
     }
     __syncthreads();
+    fl_prof_mark(1);
     fl_scan_counters<256, 4>(cnt1, wsum, tid);
+    fl_prof_mark(2);
     // ---- pass 1 scatter into LDS; count pass 2's digits per destination slice ----
+    uint32_t wn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t p = slice0 + u * 64 + lane;
+        wn[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
+    }
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
         uint32_t w[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = slice0 + (r + u) * 64 + lane;
-            w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
+        for (int u = 0; u < 4; u++) w[u] = wn[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // next group's loads fly while this one is ranked
+            const uint32_t p = slice0 + (r + 4 + u) * 64 + lane;
+            wn[u] = (r + 4 < FL_SORT_SLICE / 64 && p < M) ? fl_load_u32_unaligned(src + p) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -192,20 +233,31 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
         }
     }
     __syncthreads();
+    fl_prof_mark(3);
     fl_scan_counters<128, 2>(cnt2, wsum, tid);
+    fl_prof_mark(4);
     // ---- pass 2 scatter: high 7 bits, to global memory ----
+    uint32_t ppn[4], a0n[4], a1n[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t e = slice0 + u * 64 + lane;
+        ppn[u] = e < M ? tmp[e] : 0;
+        fl_load_prefix8(src, ppn[u], N, e < M, a0n[u], a1n[u]);
+    }
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
         uint32_t pp[4], a0[4], a1[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t e = slice0 + (r + u) * 64 + lane;
-            pp[u] = e < M ? tmp[e] : 0;
+            pp[u] = ppn[u];
+            a0[u] = a0n[u];
+            a1[u] = a1n[u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t e = slice0 + (r + u) * 64 + lane;
-            a0[u] = e < M ? fl_load_u32_unaligned(src + pp[u]) : 0;  // p <= N - 4
-            a1[u] = e < M ? fl_load_u32_clamped(src, pp[u] + 4, N) : 0;
+        for (int u = 0; u < 4; u++) {  // next group's gathers fly while this one is ranked
+            const uint32_t e = slice0 + (r + 4 + u) * 64 + lane;
+            const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < M;
+            ppn[u] = okn ? tmp[e] : 0;
+            fl_load_prefix8(src, ppn[u], N, okn, a0n[u], a1n[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -217,8 +269,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             if (valid) {
                 const uint32_t dst = cnt2[wave][d] + rank;
                 So[dst] = (uint16_t)pp[u];
-                W0o[dst] = a0[u];
-                W1o[dst] = a1[u];
+                Wo[dst] = make_uint2(a0[u], a1[u]);
             }
             fl_lds_order();
             if (valid && rank == np - 1) cnt2[wave][d] += np;
@@ -226,29 +277,31 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
         }
     }
     __syncthreads();  // W0 of the whole chunk is complete and visible inside the workgroup
+    fl_prof_mark(5);
     // ---- bucket offsets: NC[i] = i - (first sorted index with the same hash) ----
     // sweep 1: last bucket start inside each wave's slice
     uint32_t last_start = 0;
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
         const uint32_t i = slice0 + r * 64 + lane;
         const bool valid = i < M;
-        const uint32_t h = valid ? fl_hash_le(W0o[i]) : 0xffffffffu;
+        const uint32_t h = valid ? fl_hash_le(Wo[i].x) : 0xffffffffu;
         uint32_t hp = __shfl_up(h, 1, 64);
-        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(W0o[i - 1]) : 0xfffffffeu;
+        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(Wo[i - 1].x) : 0xfffffffeu;
         const uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;  // i + 1 so that 0 = none
         last_start = max(last_start, fl_wave_max(st));
     }
     if (lane == 0) wsum[wave] = last_start;
     __syncthreads();
+    fl_prof_mark(6);
     uint32_t carry = 0;
     for (uint32_t w = 0; w < wave; w++) carry = max(carry, wsum[w]);
     // sweep 2: offsets
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
         const uint32_t i = slice0 + r * 64 + lane;
         const bool valid = i < M;
-        const uint32_t h = valid ? fl_hash_le(W0o[i]) : 0xffffffffu;
+        const uint32_t h = valid ? fl_hash_le(Wo[i].x) : 0xffffffffu;
         uint32_t hp = __shfl_up(h, 1, 64);
-        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(W0o[i - 1]) : 0xfffffffeu;
+        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(Wo[i - 1].x) : 0xfffffffeu;
         uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
         // inclusive prefix max across lanes
 #pragma unroll
@@ -260,6 +313,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
         if (valid) NCo[i] = (uint16_t)(i + 1 - st);
         carry = __shfl(st, 63, 64);
     }
+    fl_prof_mark(7);
 }
 
 // ------------------------------------------------------------------ k_lz_match
@@ -304,8 +358,7 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8_t* __restrict__ in,
                                                                      const fl_chunk* __restrict__ chunks,
                                                                      fl_params prm, const uint16_t* __restrict__ S,
-                                                                     const uint32_t* __restrict__ W0,
-                                                                     const uint32_t* __restrict__ W1,
+                                                                     const uint2* __restrict__ W01,
                                                                      const uint16_t* __restrict__ NC,
                                                                      uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
@@ -320,11 +373,12 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint32_t* W0c = W0 + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint32_t* W1c = W1 + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint2* Wc = W01 + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint16_t* NCc = NC + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
+    uint2* rec2 = (uint2*)rec;
 
+    fl_prof_mark(8);
     // stage the chunk in LDS (zero padded)
     const uint32_t ndw = (N + 3) >> 2;
     for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES)
@@ -342,14 +396,16 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
     uint32_t* tw0 = tW0[wave];
     uint32_t* tw1 = tW1[wave];
 
+    fl_prof_mark(9);
     // software pipeline: the next batch's own entries are fetched while this one is searched
     uint32_t nx_p = 0, nx_p0 = 0, nx_p1 = 0, nx_n = 0;
     {
         const uint32_t i = (wave << 6) + lane;
         if (wave < nbatch && i < M) {
+            const uint2 w = Wc[i];
             nx_p = Sc[i];
-            nx_p0 = W0c[i];
-            nx_p1 = W1c[i];
+            nx_p0 = w.x;
+            nx_p1 = w.y;
             nx_n = NCc[i];
         }
     }
@@ -362,9 +418,10 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
             const uint32_t bn = batch + FL_MATCH_WAVES;
             const uint32_t in_ = (bn << 6) + lane;
             const bool okn = bn < nbatch && in_ < M;
+            const uint2 w = okn ? Wc[in_] : make_uint2(0u, 0u);
             nx_p = okn ? Sc[in_] : 0;
-            nx_p0 = okn ? W0c[in_] : 0;
-            nx_p1 = okn ? W1c[in_] : 0;
+            nx_p0 = w.x;
+            nx_p1 = w.y;
             nx_n = okn ? NCc[in_] : 0;
         }
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248) and
@@ -382,9 +439,10 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
             for (uint32_t t = lane; t < FL_TILE; t += 64) {
                 const int32_t idx = (int32_t)i0 - (int32_t)kb - FL_KB + (int32_t)t;
                 const bool ok = idx >= 0 && idx < (int32_t)M;
+                const uint2 w = ok ? Wc[idx] : make_uint2(0u, 0u);
                 ts[t] = ok ? Sc[idx] : 0;
-                tw0[t] = ok ? W0c[idx] : 0;
-                tw1[t] = ok ? W1c[idx] : 0;
+                tw0[t] = w.x;
+                tw1[t] = w.y;
             }
             fl_lds_order();
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
@@ -435,11 +493,10 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
             qbest = best;
             qdist = bdist;
         }
-        if (active) {
-            rec[2 * p] = best ? ((best << 16) | (bdist - 1)) : 0;
-            rec[2 * p + 1] = qbest ? ((qbest << 16) | (qdist - 1)) : 0;
-        }
+        if (active)
+            rec2[p] = make_uint2(best ? ((best << 16) | (bdist - 1)) : 0u, qbest ? ((qbest << 16) | (qdist - 1)) : 0u);
     }
+    fl_prof_mark(10);
 }
 
 // ------------------------------------------------------------------ k_lz_parse
@@ -512,6 +569,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
     uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* tokens = tokens_all + (uint64_t)c * FL_CHUNK_STRIDE;
 
+    fl_prof_mark(16);
     // (a) anchor function for every position
     for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
         const uint32_t d = fl_anchor_desc(rec, p, N, prm.good, prm.lazy);
@@ -523,6 +581,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
     if (tid < 256) entry[tid] = 0xffff;
     if (tid == 0) v1_sh = N;
     __syncthreads();
+    fl_prof_mark(17);
     // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
     // lies at or beyond the end of p's segment.  Racy reads only ever see a node further along
     // the same path, so 8 rounds (2^8 = segment length) always suffice.
@@ -534,6 +593,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
         }
         __syncthreads();
     }
+    fl_prof_mark(18);
     // (c) first anchor of every segment: at most 256 serial steps
     if (tid == 0) {
         uint32_t a = 0;
@@ -543,9 +603,11 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
         }
     }
     __syncthreads();
+    fl_prof_mark(19);
     // (d) restore the one-step pointers
     for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) J[p] = (uint16_t)fl_desc_next(desc[p], p);
     __syncthreads();
+    fl_prof_mark(20);
     // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
     if (tid < 256) {
         uint32_t a = entry[tid];
@@ -556,6 +618,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
         }
     }
     __syncthreads();
+    fl_prof_mark(21);
     // (f) token counts: thread t owns positions [64 t, 64 t + 64)
     uint32_t cnt = 0;
     for (int w = 0; w < 2; w++) {
@@ -576,6 +639,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
         if (w < wave) base += wsum[w];
         total += wsum[w];
     }
+    fl_prof_mark(22);
     // (g) emit tokens + histograms (block_writer.zig:455-462)
     uint32_t idx = base;
     for (int w = 0; w < 2; w++) {
@@ -605,6 +669,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
         }
     }
     __syncthreads();
+    fl_prof_mark(23);
     // (h) block boundaries (deflate.zig:227-230, 268-288) and histograms
     const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
     uint32_t* h0 = hist_all + (uint64_t)ck.first_block * 320;

@@ -136,6 +136,12 @@ class Engine:
         n = self._L.flate_hip_profile_read(self._h, names, ms, cnt, cap)
         return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(max(n, 0))}
 
+    def phase_cycles(self):
+        """Shader-clock timestamps of workgroup 0's phases in the last tokenizer launch (tuning aid)."""
+        buf = np.zeros(64, dtype=np.uint64)
+        self._L.flate_hip_debug_phase_cycles(self._h, buf.ctypes.data, 64)
+        return buf
+
     def debug_tokens(self, chunk):
         """Token list the tokenizer kernels produced for `chunk` of the last level 4..9 call."""
         buf = np.zeros(65536, dtype=np.uint32)

@@ -163,6 +163,10 @@ int flate_hip_profile_reset(flate_hip_handle h);
  * dist-1) into host memory.  Returns the token count or a negative error. */
 int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tokens, uint64_t cap);
 
+/* Tuning aid: shader-clock timestamps that workgroup 0 of the tokenizer kernels took at its
+ * phase boundaries during the last call (slots: sort 0-7, match 8-10, parse 16-23). */
+int flate_hip_debug_phase_cycles(flate_hip_handle h, uint64_t* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

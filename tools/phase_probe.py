@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Print the per-phase shader-clock breakdown of workgroup 0 of the tokenizer kernels."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from flate_amd import Engine, synth
+
+n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+eng = Engine(0)
+data = synth.text(synth.SEED_TEXT, 65535 * 8).tobytes()
+chunks = [data[i:i + 65535] for i in range(0, len(data), 65535)] * (n_chunks // 8)
+for rep in range(2):
+    outs, st = eng.compress_many(chunks, 0, level)
+t = eng.phase_cycles().astype(np.int64)
+def seg(name, a, b): print("%-28s %10d cycles" % (name, t[b] - t[a]))
+print("n_chunks", len(chunks))
+seg("sort: zero+count1", 0, 1); seg("sort: scan1", 1, 2); seg("sort: scatter1 (LDS)", 2, 3); seg("sort: scan2", 3, 4)
+seg("sort: scatter2 (global)", 4, 5); seg("sort: NC sweep1", 5, 6); seg("sort: NC sweep2", 6, 7); seg("sort: total", 0, 7)
+seg("match: stage window", 8, 9); seg("match: batches", 9, 10)
+seg("parse: (a) desc", 16, 17); seg("parse: (b) jump", 17, 18); seg("parse: (c) serial", 18, 19); seg("parse: (d) restore", 19, 20)
+seg("parse: (e) mark", 20, 21); seg("parse: (f) count", 21, 22); seg("parse: (g) emit", 22, 23); seg("parse: total", 16, 23)
