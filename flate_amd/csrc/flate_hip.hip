@@ -26,6 +26,7 @@ enum KernelId {
     K_LZ_SORT,
     K_LZ_MATCH,
     K_LZ_PARSE,
+    K_LZ_EMIT,
     K_PLAN,
     K_OFFSETS,
     K_ENCODE,
@@ -34,8 +35,8 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_parse", "k_plan",      "k_offsets",  "k_encode",  "k_inflate",
-                                           "k_gather"};
+                                           "k_lz_parse", "k_lz_emit",   "k_plan",     "k_offsets", "k_encode",
+                                           "k_inflate",  "k_gather"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -52,7 +53,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, W01, NC, rec, desc, tokens, ntok;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
@@ -241,7 +242,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
-    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->W01, &h->NC, &h->rec, &h->desc,
+    for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
@@ -409,7 +410,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         if (mode >= 4) {
             const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
-            if ((rc = ensure(h, h->W01, per * sizeof(uint2)))) return rc;
+            if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->NC, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
@@ -417,20 +418,23 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
             {
                 ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch, (uint16_t*)h->S.p,
-                                   (uint2*)h->W01.p, (uint16_t*)h->NC.p);
+                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch, (uint16_t*)h->S.p);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(64 * FL_MATCH_WAVES), 0, st, d_in, dch, prm,
-                                   (const uint16_t*)h->S.p, (const uint2*)h->W01.p, (const uint16_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p);
+                hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint16_t*)h->S.p, (uint16_t*)h->NC.p, (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);
-                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->tokens.p, dhist, dpl,
-                                   (uint32_t*)h->ntok.p);
+                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, dch, prm,
+                                   (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_EMIT);
+                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p,
+                                   dhist, dpl, (uint32_t*)h->ntok.p);
             }
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;

@@ -67,19 +67,16 @@ __device__ __forceinline__ void fl_wave_excl_scan_lds(uint32_t* cnt, uint32_t n,
 }
 
 // ------------------------------------------------------------------ k_lz_sort
-// One workgroup (16 waves) per chunk.  Output, sorted by (hash, position):
-//   S[c][0..M)   positions 0..M-1 (M = in_len - 3: those with 4 bytes left, Lookup.zig:24)
-//   W0[c][0..M)  bytes p .. p+3 of each (little endian) -- the hash is a function of these
-//   W1[c][0..M)  bytes p+4 .. p+7, zero beyond the end of the chunk
-//   NC[c][0..M)  offset of the entry inside its hash bucket = number of chain predecessors
-// The two prefix words let the match kernel settle most candidates (match length < 8)
-// without touching the window at all.
+// One workgroup (16 waves) per chunk.  Output: S[c][0..M) = the positions 0..M-1
+// (M = in_len - 3: those with 4 bytes left, Lookup.zig:24) sorted by (hash, position).
 //
 // Stable LSD radix sort, 8 + 7 bits.  Wave w owns elements [4096 w, 4096 (w+1)) of each
 // pass and keeps its own digit counters, so the scatter is stable without atomics on the
 // destination.  Pass 1 scatters 16-bit positions inside LDS (128 KiB); pass 2 scatters to
-// global memory as 128 sequential write streams per array, which the L2 merges into whole
-// lines because only one chunk per CU is in flight.
+// global memory as 128 sequential 2-byte write streams which the L2 / Infinity Cache merge
+// into whole lines because only one chunk per CU is in flight.  A scattered vector-memory
+// instruction costs the CU's memory pipe per lane, so pass 2 issues exactly two of them per
+// element batch: the 8-byte gather that recomputes the hash and the 2-byte store.
 #define FL_SORT_WAVES 16
 #define FL_SORT_THREADS (64 * FL_SORT_WAVES)
 #define FL_SORT_SLICE 4096u
@@ -99,35 +96,17 @@ __device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint
     return v;
 }
 
-// bytes p..p+3 and p+4..p+7 of the chunk (p <= N - 4), zero beyond N, with ONE 12-byte load
-// from the aligned dword below p (a scattered access costs the CU's memory pipe per
-// instruction, not per byte).  The third dword is only touched when it holds valid bytes.
-__device__ __forceinline__ void fl_load_prefix8(const uint8_t* src, uint32_t p, uint32_t N, bool ok, uint32_t& w0,
-                                                uint32_t& w1) {
-    w0 = 0;
-    w1 = 0;
-    if (!ok) return;
-    const uintptr_t a = (uintptr_t)(src + p);
-    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
-    const uint32_t nb = min(N - p, 8u);  // valid bytes from p (>= 4)
-    uint32_t d0, d1, d2;
-    if (sh + nb > 8) {
-        d0 = w[0];
-        d1 = w[1];
-        d2 = w[2];
-    } else if (sh + nb > 4) {
-        d0 = w[0];
-        d1 = w[1];
-        d2 = 0;
-    } else {
-        d0 = w[0];
-        d1 = 0;
-        d2 = 0;
+struct __attribute__((packed, aligned(4))) fl_u32x2 {
+    uint32_t a, b;
+};
+// bytes p..p+3 (p <= N - 4) with a single 8-byte load whenever both dwords are inside the chunk
+__device__ __forceinline__ uint32_t fl_gather_u32(const uint8_t* src, uint32_t p, uint32_t N) {
+    if (p + 8 <= N) {
+        const uintptr_t a = (uintptr_t)(src + p);
+        const fl_u32x2 w = *(const fl_u32x2*)(a & ~(uintptr_t)3);
+        return __builtin_amdgcn_alignbyte(w.b, w.a, (uint32_t)(a & 3));
     }
-    w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    if (nb < 8) w1 &= nb > 4 ? ((1u << (8 * (nb - 4))) - 1) : 0u;
+    return fl_load_u32_clamped(src, p, N);
 }
 
 // Exclusive scan of a [waves][ndig] counter table in (digit major, wave minor) order, in
@@ -159,8 +138,7 @@ __device__ __forceinline__ void fl_scan_counters(uint32_t (*cnt)[NDIG], uint32_t
 
 __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
-                                                              uint16_t* __restrict__ S, uint2* __restrict__ W01,
-                                                              uint16_t* __restrict__ NC) {
+                                                              uint16_t* __restrict__ S) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
@@ -173,8 +151,6 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint2* Wo = W01 + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint16_t* NCo = NC + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t slice0 = wave * FL_SORT_SLICE;
 
@@ -183,15 +159,15 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     for (uint32_t i = tid; i < FL_SORT_WAVES * 128; i += FL_SORT_THREADS) (&cnt2[0][0])[i] = 0;
     __syncthreads();
     // ---- pass 1 count: low 8 bits of the hash ----
-    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
-        uint32_t w[4];
+    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 8) {
+        uint32_t w[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
             const uint32_t p = slice0 + (r + u) * 64 + lane;
             w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 8; u++)
             if (slice0 + (r + u) * 64 + lane < M) atomicAdd(&cnt1[wave][fl_hash_le(w[u]) & 255], 1u);
     }
     __syncthreads();
@@ -237,27 +213,26 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     fl_scan_counters<128, 2>(cnt2, wsum, tid);
     fl_prof_mark(4);
     // ---- pass 2 scatter: high 7 bits, to global memory ----
-    uint32_t ppn[4], a0n[4], a1n[4];
+    uint32_t ppn[4], a0n[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const uint32_t e = slice0 + u * 64 + lane;
         ppn[u] = e < M ? tmp[e] : 0;
-        fl_load_prefix8(src, ppn[u], N, e < M, a0n[u], a1n[u]);
+        a0n[u] = e < M ? fl_gather_u32(src, ppn[u], N) : 0;
     }
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
-        uint32_t pp[4], a0[4], a1[4];
+        uint32_t pp[4], a0[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             pp[u] = ppn[u];
             a0[u] = a0n[u];
-            a1[u] = a1n[u];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // next group's gathers fly while this one is ranked
             const uint32_t e = slice0 + (r + 4 + u) * 64 + lane;
             const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < M;
             ppn[u] = okn ? tmp[e] : 0;
-            fl_load_prefix8(src, ppn[u], N, okn, a0n[u], a1n[u]);
+            a0n[u] = okn ? fl_gather_u32(src, ppn[u], N) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -266,58 +241,18 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t d = fl_hash_le(a0[u]) >> 8;
             const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-            if (valid) {
-                const uint32_t dst = cnt2[wave][d] + rank;
-                So[dst] = (uint16_t)pp[u];
-                Wo[dst] = make_uint2(a0[u], a1[u]);
-            }
+            if (valid) So[cnt2[wave][d] + rank] = (uint16_t)pp[u];
             fl_lds_order();
             if (valid && rank == np - 1) cnt2[wave][d] += np;
             fl_lds_order();
         }
     }
-    __syncthreads();  // W0 of the whole chunk is complete and visible inside the workgroup
     fl_prof_mark(5);
-    // ---- bucket offsets: NC[i] = i - (first sorted index with the same hash) ----
-    // sweep 1: last bucket start inside each wave's slice
-    uint32_t last_start = 0;
-    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
-        const uint32_t i = slice0 + r * 64 + lane;
-        const bool valid = i < M;
-        const uint32_t h = valid ? fl_hash_le(Wo[i].x) : 0xffffffffu;
-        uint32_t hp = __shfl_up(h, 1, 64);
-        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(Wo[i - 1].x) : 0xfffffffeu;
-        const uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;  // i + 1 so that 0 = none
-        last_start = max(last_start, fl_wave_max(st));
-    }
-    if (lane == 0) wsum[wave] = last_start;
-    __syncthreads();
-    fl_prof_mark(6);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < wave; w++) carry = max(carry, wsum[w]);
-    // sweep 2: offsets
-    for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r++) {
-        const uint32_t i = slice0 + r * 64 + lane;
-        const bool valid = i < M;
-        const uint32_t h = valid ? fl_hash_le(Wo[i].x) : 0xffffffffu;
-        uint32_t hp = __shfl_up(h, 1, 64);
-        if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(Wo[i - 1].x) : 0xfffffffeu;
-        uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
-        // inclusive prefix max across lanes
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(st, d, 64);
-            if (lane >= (uint32_t)d) st = max(st, o);
-        }
-        st = max(st, carry);
-        if (valid) NCo[i] = (uint16_t)(i + 1 - st);
-        carry = __shfl(st, 63, 64);
-    }
-    fl_prof_mark(7);
 }
 
 // ------------------------------------------------------------------ k_lz_match
 #define FL_MATCH_WAVES 16
+#define FL_MATCH_THREADS (64 * FL_MATCH_WAVES)
 #define FL_KB 32                 // candidates per tile
 #define FL_TILE (FL_KB + 64)     // FL_KB back + 64 lanes
 
@@ -325,13 +260,22 @@ __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t
     const uint32_t i = off >> 2;
     return __builtin_amdgcn_alignbyte(win32[i + 1], win32[i], off & 3);
 }
+// window bytes off..off+3 and off+4..off+7
+__device__ __forceinline__ void fl_lds_load8(const uint32_t* win32, uint32_t off, uint32_t& w0, uint32_t& w1) {
+    const uint32_t i = off >> 2, sh = off & 3;
+    const uint32_t d0 = win32[i], d1 = win32[i + 1], d2 = win32[i + 2];
+    w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+}
 
 // exact common prefix of the window at p and q, known to be >= 8, capped at maxlen
 __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t maxlen) {
     uint32_t len = 8;
     while (len < maxlen) {
-        const uint32_t y0 = fl_lds_load4(win32, p + len) ^ fl_lds_load4(win32, q + len);
-        const uint32_t y1 = fl_lds_load4(win32, p + len + 4) ^ fl_lds_load4(win32, q + len + 4);
+        uint32_t a0, a1, b0, b1;
+        fl_lds_load8(win32, p + len, a0, a1);
+        fl_lds_load8(win32, q + len, b0, b1);
+        const uint32_t y0 = a0 ^ b0, y1 = a1 ^ b1;
         if (y0) {
             len += (uint32_t)__builtin_ctz(y0) >> 3;
             break;
@@ -345,26 +289,29 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
     return min(len, maxlen);
 }
 
-// rec[c][2p]   = record for the full chain budget
-// rec[c][2p+1] = record for chain >> 2       (0 = no match, else len << 16 | dist-1)
+// rec[c][p] = { record for the full chain budget, record for chain >> 2 }
+//             (0 = no match, else len << 16 | dist-1)
 //
 // Lane = one sorted entry, loop = its chain candidates (the preceding entries of its hash
 // bucket, nearest first).  `n` is the number of candidates the lane may still look at:
 // min(bucket offset, chain); it drops to 0 at the null position / beyond the window / once
-// a match of `nice` is found.  Candidates whose first 8 bytes settle the comparison (the
-// common case) are handled with a handful of VALU ops on registers; the window in LDS is
-// only read to extend a match beyond 8 bytes.  The per-candidate predicates are kept in
-// integer form (few lane masks => little scalar-unit work, which is what bounds this loop).
-__global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8_t* __restrict__ in,
-                                                                     const fl_chunk* __restrict__ chunks,
-                                                                     fl_params prm, const uint16_t* __restrict__ S,
-                                                                     const uint2* __restrict__ W01,
-                                                                     const uint16_t* __restrict__ NC,
-                                                                     uint32_t* __restrict__ rec_all) {
+// a match of `nice` is found.  The first 8 bytes of every entry are gathered from the LDS
+// window when a tile of sorted entries is loaded, so a candidate whose first 8 bytes settle
+// the comparison (the common case) costs a handful of VALU ops on registers; the window
+// is read again only to extend a match beyond 8 bytes.  Candidates go in groups of four:
+// when no lane of the wave needs the window for any of the four, the group takes a
+// branch-free path.  Predicates are kept in integer form (few lane masks => little
+// scalar-unit work, which is what bounded the first versions of this loop).
+__global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
+                                                                  const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                  const uint16_t* __restrict__ S,
+                                                                  uint16_t* __restrict__ NC,
+                                                                  uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
     __shared__ uint32_t tW0[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint32_t tW1[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint16_t tS[FL_MATCH_WAVES][FL_TILE];
+    __shared__ uint32_t wlast[FL_MATCH_WAVES];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
@@ -373,22 +320,75 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint2* Wc = W01 + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint16_t* NCc = NC + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
-    uint2* rec2 = (uint2*)rec;
+    uint16_t* NCc = NC + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint2* rec2 = (uint2*)(rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE);
 
     fl_prof_mark(8);
     // stage the chunk in LDS (zero padded)
     const uint32_t ndw = (N + 3) >> 2;
-    for (uint32_t i = tid; i < 16384 + 8; i += 64 * FL_MATCH_WAVES)
+    for (uint32_t i = tid; i < 16384 + 8; i += FL_MATCH_THREADS)
         win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
     // positions without a hash entry never match (Lookup.zig:24)
-    for (uint32_t p = M + tid; p < N; p += 64 * FL_MATCH_WAVES) {
-        rec[2 * p] = 0;
-        rec[2 * p + 1] = 0;
-    }
+    for (uint32_t p = M + tid; p < N; p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
     __syncthreads();
+    fl_prof_mark(9);
+
+    // ---- bucket offsets: NC[i] = i - (first sorted index with the same hash) = the number of
+    // chain predecessors of entry i.  Wave w owns sorted indices [4096 w, 4096 (w+1)).
+    {
+        const uint32_t slice0 = wave * 4096u;
+        uint32_t last_start = 0;
+        for (uint32_t r = 0; r < 64; r += 4) {
+            uint32_t sp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = slice0 + (r + u) * 64 + lane;
+                sp[u] = i < M ? Sc[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = slice0 + (r + u) * 64 + lane;
+                const bool valid = i < M;
+                const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, sp[u])) : 0xffffffffu;
+                uint32_t hp = __shfl_up(h, 1, 64);
+                if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(fl_lds_load4(win32, Sc[i - 1])) : 0xfffffffeu;
+                const uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;  // i + 1 so that 0 = none
+                last_start = max(last_start, st);
+            }
+        }
+        last_start = fl_wave_max(last_start);
+        if (lane == 0) wlast[wave] = last_start;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w = 0; w < wave; w++) carry = max(carry, wlast[w]);
+        for (uint32_t r = 0; r < 64; r += 4) {
+            uint32_t sp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = slice0 + (r + u) * 64 + lane;
+                sp[u] = i < M ? Sc[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = slice0 + (r + u) * 64 + lane;
+                const bool valid = i < M;
+                const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, sp[u])) : 0xffffffffu;
+                uint32_t hp = __shfl_up(h, 1, 64);
+                if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(fl_lds_load4(win32, Sc[i - 1])) : 0xfffffffeu;
+                uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {  // inclusive prefix max across lanes
+                    const uint32_t o = __shfl_up(st, d, 64);
+                    if (lane >= (uint32_t)d) st = max(st, o);
+                }
+                st = max(st, carry);
+                if (valid) NCc[i] = (uint16_t)(i + 1 - st);
+                carry = __shfl(st, 63, 64);
+            }
+        }
+        __syncthreads();  // NC is read back by other waves below
+    }
+    fl_prof_mark(10);
 
     const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
     const uint32_t nbatch = (M + 63) >> 6;
@@ -396,34 +396,28 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
     uint32_t* tw0 = tW0[wave];
     uint32_t* tw1 = tW1[wave];
 
-    fl_prof_mark(9);
-    // software pipeline: the next batch's own entries are fetched while this one is searched
-    uint32_t nx_p = 0, nx_p0 = 0, nx_p1 = 0, nx_n = 0;
+    // software pipeline: the next batch's own entry is fetched while this one is searched
+    uint32_t nx_p = 0, nx_n = 0;
     {
         const uint32_t i = (wave << 6) + lane;
         if (wave < nbatch && i < M) {
-            const uint2 w = Wc[i];
             nx_p = Sc[i];
-            nx_p0 = w.x;
-            nx_p1 = w.y;
             nx_n = NCc[i];
         }
     }
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const bool active = i < M;
-        const uint32_t p = nx_p, p0 = nx_p0, p1 = nx_p1;
+        const uint32_t p = nx_p;
         uint32_t n = active ? min(nx_n, chain) : 0;  // candidates left to look at
         {
-            const uint32_t bn = batch + FL_MATCH_WAVES;
-            const uint32_t in_ = (bn << 6) + lane;
-            const bool okn = bn < nbatch && in_ < M;
-            const uint2 w = okn ? Wc[in_] : make_uint2(0u, 0u);
+            const uint32_t in_ = ((batch + FL_MATCH_WAVES) << 6) + lane;
+            const bool okn = batch + FL_MATCH_WAVES < nbatch && in_ < M;
             nx_p = okn ? Sc[in_] : 0;
-            nx_p0 = w.x;
-            nx_p1 = w.y;
             nx_n = okn ? NCc[in_] : 0;
         }
+        uint32_t p0, p1;
+        fl_lds_load8(win32, p, p0, p1);
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248) and
         // p - q <= 32768 (deflate.zig:250-251); both end the walk
         const uint32_t lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
@@ -433,16 +427,18 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
         bool qsnap = false;
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
-            // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64)
+            // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64) with their first 8 bytes
             fl_lds_order();
 #pragma unroll
             for (uint32_t t = lane; t < FL_TILE; t += 64) {
                 const int32_t idx = (int32_t)i0 - (int32_t)kb - FL_KB + (int32_t)t;
                 const bool ok = idx >= 0 && idx < (int32_t)M;
-                const uint2 w = ok ? Wc[idx] : make_uint2(0u, 0u);
-                ts[t] = ok ? Sc[idx] : 0;
-                tw0[t] = w.x;
-                tw1[t] = w.y;
+                const uint32_t q = ok ? Sc[idx] : 0;
+                uint32_t a0, a1;
+                fl_lds_load8(win32, q, a0, a1);
+                ts[t] = (uint16_t)q;
+                tw0[t] = a0;
+                tw1[t] = a1;
             }
             fl_lds_order();
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
@@ -454,37 +450,59 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
                     qsnap = true;
                 }
                 if (!__any(n >= kb + kk0)) break;
+                const uint32_t tb = FL_KB + lane - kk0 - 3;  // tile slot of the group's last candidate
+                uint32_t q[4], w0[4], w1[4], len[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
-                    const uint32_t kk = kk0 + u;
-                    const uint32_t k = kb + kk;
-                    const uint32_t t = FL_KB + lane - kk;
-                    const uint32_t q = ts[t], w0 = tw0[t], w1 = tw1[t];
-                    // the walk ends at the first candidate below `lo`
-                    n = q >= lo ? n : min(n, k - 1);
-                    const uint32_t x = w1 ^ p1;
+                    q[u] = ts[tb + 3 - u];
+                    w0[u] = tw0[tb + 3 - u];
+                    w1[u] = tw1[tb + 3 - u];
+                }
+                uint32_t zmin = 0xffffffffu;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t k = kb + kk0 + u;
+                    n = q[u] >= lo ? n : min(n, k - 1);  // the walk ends at the first candidate below `lo`
+                    const uint32_t x = w1[u] ^ p1;
                     // common prefix from the two prefix words: 4..7, or 8 when they agree
-                    // (ffbl(0) = ~0 -> min(.., 4) = 4)
-                    uint32_t len = 4u + min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
-                    len = min(len, maxlen);
+                    // (ffs(0) - 1 = ~0 -> min(.., 4) = 4)
+                    uint32_t l = 4u + min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
+                    l = min(l, maxlen);
                     // bad != 0: beyond the lane's candidates, or the first four bytes differ
                     // (another 4-gram with the same hash)
-                    const uint32_t bad = (w0 ^ p0) | ((n - k) >> 31);
-                    len = bad ? 0u : len;
-                    if (__any((bad | x) == 0 && maxlen > max(best, 8u))) {
+                    const uint32_t bad = (w0[u] ^ p0) | ((n - k) >> 31);
+                    len[u] = bad ? 0u : l;
+                    zmin = min(zmin, bad | x);
+                }
+                // does any lane have a candidate whose 8 prefix bytes all agree and that could
+                // still beat its best?  (best only moves within <= 8 inside a quiet group)
+                if (!__any(zmin == 0 && maxlen > max(best, 8u))) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {  // deflate.zig:254-261, lengths <= 8 < nice
+                        const bool up = len[u] > best;
+                        bdist = up ? p - q[u] : bdist;
+                        best = max(best, len[u]);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t k = kb + kk0 + u;
+                        const uint32_t x = w1[u] ^ p1;
+                        const uint32_t bad = (w0[u] ^ p0) | ((n - k) >> 31);  // n may have dropped to 0
+                        uint32_t l = bad ? 0u : len[u];
                         if ((bad | x) == 0 && maxlen > max(best, 8u)) {
                             // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
                             // candidate that does not extend the best match is dropped on one compare
                             bool cand = true;
-                            if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
-                            len = cand ? fl_extend_match(win32, p, q, maxlen) : 0u;
+                            if (best >= 8) cand = fl_lds_load4(win32, q[u] + best - 3) == pb;
+                            l = cand ? fl_extend_match(win32, p, q[u], maxlen) : 0u;
                         }
-                    }
-                    if (len > best) {  // deflate.zig:254-261
-                        best = len;
-                        bdist = p - q;
-                        if (len >= nice) n = 0;
-                        if (len >= 8) pb = fl_lds_load4(win32, p + len - 3);
+                        if (l > best) {  // deflate.zig:254-261
+                            best = l;
+                            bdist = p - q[u];
+                            if (l >= nice) n = 0;
+                            if (l >= 8) pb = fl_lds_load4(win32, p + l - 3);
+                        }
                     }
                 }
             }
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(64 * FL_MATCH_WAVES, 8) void k_lz_match(const uint8
         if (active)
             rec2[p] = make_uint2(best ? ((best << 16) | (bdist - 1)) : 0u, qbest ? ((qbest << 16) | (qdist - 1)) : 0u);
     }
-    fl_prof_mark(10);
+    fl_prof_mark(11);
 }
 
 // ------------------------------------------------------------------ k_lz_parse
@@ -510,18 +528,22 @@ __device__ __forceinline__ uint32_t fl_desc_next(uint32_t d, uint32_t p) {
     return p + ((d >> 23) & 0xff) + ((d >> 15) & 0xff) + 3;
 }
 
-// deflate.zig:154-194 seen from a position visited with no pending match.
-__device__ __forceinline__ uint32_t fl_anchor_desc(const uint32_t* __restrict__ rec, uint32_t p, uint32_t N,
+// deflate.zig:154-194 seen from a position visited with no pending match.  ra / rb are the
+// records of p and p + 1.
+__device__ __forceinline__ uint32_t fl_anchor_desc(const uint2* __restrict__ rec2, uint32_t p, uint2 ra, uint2 rb,
                                                    uint32_t good, uint32_t lazy) {
-    const uint2* rec2 = (const uint2*)rec;
-    const uint2 ra = rec2[p];                                        // both budgets of p
-    const uint2 rb = p + 1 < N ? rec2[p + 1] : make_uint2(0u, 0u);  // ... and of p + 1 (one round trip)
     const uint32_t r = ra.x;  // findMatch(pos, lh, 0): full budget
     if (!r) return 0;
     uint32_t len = r >> 16, dist0 = r & 0x7fff, j = 0, q = p;
     while (len < lazy) {  // deflate.zig:171-178: keep the match, look one position further
         const uint32_t sel = len >= good ? 1u : 0u;  // deflate.zig:242-245
-        const uint32_t r2 = j == 0 ? (sel ? rb.y : rb.x) : rec[2 * (q + 1) + sel];
+        uint32_t r2;
+        if (j == 0) {
+            r2 = sel ? rb.y : rb.x;
+        } else {
+            const uint2 rr = rec2[q + 1];
+            r2 = sel ? rr.y : rr.x;
+        }
         const uint32_t l2 = r2 >> 16;
         if (l2 <= len) break;  // deflate.zig:182-184: no better match, the pending one goes out
         len = l2;              // deflate.zig:166-168: better match, the pending one becomes a literal
@@ -532,54 +554,46 @@ __device__ __forceinline__ uint32_t fl_anchor_desc(const uint32_t* __restrict__ 
     return 0x80000000u | (j << 23) | ((len - 3) << 15) | dist0;
 }
 
-struct fl_chunk_tok {
-    uint32_t ntok;
-};
-
-__global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ in,
-                                                                const fl_chunk* __restrict__ chunks,
-                                                                fl_params prm, const uint32_t* __restrict__ rec_all,
+// One workgroup per chunk: which positions are anchors (visited with no pending match)?
+// Output: desc[c][p] for every position and the anchor bit set marks[c][2048].
+__global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                const uint32_t* __restrict__ rec_all,
                                                                 uint32_t* __restrict__ desc_all,
-                                                                uint32_t* __restrict__ tokens_all,
-                                                                uint32_t* __restrict__ hist_all,
-                                                                fl_block_plan* __restrict__ plans,
-                                                                uint32_t* __restrict__ ntok_all) {
+                                                                uint32_t* __restrict__ marks_all) {
     __shared__ uint16_t J[65536];
     __shared__ uint32_t marks[2048];
     __shared__ uint16_t entry[256];
-    __shared__ uint32_t hist[2][320];
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t v1_sh;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    fl_block_plan* plan0 = &plans[ck.first_block];
-    fl_block_plan* plan1 = &plans[ck.first_block + 1];
-    if (ck.skip) {
-        if (tid == 0) {
-            plan0->valid = 0;
-            plan1->valid = 0;
-            ntok_all[c] = 0;
-        }
-        return;
-    }
+    const uint32_t tid = threadIdx.x;
+    if (ck.skip) return;
     const uint32_t N = ck.in_len;
-    const uint8_t* src = in + ck.in_off;
-    const uint32_t* rec = rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE;
+    const uint2* rec2 = (const uint2*)(rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE);
     uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* tokens = tokens_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* gmarks = marks_all + (uint64_t)c * 2048;
 
     fl_prof_mark(16);
-    // (a) anchor function for every position
-    for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
-        const uint32_t d = fl_anchor_desc(rec, p, N, prm.good, prm.lazy);
-        desc[p] = d;
-        J[p] = (uint16_t)fl_desc_next(d, p);
+    // (a) anchor function for every position, 8 positions per thread per round trip
+    for (uint32_t base = 0; base < N; base += FL_PARSE_THREADS * 8) {
+        uint2 ra[8], rb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            ra[u] = p < N ? rec2[p] : make_uint2(0u, 0u);
+            rb[u] = p + 1 < N ? rec2[p + 1] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            if (p < N) {
+                const uint32_t d = fl_anchor_desc(rec2, p, ra[u], rb[u], prm.good, prm.lazy);
+                desc[p] = d;
+                J[p] = (uint16_t)fl_desc_next(d, p);
+            }
+        }
     }
     for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) marks[i] = 0;
-    for (uint32_t i = tid; i < 640; i += FL_PARSE_THREADS) (&hist[0][0])[i] = 0;
     if (tid < 256) entry[tid] = 0xffff;
-    if (tid == 0) v1_sh = N;
     __syncthreads();
     fl_prof_mark(17);
     // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
@@ -605,7 +619,19 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
     __syncthreads();
     fl_prof_mark(19);
     // (d) restore the one-step pointers
-    for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) J[p] = (uint16_t)fl_desc_next(desc[p], p);
+    for (uint32_t base = 0; base < N; base += FL_PARSE_THREADS * 8) {
+        uint32_t d[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            d[u] = p < N ? desc[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            if (p < N) J[p] = (uint16_t)fl_desc_next(d[u], p);
+        }
+    }
     __syncthreads();
     fl_prof_mark(20);
     // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
@@ -619,61 +645,131 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const uint8_t* __
     }
     __syncthreads();
     fl_prof_mark(21);
-    // (f) token counts: thread t owns positions [64 t, 64 t + 64)
+    for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) gmarks[i] = marks[i];
+}
+
+// ------------------------------------------------------------------ k_lz_emit
+// One workgroup per chunk: turn the anchors into the token list (deflate.zig:213-230), the
+// per-block symbol histograms (block_writer.zig:455-462) and the block boundaries
+// (32768 tokens per block, deflate.zig:227-230, 268-288).  Lane = position: descriptors are
+// read coalesced, literal bytes come from the LDS window, token offsets from wave prefix sums.
+#define FL_EMIT_WAVES 8
+#define FL_EMIT_THREADS (64 * FL_EMIT_WAVES)
+#define FL_EMIT_SPAN (65536u / FL_EMIT_WAVES)  // positions per wave
+
+__device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t off) {
+    return (win32[off >> 2] >> (8 * (off & 3))) & 0xff;
+}
+
+__global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __restrict__ in,
+                                                              const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                              const uint32_t* __restrict__ desc_all,
+                                                              const uint32_t* __restrict__ marks_all,
+                                                              uint32_t* __restrict__ tokens_all,
+                                                              uint32_t* __restrict__ hist_all,
+                                                              fl_block_plan* __restrict__ plans,
+                                                              uint32_t* __restrict__ ntok_all) {
+    __shared__ uint32_t win32[16384 + 8];
+    __shared__ uint32_t marks[2048];
+    __shared__ uint32_t hist[2][320];
+    __shared__ uint32_t wtot[FL_EMIT_WAVES];
+    __shared__ uint32_t v1_sh;
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fl_block_plan* plan0 = &plans[ck.first_block];
+    fl_block_plan* plan1 = &plans[ck.first_block + 1];
+    if (ck.skip) {
+        if (tid == 0) {
+            plan0->valid = 0;
+            plan1->valid = 0;
+            ntok_all[c] = 0;
+        }
+        return;
+    }
+    const uint32_t N = ck.in_len;
+    const uint8_t* src = in + ck.in_off;
+    const uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t* gmarks = marks_all + (uint64_t)c * 2048;
+    uint32_t* tokens = tokens_all + (uint64_t)c * FL_CHUNK_STRIDE;
+
+    fl_prof_mark(24);
+    const uint32_t ndw = (N + 3) >> 2;
+    for (uint32_t i = tid; i < 16384 + 8; i += FL_EMIT_THREADS)
+        win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
+    for (uint32_t i = tid; i < 2048; i += FL_EMIT_THREADS) marks[i] = gmarks[i];
+    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS) (&hist[0][0])[i] = 0;
+    if (tid == 0) v1_sh = N;
+    __syncthreads();
+    fl_prof_mark(25);
+    const uint32_t span0 = wave * FL_EMIT_SPAN;
+    // pass 1: tokens per wave
     uint32_t cnt = 0;
-    for (int w = 0; w < 2; w++) {
-        uint32_t m = marks[2 * tid + w];
-        while (m) {
-            const uint32_t p = 64 * tid + 32 * w + (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            const uint32_t d = desc[p];
-            cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
+    for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            d[u] = p < N ? desc[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            cnt += mk ? (d[u] ? ((d[u] >> 23) & 0xff) + 1 : 1) : 0;
         }
     }
-    const uint32_t incl = fl_wave_incl_scan(cnt, lane);
-    if (lane == 63) wsum[wave] = incl;
+    cnt = fl_wave_sum(cnt);
+    if (lane == 0) wtot[wave] = cnt;
     __syncthreads();
-    uint32_t base = incl - cnt;
-    uint32_t total = 0;
-    for (uint32_t w = 0; w < 16; w++) {
-        if (w < wave) base += wsum[w];
-        total += wsum[w];
+    fl_prof_mark(26);
+    uint32_t run = 0, total = 0;
+    for (uint32_t w = 0; w < FL_EMIT_WAVES; w++) {
+        if (w < wave) run += wtot[w];
+        total += wtot[w];
     }
-    fl_prof_mark(22);
-    // (g) emit tokens + histograms (block_writer.zig:455-462)
-    uint32_t idx = base;
-    for (int w = 0; w < 2; w++) {
-        uint32_t m = marks[2 * tid + w];
-        while (m) {
-            const uint32_t p = 64 * tid + 32 * w + (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            const uint32_t d = desc[p];
-            const uint32_t nl = d ? ((d >> 23) & 0xff) : 1;
+    // pass 2: emit
+    for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            d[u] = p < N ? desc[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            const uint32_t dd = d[u];
+            const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;  // literals of this anchor
+            const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
+            const uint32_t incl = fl_wave_incl_scan(nt, lane);
+            uint32_t idx = run + incl - nt;
+            run += __shfl(incl, 63, 64);
             for (uint32_t x = 0; x < nl; x++) {
-                const uint32_t byte = src[p + x];
+                const uint32_t byte = fl_win_byte(win32, p + x);
                 tokens[idx] = FL_TOK_LIT(byte);
                 atomicAdd(&hist[idx >> 15][byte], 1u);
                 if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
                 idx++;
             }
-            if (d) {
-                const uint32_t ll = (d >> 15) & 0xff, d0 = d & 0x7fff;
+            if (mk && dd) {
+                const uint32_t ll = (dd >> 15) & 0xff, d0 = dd & 0x7fff;
                 tokens[idx] = (1u << 23) | (ll << 15) | d0;
                 atomicAdd(&hist[idx >> 15][257 + fl_len_index(ll)], 1u);
                 atomicAdd(&hist[idx >> 15][286 + fl_dist_code(d0)], 1u);
                 // a match of at least `lazy` goes out at its own visit, a shorter one at the next
                 // (deflate.zig:171-173 vs 182-184); rp at that moment decides the Q1 input slice
                 if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
-                idx++;
             }
         }
     }
     __syncthreads();
-    fl_prof_mark(23);
-    // (h) block boundaries (deflate.zig:227-230, 268-288) and histograms
+    fl_prof_mark(27);
+    // block boundaries (deflate.zig:227-230, 268-288) and histograms
     const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
     uint32_t* h0 = hist_all + (uint64_t)ck.first_block * 320;
-    for (uint32_t i = tid; i < 640; i += FL_PARSE_THREADS)
+    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS)
         if (i < 320 * nblk) h0[i] = (&hist[0][0])[i];
     if (tid == 0) {
         ntok_all[c] = total;

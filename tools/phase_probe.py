@@ -16,7 +16,8 @@ t = eng.phase_cycles().astype(np.int64)
 def seg(name, a, b): print("%-28s %10d cycles" % (name, t[b] - t[a]))
 print("n_chunks", len(chunks))
 seg("sort: zero+count1", 0, 1); seg("sort: scan1", 1, 2); seg("sort: scatter1 (LDS)", 2, 3); seg("sort: scan2", 3, 4)
-seg("sort: scatter2 (global)", 4, 5); seg("sort: NC sweep1", 5, 6); seg("sort: NC sweep2", 6, 7); seg("sort: total", 0, 7)
-seg("match: stage window", 8, 9); seg("match: batches", 9, 10)
+seg("sort: scatter2 (global)", 4, 5); seg("sort: total", 0, 5)
+seg("match: stage window", 8, 9); seg("match: bucket offsets", 9, 10); seg("match: batches", 10, 11); seg("match: total", 8, 11)
 seg("parse: (a) desc", 16, 17); seg("parse: (b) jump", 17, 18); seg("parse: (c) serial", 18, 19); seg("parse: (d) restore", 19, 20)
-seg("parse: (e) mark", 20, 21); seg("parse: (f) count", 21, 22); seg("parse: (g) emit", 22, 23); seg("parse: total", 16, 23)
+seg("parse: (e) mark", 20, 21); seg("parse: total", 16, 21)
+seg("emit: stage", 24, 25); seg("emit: count", 25, 26); seg("emit: emit", 26, 27); seg("emit: total", 24, 27)
