@@ -337,26 +337,21 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     // chain predecessors of entry i.  Wave w owns sorted indices [4096 w, 4096 (w+1)).
     {
         const uint32_t slice0 = wave * 4096u;
-        uint32_t last_start = 0;
-        for (uint32_t r = 0; r < 64; r += 4) {
-            uint32_t sp[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = slice0 + (r + u) * 64 + lane;
-                sp[u] = i < M ? Sc[i] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = slice0 + (r + u) * 64 + lane;
-                const bool valid = i < M;
-                const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, sp[u])) : 0xffffffffu;
-                uint32_t hp = __shfl_up(h, 1, 64);
-                if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(fl_lds_load4(win32, Sc[i - 1])) : 0xfffffffeu;
-                const uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;  // i + 1 so that 0 = none
-                last_start = max(last_start, st);
+        // last bucket start at or before the end of this wave's slice: walk back from the end
+        // (buckets are short, so this almost always ends in the first step)
+        uint32_t last_start = 0;  // encoded i + 1, 0 = none
+        {
+            const uint32_t hi = min(slice0 + 4096u, M);
+            for (uint32_t e = hi; e > slice0 && last_start == 0; e = e > 64 ? e - 64 : 0) {
+                const int32_t i = (int32_t)e - 1 - (int32_t)lane;  // candidates e-1 .. e-64
+                const bool valid = i >= (int32_t)slice0;
+                const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, Sc[i])) : 0;
+                const uint32_t hp = (valid && i > 0) ? fl_hash_le(fl_lds_load4(win32, Sc[i - 1])) : ~0u;
+                const uint32_t st = (valid && (i == 0 || h != hp)) ? (uint32_t)i + 1 : 0;
+                last_start = fl_wave_max(st);
+                if (e <= slice0 + 64) break;
             }
         }
-        last_start = fl_wave_max(last_start);
         if (lane == 0) wlast[wave] = last_start;
         __syncthreads();
         uint32_t carry = 0;
@@ -425,20 +420,34 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
         uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
         bool qsnap = false;
+        // positions of the tile entries, fetched one tile ahead: slots lane and lane + 64 (< FL_TILE)
+        uint32_t tq0, tq1;
+        {
+            const int32_t ia = (int32_t)i0 - FL_KB + (int32_t)lane, ib = ia + 64;
+            tq0 = (ia >= 0 && ia < (int32_t)M) ? Sc[ia] : 0;
+            tq1 = (lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
+        }
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64) with their first 8 bytes
             fl_lds_order();
-#pragma unroll
-            for (uint32_t t = lane; t < FL_TILE; t += 64) {
-                const int32_t idx = (int32_t)i0 - (int32_t)kb - FL_KB + (int32_t)t;
-                const bool ok = idx >= 0 && idx < (int32_t)M;
-                const uint32_t q = ok ? Sc[idx] : 0;
+            {
                 uint32_t a0, a1;
-                fl_lds_load8(win32, q, a0, a1);
-                ts[t] = (uint16_t)q;
-                tw0[t] = a0;
-                tw1[t] = a1;
+                fl_lds_load8(win32, tq0, a0, a1);
+                ts[lane] = (uint16_t)tq0;
+                tw0[lane] = a0;
+                tw1[lane] = a1;
+                if (lane < FL_TILE - 64) {
+                    fl_lds_load8(win32, tq1, a0, a1);
+                    ts[lane + 64] = (uint16_t)tq1;
+                    tw0[lane + 64] = a0;
+                    tw1[lane + 64] = a1;
+                }
+            }
+            if (__any(n > kb + FL_KB)) {  // the following tile's positions fly during this tile's search
+                const int32_t ia = (int32_t)i0 - (int32_t)kb - 2 * FL_KB + (int32_t)lane, ib = ia + 64;
+                tq0 = (ia >= 0 && ia < (int32_t)M) ? Sc[ia] : 0;
+                tq1 = (lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
             }
             fl_lds_order();
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
@@ -451,57 +460,36 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 }
                 if (!__any(n >= kb + kk0)) break;
                 const uint32_t tb = FL_KB + lane - kk0 - 3;  // tile slot of the group's last candidate
-                uint32_t q[4], w0[4], w1[4], len[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    q[u] = ts[tb + 3 - u];
-                    w0[u] = tw0[tb + 3 - u];
-                    w1[u] = tw1[tb + 3 - u];
-                }
-                uint32_t zmin = 0xffffffffu;
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     const uint32_t k = kb + kk0 + u;
-                    n = q[u] >= lo ? n : min(n, k - 1);  // the walk ends at the first candidate below `lo`
-                    const uint32_t x = w1[u] ^ p1;
+                    const uint32_t q = ts[tb + 3 - u], w0 = tw0[tb + 3 - u], w1 = tw1[tb + 3 - u];
+                    n = q >= lo ? n : min(n, k - 1);  // the walk ends at the first candidate below `lo`
+                    const uint32_t x = w1 ^ p1;
                     // common prefix from the two prefix words: 4..7, or 8 when they agree
                     // (ffs(0) - 1 = ~0 -> min(.., 4) = 4)
                     uint32_t l = 4u + min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
                     l = min(l, maxlen);
                     // bad != 0: beyond the lane's candidates, or the first four bytes differ
                     // (another 4-gram with the same hash)
-                    const uint32_t bad = (w0[u] ^ p0) | ((n - k) >> 31);
-                    len[u] = bad ? 0u : l;
-                    zmin = min(zmin, bad | x);
-                }
-                // does any lane have a candidate whose 8 prefix bytes all agree and that could
-                // still beat its best?  (best only moves within <= 8 inside a quiet group)
-                if (!__any(zmin == 0 && maxlen > max(best, 8u))) {
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {  // deflate.zig:254-261, lengths <= 8 < nice
-                        const bool up = len[u] > best;
-                        bdist = up ? p - q[u] : bdist;
-                        best = max(best, len[u]);
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        const uint32_t k = kb + kk0 + u;
-                        const uint32_t x = w1[u] ^ p1;
-                        const uint32_t bad = (w0[u] ^ p0) | ((n - k) >> 31);  // n may have dropped to 0
-                        uint32_t l = bad ? 0u : len[u];
-                        if ((bad | x) == 0 && maxlen > max(best, 8u)) {
+                    const uint32_t bad = (w0 ^ p0) | ((n - k) >> 31);
+                    l = bad ? 0u : l;
+                    const bool deep = (bad | x) == 0 && maxlen > max(best, 8u);
+                    if (__any(deep)) {
+                        if (deep) {
                             // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
                             // candidate that does not extend the best match is dropped on one compare
                             bool cand = true;
-                            if (best >= 8) cand = fl_lds_load4(win32, q[u] + best - 3) == pb;
-                            l = cand ? fl_extend_match(win32, p, q[u], maxlen) : 0u;
+                            if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
+                            l = cand ? fl_extend_match(win32, p, q, maxlen) : 0u;
                         }
-                        if (l > best) {  // deflate.zig:254-261
-                            best = l;
-                            bdist = p - q[u];
+                    }
+                    if (l > best) {  // deflate.zig:254-261
+                        best = l;
+                        bdist = p - q;
+                        if (l >= 8) {
                             if (l >= nice) n = 0;
-                            if (l >= 8) pb = fl_lds_load4(win32, p + l - 3);
+                            pb = fl_lds_load4(win32, p + l - 3);
                         }
                     }
                 }
