@@ -312,6 +312,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
     if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
     prm.container = container;
     prm.mode = mode;
+    prm.dbg = getenv("FLATE_HIP_DBG") ? (uint32_t)atoi(getenv("FLATE_HIP_DBG")) : 0u;
     hipStream_t st = h->stream;
 
     std::vector<uint64_t> hin, hout;
@@ -411,7 +412,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->NC, per * sizeof(uint16_t)))) return rc;
+            if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
             if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
@@ -423,7 +424,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             {
                 ProfScope ps(h, K_LZ_MATCH);
                 hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint16_t*)h->S.p, (uint16_t*)h->NC.p, (uint32_t*)h->rec.p);
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);

@@ -28,6 +28,7 @@ struct fl_params {
     int32_t mode;       // 0 store, 1 huffman, 4..9
     // level args (deflate.zig:41-52)
     uint32_t good, lazy, nice, chain;
+    uint32_t dbg;  // tuning experiments only (FLATE_HIP_DBG), 0 in production
 };
 
 // CRC-32 helper constants computed on the host once (reflected representation,

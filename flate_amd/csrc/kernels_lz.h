@@ -293,23 +293,26 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 //             (0 = no match, else len << 16 | dist-1)
 //
 // Lane = one sorted entry, loop = its chain candidates (the preceding entries of its hash
-// bucket, nearest first).  `n` is the number of candidates the lane may still look at:
-// min(bucket offset, chain); it drops to 0 at the null position / beyond the window / once
-// a match of `nice` is found.  The first 8 bytes of every entry are gathered from the LDS
-// window when a tile of sorted entries is loaded, so a candidate whose first 8 bytes settle
-// the comparison (the common case) costs a handful of VALU ops on registers; the window
-// is read again only to extend a match beyond 8 bytes.  Candidates go in groups of four:
-// when no lane of the wave needs the window for any of the four, the group takes a
-// branch-free path.  Predicates are kept in integer form (few lane masks => little
-// scalar-unit work, which is what bounded the first versions of this loop).
+// bucket, nearest first).  The first 8 bytes of every entry are gathered from the LDS window
+// when a tile of sorted entries is loaded, so a candidate whose first 8 bytes settle the
+// comparison (the common case) costs ~15 VALU ops on registers; the window is read again only
+// to extend a match beyond 8 bytes.
+//
+// How the reference's walk (deflate.zig:233-266) is encoded branch-free:
+//  * a lane may look at min(bucket offset, chain) candidates.  Positions fall along the
+//    chain, so "candidate number <= n" is the same as "position >= position of candidate n";
+//    that bound is merged with the window limit p - 32768 and the null position 0 into one
+//    per-lane lower bound `lov` (entries of other buckets that follow in the tile differ in
+//    their first four bytes, because the hash is a function of those bytes).
+//  * the best match so far is one 32-bit key  len << 16 | (65535 - dist):  a longer match
+//    wins, and for equal length the nearer one, which is the one the reference met first.
 __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks, fl_params prm,
                                                                   const uint16_t* __restrict__ S,
-                                                                  uint16_t* __restrict__ NC,
+                                                                  uint32_t* __restrict__ NQ,
                                                                   uint32_t* __restrict__ rec_all) {
     __shared__ uint32_t win32[16384 + 8];
-    __shared__ uint32_t tW0[FL_MATCH_WAVES][FL_TILE];
-    __shared__ uint32_t tW1[FL_MATCH_WAVES][FL_TILE];
+    __shared__ uint2 tW[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint16_t tS[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint32_t wlast[FL_MATCH_WAVES];
     const uint32_t c = blockIdx.x;
@@ -320,8 +323,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     const uint32_t M = N >= 4 ? N - 3 : 0;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint16_t* NCc = NC + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* NQc = NQ + (uint64_t)c * FL_CHUNK_STRIDE;
     uint2* rec2 = (uint2*)(rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE);
+    const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
 
     fl_prof_mark(8);
     // stage the chunk in LDS (zero padded)
@@ -333,8 +337,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     __syncthreads();
     fl_prof_mark(9);
 
-    // ---- bucket offsets: NC[i] = i - (first sorted index with the same hash) = the number of
-    // chain predecessors of entry i.  Wave w owns sorted indices [4096 w, 4096 (w+1)).
+    // ---- per entry: n = min(bucket offset, chain) = how many chain candidates it may look at,
+    // and qn = the position of candidate number n.  NQ[i] = n | qn << 16.
+    // Wave w owns sorted indices [4096 w, 4096 (w+1)).
     {
         const uint32_t slice0 = wave * 4096u;
         // last bucket start at or before the end of this wave's slice: walk back from the end
@@ -377,47 +382,51 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     if (lane >= (uint32_t)d) st = max(st, o);
                 }
                 st = max(st, carry);
-                if (valid) NCc[i] = (uint16_t)(i + 1 - st);
+                if (valid) {
+                    const uint32_t n = min(i + 1 - st, chain);
+                    const uint32_t qn = n ? Sc[i - n] : 0xffffu;
+                    NQc[i] = n | (qn << 16);
+                }
                 carry = __shfl(st, 63, 64);
             }
         }
-        __syncthreads();  // NC is read back by other waves below
+        __syncthreads();  // NQ is read back by other waves below
     }
     fl_prof_mark(10);
 
-    const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
     const uint32_t nbatch = (M + 63) >> 6;
     uint16_t* ts = tS[wave];
-    uint32_t* tw0 = tW0[wave];
-    uint32_t* tw1 = tW1[wave];
+    uint2* tw = tW[wave];
 
     // software pipeline: the next batch's own entry is fetched while this one is searched
-    uint32_t nx_p = 0, nx_n = 0;
+    uint32_t nx_p = 0, nx_nq = 0xffff0000u;
     {
         const uint32_t i = (wave << 6) + lane;
         if (wave < nbatch && i < M) {
             nx_p = Sc[i];
-            nx_n = NCc[i];
+            nx_nq = NQc[i];
         }
     }
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const bool active = i < M;
         const uint32_t p = nx_p;
-        uint32_t n = active ? min(nx_n, chain) : 0;  // candidates left to look at
+        uint32_t n = active ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only)
+        // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248),
+        // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
+        uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
+        if (n == 0) lov = 0x7fffffffu;
         {
             const uint32_t in_ = ((batch + FL_MATCH_WAVES) << 6) + lane;
             const bool okn = batch + FL_MATCH_WAVES < nbatch && in_ < M;
             nx_p = okn ? Sc[in_] : 0;
-            nx_n = okn ? NCc[in_] : 0;
+            nx_nq = okn ? NQc[in_] : 0xffff0000u;
         }
         uint32_t p0, p1;
         fl_lds_load8(win32, p, p0, p1);
-        // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248) and
-        // p - q <= 32768 (deflate.zig:250-251); both end the walk
-        const uint32_t lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
         const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
-        uint32_t best = 0, bdist = 0, qbest = 0, qdist = 0;
+        const uint32_t cp = 0xffffu - p;  // key low half = 65535 - (p - q) = q + cp
+        uint32_t key = 0, qkey = 0;
         uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
         bool qsnap = false;
         // positions of the tile entries, fetched one tile ahead: slots lane and lane + 64 (< FL_TILE)
@@ -435,13 +444,11 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 uint32_t a0, a1;
                 fl_lds_load8(win32, tq0, a0, a1);
                 ts[lane] = (uint16_t)tq0;
-                tw0[lane] = a0;
-                tw1[lane] = a1;
+                tw[lane] = make_uint2(a0, a1);
                 if (lane < FL_TILE - 64) {
                     fl_lds_load8(win32, tq1, a0, a1);
                     ts[lane + 64] = (uint16_t)tq1;
-                    tw0[lane + 64] = a0;
-                    tw1[lane + 64] = a1;
+                    tw[lane + 64] = make_uint2(a0, a1);
                 }
             }
             if (__any(n > kb + FL_KB)) {  // the following tile's positions fly during this tile's search
@@ -450,57 +457,66 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 tq1 = (lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
             }
             fl_lds_order();
+            // candidate kk of this tile sits in slot FL_KB + lane - kk; walk the slots downwards
+            const uint16_t* tsp = ts + FL_KB + lane;
+            const uint2* twp = tw + FL_KB + lane;
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
                 // the chain >> 2 budget (deflate.zig:241-245) ends after candidate `quarter`
                 // (a multiple of 4 at every level, deflate.zig:44-49)
                 if (kb + kk0 - 1 == quarter) {
-                    qbest = best;
-                    qdist = bdist;
+                    qkey = key;
                     qsnap = true;
                 }
                 if (!__any(n >= kb + kk0)) break;
-                const uint32_t tb = FL_KB + lane - kk0 - 3;  // tile slot of the group's last candidate
+                tsp -= 4;
+                twp -= 4;
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    const uint32_t k = kb + kk0 + u;
-                    const uint32_t q = ts[tb + 3 - u], w0 = tw0[tb + 3 - u], w1 = tw1[tb + 3 - u];
-                    n = q >= lo ? n : min(n, k - 1);  // the walk ends at the first candidate below `lo`
-                    const uint32_t x = w1 ^ p1;
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t q = tsp[3 - u];
+                    const uint2 w = twp[3 - u];
+                    const uint32_t x = w.y ^ p1;
                     // common prefix from the two prefix words: 4..7, or 8 when they agree
-                    // (ffs(0) - 1 = ~0 -> min(.., 4) = 4)
-                    uint32_t l = 4u + min(((uint32_t)__ffs((int)x) - 1u) >> 3, 4u);
-                    l = min(l, maxlen);
-                    // bad != 0: beyond the lane's candidates, or the first four bytes differ
-                    // (another 4-gram with the same hash)
-                    const uint32_t bad = (w0 ^ p0) | ((n - k) >> 31);
-                    l = bad ? 0u : l;
-                    const bool deep = (bad | x) == 0 && maxlen > max(best, 8u);
-                    if (__any(deep)) {
-                        if (deep) {
-                            // at least 8 bytes agree: go to the window.  SlidingWindow.zig:91-98: a
-                            // candidate that does not extend the best match is dropped on one compare
+                    // (v_ffbl_b32 of 0 is ~0), capped at maxlen
+                    uint32_t tz;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(x));
+                    const uint32_t l = min(min(4u + (tz >> 3), 8u), maxlen);
+                    // bad != 0: first four bytes differ (a colliding 4-gram or another bucket),
+                    // or the candidate is below the lane's lower bound
+                    const uint32_t bad = (w.x ^ p0) | ((q - lov) >> 31);
+                    uint32_t kc = bad ? 0u : ((l << 16) | (q + cp));
+                    if ((bad | x) == 0) {
+                        // all 8 prefix bytes agree: a longer match needs the window
+                        const uint32_t best = key >> 16;
+                        if (maxlen > max(best, 8u)) {
+                            // SlidingWindow.zig:91-98: a candidate that does not extend the best
+                            // match is dropped on one compare
                             bool cand = true;
                             if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
-                            l = cand ? fl_extend_match(win32, p, q, maxlen) : 0u;
+                            kc = 0;
+                            if (cand) {
+                                const uint32_t le = fl_extend_match(win32, p, q, maxlen);
+                                kc = (le << 16) | (q + cp);
+                                if (kc > key) {  // deflate.zig:254-261
+                                    pb = fl_lds_load4(win32, p + le - 3);
+                                    if (le >= nice) {  // deflate.zig:256-258: stop looking
+                                        n = 0;
+                                        lov = 0x7fffffffu;
+                                    }
+                                }
+                            }
                         }
                     }
-                    if (l > best) {  // deflate.zig:254-261
-                        best = l;
-                        bdist = p - q;
-                        if (l >= 8) {
-                            if (l >= nice) n = 0;
-                            pb = fl_lds_load4(win32, p + l - 3);
-                        }
-                    }
+                    key = max(key, kc);
                 }
             }
         }
-        if (!qsnap) {
-            qbest = best;
-            qdist = bdist;
+        if (!qsnap) qkey = key;
+        if (active) {
+            // key -> record: len << 16 | dist - 1, dist = 65535 - low half
+            const uint32_t rf = (key >> 16) ? ((key & 0xffff0000u) | (0xfffeu - (key & 0xffffu))) : 0u;
+            const uint32_t rq = (qkey >> 16) ? ((qkey & 0xffff0000u) | (0xfffeu - (qkey & 0xffffu))) : 0u;
+            rec2[(prm.dbg & 1) ? (i & 1023u) : p] = make_uint2(rf, rq);
         }
-        if (active)
-            rec2[p] = make_uint2(best ? ((best << 16) | (bdist - 1)) : 0u, qbest ? ((qbest << 16) | (qdist - 1)) : 0u);
     }
     fl_prof_mark(11);
 }
