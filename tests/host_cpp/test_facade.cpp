@@ -1,0 +1,71 @@
+// "flate public interface" (flate.zig:356-481) through the C++ façade.  Needs a GPU to run.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../flate_amd/host/flate.hpp"
+
+using namespace flate_hip;
+
+#define CHECK(c)                                                         \
+    do {                                                                 \
+        if (!(c)) {                                                      \
+            fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            exit(1);                                                     \
+        }                                                                \
+    } while (0)
+
+template <class F>
+static std::vector<uint8_t> run(F f, const std::vector<uint8_t>& in) {
+    BufferReader r(in.data(), in.size());
+    VectorWriter w;
+    f(r, w);
+    return w.data;
+}
+
+int main() {
+    const std::vector<uint8_t> plain = {'H', 'e', 'l', 'l', 'o', ' ', 'w', 'o', 'r', 'l', 'd', 0x0a};
+    std::vector<uint8_t> block = {0x01, 0x0c, 0x00, 0xf3, 0xff};
+    block.insert(block.end(), plain.begin(), plain.end());
+    std::vector<uint8_t> gz = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0x03};
+    gz.insert(gz.end(), block.begin(), block.end());
+    for (uint8_t b : {0xd5, 0xe0, 0x39, 0xb7, 0x0c, 0x00, 0x00, 0x00}) gz.push_back(b);
+    std::vector<uint8_t> zl = {0x78, 0x9c};
+    zl.insert(zl.end(), block.begin(), block.end());
+    for (uint8_t b : {0x1c, 0xf2, 0x04, 0x47}) zl.push_back(b);
+
+    CHECK(run([](auto& r, auto& w) { gzip::decompress(r, w); }, gz) == plain);
+    CHECK(run([](auto& r, auto& w) { zlib::decompress(r, w); }, zl) == plain);
+    CHECK(run([](auto& r, auto& w) { flate::decompress(r, w); }, block) == plain);
+    CHECK(run([](auto& r, auto& w) { gzip::store::compress(r, w); }, plain) == gz);
+    CHECK(run([](auto& r, auto& w) { zlib::store::compress(r, w); }, plain) == zl);
+    CHECK(run([](auto& r, auto& w) { flate::store::compress(r, w); }, plain) == block);
+    // compress / decompress, compressor / decompressor, huffman (flate.zig:399-447)
+    auto c1 = run([](auto& r, auto& w) { gzip::compress(r, w, gzip::Options{}); }, plain);
+    CHECK(run([](auto& r, auto& w) { gzip::decompress(r, w); }, c1) == plain);
+    VectorWriter cw;
+    auto cmp = zlib::compressor(cw, zlib::Options{Level::best});
+    cmp.write(plain.data(), 5);
+    cmp.write(plain.data() + 5, plain.size() - 5);
+    cmp.finish();
+    BufferReader rr(cw.data.data(), cw.data.size());
+    auto dcp = zlib::decompressor(rr);
+    uint8_t buf[64];
+    CHECK(dcp.read(buf, sizeof buf) == plain.size() && memcmp(buf, plain.data(), plain.size()) == 0);
+    auto h1 = run([](auto& r, auto& w) { flate::huffman::compress(r, w); }, plain);
+    CHECK(run([](auto& r, auto& w) { flate::decompress(r, w); }, h1) == plain);
+    // error names (flate.zig:267-295)
+    try {
+        run([](auto& r, auto& w) { zlib::decompress(r, w); }, std::vector<uint8_t>{0x79, 0x94});
+        CHECK(false);
+    } catch (const Error& e) {
+        CHECK(std::string(e.what()) == "BadZlibHeader");
+    }
+    try {
+        run([](auto& r, auto& w) { flate::compress(r, w); }, std::vector<uint8_t>(70000, 'a'));
+        CHECK(false);
+    } catch (const Error& e) {
+        CHECK(e.status == FLATE_HIP_ST_CHUNK_TOO_LARGE);
+    }
+    printf("facade ok\n");
+    return 0;
+}
