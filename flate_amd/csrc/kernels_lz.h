@@ -427,6 +427,11 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
         const uint32_t cp = 0xffffu - p;  // key low half = 65535 - (p - q) = q + cp
         uint32_t key = 0, qkey = 0;
+        // A candidate can beat the lane's best only if its first best+1 bytes agree with p's.
+        // The first four are compared through `bad`; `mk` selects the bytes of the second
+        // prefix word that must agree as well (0 while there is no match yet, all ones once
+        // the best is >= 7: then the whole word must agree and the window decides).
+        uint32_t mk = 0;
         uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
         bool qsnap = false;
         // positions of the tile entries, fetched one tile ahead: slots lane and lane + 64 (< FL_TILE)
@@ -475,38 +480,37 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     const uint32_t q = tsp[3 - u];
                     const uint2 w = twp[3 - u];
                     const uint32_t x = w.y ^ p1;
-                    // common prefix from the two prefix words: 4..7, or 8 when they agree
-                    // (v_ffbl_b32 of 0 is ~0), capped at maxlen
-                    uint32_t tz;
-                    asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(x));
-                    const uint32_t l = min(min(4u + (tz >> 3), 8u), maxlen);
                     // bad != 0: first four bytes differ (a colliding 4-gram or another bucket),
                     // or the candidate is below the lane's lower bound
                     const uint32_t bad = (w.x ^ p0) | ((q - lov) >> 31);
-                    uint32_t kc = bad ? 0u : ((l << 16) | (q + cp));
-                    if ((bad | x) == 0) {
-                        // all 8 prefix bytes agree: a longer match needs the window
-                        const uint32_t best = key >> 16;
-                        if (maxlen > max(best, 8u)) {
+                    if (((x & mk) | bad) == 0) {
+                        // this candidate is longer than the best so far (deflate.zig:254), unless the
+                        // window says otherwise beyond the 8 prefix bytes
+                        uint32_t tz;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(x));  // ~0 for x == 0
+                        uint32_t le = min(min(4u + (tz >> 3), 8u), maxlen);
+                        bool take = true;
+                        if (x == 0 && maxlen > 8) {
+                            const uint32_t best = key >> 16;
                             // SlidingWindow.zig:91-98: a candidate that does not extend the best
                             // match is dropped on one compare
-                            bool cand = true;
-                            if (best >= 8) cand = fl_lds_load4(win32, q + best - 3) == pb;
-                            kc = 0;
-                            if (cand) {
-                                const uint32_t le = fl_extend_match(win32, p, q, maxlen);
-                                kc = (le << 16) | (q + cp);
-                                if (kc > key) {  // deflate.zig:254-261
-                                    pb = fl_lds_load4(win32, p + le - 3);
-                                    if (le >= nice) {  // deflate.zig:256-258: stop looking
-                                        n = 0;
-                                        lov = 0x7fffffffu;
-                                    }
-                                }
+                            if (best >= 8) take = fl_lds_load4(win32, q + best - 3) == pb;
+                            if (take) le = fl_extend_match(win32, p, q, maxlen);
+                        }
+                        const uint32_t kc = (le << 16) | (q + cp);
+                        if (take && kc > key) {  // deflate.zig:254-261
+                            key = kc;
+                            if (le >= maxlen || le >= nice) {  // nothing longer possible / deflate.zig:256-258
+                                n = 0;
+                                lov = 0x7fffffffu;
+                            } else if (le >= 7) {
+                                mk = ~0u;
+                                if (le >= 8) pb = fl_lds_load4(win32, p + le - 3);
+                            } else {
+                                mk = (1u << (8 * (le - 3))) - 1u;
                             }
                         }
                     }
-                    key = max(key, kc);
                 }
             }
         }
