@@ -361,12 +361,22 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         __syncthreads();
         uint32_t carry = 0;
         for (uint32_t w = 0; w < wave; w++) carry = max(carry, wlast[w]);
+        uint32_t spn[4];
+        uint32_t hlast = 0xfffffffeu;  // hash of the entry just before the current round
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = slice0 + u * 64 + lane;
+            spn[u] = i < M ? Sc[i] : 0;
+        }
+        if (slice0 > 0 && slice0 <= M) hlast = fl_hash_le(fl_lds_load4(win32, Sc[slice0 - 1]));
         for (uint32_t r = 0; r < 64; r += 4) {
             uint32_t sp[4];
 #pragma unroll
+            for (int u = 0; u < 4; u++) sp[u] = spn[u];
+#pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t i = slice0 + (r + u) * 64 + lane;
-                sp[u] = i < M ? Sc[i] : 0;
+                const uint32_t i = slice0 + (r + 4 + u) * 64 + lane;
+                spn[u] = (r + 4 < 64 && i < M) ? Sc[i] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -374,7 +384,8 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 const bool valid = i < M;
                 const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, sp[u])) : 0xffffffffu;
                 uint32_t hp = __shfl_up(h, 1, 64);
-                if (lane == 0) hp = (i > 0 && valid) ? fl_hash_le(fl_lds_load4(win32, Sc[i - 1])) : 0xfffffffeu;
+                if (lane == 0) hp = hlast;
+                hlast = __shfl(h, 63, 64);
                 uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {  // inclusive prefix max across lanes
@@ -399,13 +410,16 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     uint2* tw = tW[wave];
 
     // software pipeline: the next batch's own entry is fetched while this one is searched
-    uint32_t nx_p = 0, nx_nq = 0xffff0000u;
+    uint32_t nx_p = 0, nx_nq = 0xffff0000u, nx_tq0 = 0, nx_tq1 = 0;
     {
         const uint32_t i = (wave << 6) + lane;
         if (wave < nbatch && i < M) {
             nx_p = Sc[i];
             nx_nq = NQc[i];
         }
+        const int32_t ia = (int32_t)(wave << 6) - FL_KB + (int32_t)lane, ib = ia + 64;
+        nx_tq0 = (wave < nbatch && ia >= 0 && ia < (int32_t)M) ? Sc[ia] : 0;
+        nx_tq1 = (wave < nbatch && lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
     }
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
@@ -416,11 +430,17 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
         uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
         if (n == 0) lov = 0x7fffffffu;
+        // positions of the first tile's entries (slots lane and lane + 64 < FL_TILE), fetched a batch ahead
+        uint32_t tq0 = nx_tq0, tq1 = nx_tq1;
         {
-            const uint32_t in_ = ((batch + FL_MATCH_WAVES) << 6) + lane;
-            const bool okn = batch + FL_MATCH_WAVES < nbatch && in_ < M;
+            const uint32_t bn = batch + FL_MATCH_WAVES;
+            const uint32_t in_ = (bn << 6) + lane;
+            const bool okn = bn < nbatch && in_ < M;
             nx_p = okn ? Sc[in_] : 0;
             nx_nq = okn ? NQc[in_] : 0xffff0000u;
+            const int32_t ia = (int32_t)(bn << 6) - FL_KB + (int32_t)lane, ib = ia + 64;
+            nx_tq0 = (bn < nbatch && ia >= 0 && ia < (int32_t)M) ? Sc[ia] : 0;
+            nx_tq1 = (bn < nbatch && lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
         }
         uint32_t p0, p1;
         fl_lds_load8(win32, p, p0, p1);
@@ -432,15 +452,41 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         // prefix word that must agree as well (0 while there is no match yet, all ones once
         // the best is >= 7: then the whole word must agree and the window decides).
         uint32_t mk = 0;
-        uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 8)
+        uint32_t pb = 0;     // window bytes p+best-3 .. p+best (valid when best >= 8)
+        uint32_t dmask = 0;  // candidates of the current tile whose 8 prefix bytes all agree
         bool qsnap = false;
-        // positions of the tile entries, fetched one tile ahead: slots lane and lane + 64 (< FL_TILE)
-        uint32_t tq0, tq1;
-        {
-            const int32_t ia = (int32_t)i0 - FL_KB + (int32_t)lane, ib = ia + 64;
-            tq0 = (ia >= 0 && ia < (int32_t)M) ? Sc[ia] : 0;
-            tq1 = (lane < FL_TILE - 64 && ib >= 0 && ib < (int32_t)M) ? Sc[ib] : 0;
-        }
+        // Window work is deferred to the end of the tile: there every lane with such a candidate
+        // extends one per step, instead of the whole wave stalling whenever a single lane has
+        // one.  The key is a max, so the order of evaluation inside a tile does not matter,
+        // except for `nice` (deflate.zig:256-258), which only cuts off candidates after it.
+        auto flush_deep = [&]() {
+            while (__any(dmask != 0)) {
+                if (dmask) {
+                    const uint32_t kk = (uint32_t)__builtin_ctz(dmask) + 1;  // nearest first
+                    dmask &= dmask - 1;
+                    const uint32_t q = ts[FL_KB + lane - kk];
+                    const uint32_t best = key >> 16;
+                    // SlidingWindow.zig:91-98: a candidate that does not extend the best match is
+                    // dropped on one compare
+                    bool take = maxlen > best;
+                    if (take && best >= 8) take = fl_lds_load4(win32, q + best - 3) == pb;
+                    if (take) {
+                        const uint32_t le = fl_extend_match(win32, p, q, maxlen);
+                        const uint32_t kc = (le << 16) | (q + cp);
+                        if (kc > key) {  // deflate.zig:254-261
+                            key = kc;
+                            mk = ~0u;
+                            pb = fl_lds_load4(win32, p + le - 3);
+                            if (le >= maxlen || le >= nice) {  // nothing longer possible / stop looking
+                                n = 0;
+                                lov = 0x7fffffffu;
+                                dmask = 0;
+                            }
+                        }
+                    }
+                }
+            }
+        };
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64) with their first 8 bytes
@@ -469,6 +515,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 // the chain >> 2 budget (deflate.zig:241-245) ends after candidate `quarter`
                 // (a multiple of 4 at every level, deflate.zig:44-49)
                 if (kb + kk0 - 1 == quarter) {
+                    flush_deep();
                     qkey = key;
                     qsnap = true;
                 }
@@ -484,35 +531,27 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     // or the candidate is below the lane's lower bound
                     const uint32_t bad = (w.x ^ p0) | ((q - lov) >> 31);
                     if (((x & mk) | bad) == 0) {
-                        // this candidate is longer than the best so far (deflate.zig:254), unless the
-                        // window says otherwise beyond the 8 prefix bytes
+                        // longer than the best so far (deflate.zig:254) as far as the 8 prefix bytes tell
                         uint32_t tz;
                         asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(x));  // ~0 for x == 0
-                        uint32_t le = min(min(4u + (tz >> 3), 8u), maxlen);
-                        bool take = true;
-                        if (x == 0 && maxlen > 8) {
-                            const uint32_t best = key >> 16;
-                            // SlidingWindow.zig:91-98: a candidate that does not extend the best
-                            // match is dropped on one compare
-                            if (best >= 8) take = fl_lds_load4(win32, q + best - 3) == pb;
-                            if (take) le = fl_extend_match(win32, p, q, maxlen);
-                        }
+                        const uint32_t le = min(min(4u + (tz >> 3), 8u), maxlen);
                         const uint32_t kc = (le << 16) | (q + cp);
-                        if (take && kc > key) {  // deflate.zig:254-261
+                        if (kc > key) {
                             key = kc;
-                            if (le >= maxlen || le >= nice) {  // nothing longer possible / deflate.zig:256-258
+                            if (le >= 8) pb = fl_lds_load4(win32, p + le - 3);
+                            if (le >= maxlen) {  // nothing longer possible (le <= 8 < nice here)
                                 n = 0;
                                 lov = 0x7fffffffu;
-                            } else if (le >= 7) {
-                                mk = ~0u;
-                                if (le >= 8) pb = fl_lds_load4(win32, p + le - 3);
-                            } else {
-                                mk = (1u << (8 * (le - 3))) - 1u;
+                                dmask = 0;
                             }
+                            mk = le >= 7 ? ~0u : ((1u << (8 * (le - 3))) - 1u);
                         }
+                        // all 8 prefix bytes agree and the match may go on: the window decides, later
+                        if (x == 0 && maxlen > 8) dmask |= 1u << (kk0 + u - 1);
                     }
                 }
             }
+            flush_deep();
         }
         if (!qsnap) qkey = key;
         if (active) {
