@@ -448,7 +448,8 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             if (mode == 0)
                 hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, nb, dpl);
             else
-                hipLaunchKernelGGL(k_plan, dim3(nb), dim3(64), 0, st, dch, dbc, prm, (const uint32_t*)dhist, dpl);
+                hipLaunchKernelGGL(k_plan, dim3((nb + FL_PLAN_WAVES - 1) / FL_PLAN_WAVES), dim3(64 * FL_PLAN_WAVES), 0, st,
+                                   dch, dbc, prm, (const uint32_t*)dhist, dpl);
         }
         {
             ProfScope ps(h, K_OFFSETS);

@@ -134,15 +134,26 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
 }
 
 // ------------------------------------------------------------------ planning
-// One wave per block; lane 0 runs the serial planner (flate_common.h) with its
+// One wave per block, four blocks per workgroup (more resident waves per CU than one-wave
+// workgroups get); lane 0 of each wave runs the serial planner (flate_common.h) with its
 // scratch in LDS.  mode 1: huffmanBlock; mode >= 4: BlockWriter.write.
-__global__ __launch_bounds__(64) void k_plan(const fl_chunk* __restrict__ chunks,
-                                             const uint32_t* __restrict__ blk_chunk, fl_params prm,
-                                             const uint32_t* __restrict__ hist, fl_block_plan* __restrict__ plans) {
-    __shared__ fl_plan_ws ws;
-    const uint32_t b = blockIdx.x;
+#define FL_PLAN_WAVES 4
+__global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __restrict__ chunks,
+                                                             const uint32_t* __restrict__ blk_chunk, fl_params prm,
+                                                             const uint32_t* __restrict__ hist,
+                                                             fl_block_plan* __restrict__ plans) {
+    __shared__ fl_plan_ws wss[FL_PLAN_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t b = blockIdx.x * FL_PLAN_WAVES + wave;
+    if (b >= prm.n_blocks) return;
+    if (prm.mode >= 4) {
+        // two plan slots per chunk and the second one is rarely used: visit all first slots
+        // before the second ones, so that resident waves are waves with work
+        const uint32_t half = prm.n_blocks >> 1;
+        b = b < half ? 2 * b : 2 * (b - half) + 1;
+    }
+    fl_plan_ws& ws = wss[wave];
     const fl_chunk ck = chunks[blk_chunk[b]];
-    const uint32_t lane = threadIdx.x;
     fl_block_plan* plan = &plans[b];
     if (ck.skip) {
         if (lane == 0) plan->valid = 0;
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(64) void k_plan(const fl_chunk* __restrict__ chunks
             fl_plan_huffman_block(&ws, plan, len, j + 1 == ck.n_blocks);
         }
     } else {
-        // token block: metadata (valid, tok_*, in_*, final_block) was written by the parse kernel
+        // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel
         if (!plan->valid) return;
         for (uint32_t i = lane; i < FL_NUM_LIT; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         if (lane < FL_NUM_DIST) ws.dist_freq[lane] = (uint16_t)hist[(uint64_t)b * 320 + 286 + lane];
