@@ -19,10 +19,25 @@ struct fl_hdec {
     uint16_t symbol[288];
 };
 
+// LDS pointers are typed with their address space: with generic pointers the decoder's table
+// and ring accesses became FLAT instructions (PMC: 323 k FLAT vs 30 k LDS per wave), i.e. LDS
+// traffic through the vector-memory pipe.
+#define FL_LDS __attribute__((address_space(3)))
+
+#define FL_INF_LIT_BITS 10
+#define FL_INF_DST_BITS 9
+#define FL_INF_RING 2048u                       // recent output kept in LDS (power of two)
+#define FL_INF_NEAR (FL_INF_RING - 258u - 2u)   // matches up to this distance are served from it
+#define FL_INF_FENCE 512u                       // output bytes between two "stores are visible" fences
+
 struct fl_inflate_ws {
     fl_hdec lit, dst, cl;
+    uint16_t lit_lut[1u << FL_INF_LIT_BITS];  // symbol | code_bits << 9, 0 = not in the table
+    uint16_t dst_lut[1u << FL_INF_DST_BITS];
     uint8_t lens[320];
     uint8_t cl_lens[20];
+    uint16_t offs[18];
+    uint8_t ring[FL_INF_RING];
 };
 
 struct fl_bitr {
@@ -34,12 +49,21 @@ struct fl_bitr {
     uint32_t have;
 };
 
+// Keep at least 33 valid bits in the buffer (the most one decode step consumes between two
+// refills, bit_reader.zig:46-68 fills for 5 + 15 + 13).  (pos + have) is always a byte boundary.
 __device__ __forceinline__ void fl_br_refill(fl_bitr& r) {
-    while (r.have <= 56) {
+    if (r.have <= 32) {
         const uint64_t byte = (r.pos + r.have) >> 3;
-        const uint64_t v = byte < r.nbytes ? r.data[byte] : 0;
-        r.buf |= v << r.have;
-        r.have += 8;
+        uint32_t w;
+        if (byte + 8 <= r.nbytes) {
+            w = fl_load_u32_unaligned(r.data + byte);
+        } else {  // near the end: byte by byte, zero beyond the stream
+            w = 0;
+            for (uint32_t k = 0; k < 4; k++)
+                if (byte + k < r.nbytes) w |= (uint32_t)r.data[byte + k] << (8 * k);
+        }
+        r.buf |= (uint64_t)w << r.have;
+        r.have += 32;
     }
 }
 // bit_reader.zig:46-68: fill() fails only when no bit at all is left
@@ -76,8 +100,8 @@ __device__ __forceinline__ void fl_br_align(fl_bitr& r) {  // bit_reader.zig:189
 
 // huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order).  Runs on all
 // lanes redundantly except the LDS writes (lane 0).
-__device__ int fl_hdec_generate(fl_hdec* d, const uint8_t* lens, int n, int alphabet, int max_code_bits,
-                                uint32_t lane) {
+__device__ __forceinline__ int fl_hdec_generate(FL_LDS fl_hdec* d, const FL_LDS uint8_t* lens, FL_LDS uint16_t* offs,
+                                                int n, int alphabet, int max_code_bits, uint32_t lane) {
     if (alphabet == 286 && lens[256] == 0) return 10;  // MissingEndOfBlockCode
     uint32_t cnt[16];
 #pragma unroll
@@ -108,7 +132,6 @@ __device__ int fl_hdec_generate(fl_hdec* d, const uint8_t* lens, int n, int alph
     }
     fl_wave_lds_sync();
     if (lane == 0) {
-        uint16_t offs[17];
         offs[1] = 0;
         d->count[0] = 0;
         for (int len = 1; len < 16; len++) {
@@ -128,7 +151,7 @@ __device__ int fl_hdec_generate(fl_hdec* d, const uint8_t* lens, int n, int alph
 
 // huffman_decoder.zig:156-175: the symbol whose code is a prefix of `peek`
 // (stream bit order), or InvalidCode.
-__device__ __forceinline__ int fl_hdec_find(const fl_hdec* d, uint32_t peek, int max_code_bits, uint32_t& sym,
+__device__ __forceinline__ int fl_hdec_find(const FL_LDS fl_hdec* d, uint32_t peek, int max_code_bits, uint32_t& sym,
                                             uint32_t& code_bits) {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= max_code_bits; len++) {
@@ -148,24 +171,83 @@ __device__ __forceinline__ int fl_hdec_find(const fl_hdec* d, uint32_t peek, int
     return 7;  // InvalidCode
 }
 
+// Fill a 2^bits-entry table: entry[i] = the symbol whose code is a prefix of i (stream bit
+// order) when that code has at most `bits` bits, else 0.  Every lane decodes its share of the
+// indices with the same walk as fl_hdec_find, so table and walk cannot disagree.
+__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS fl_hdec* d, FL_LDS uint16_t* lut, int bits,
+                                                  uint32_t lane) {
+    for (uint32_t i = lane; i < (1u << bits); i += 64) {
+        uint32_t sym, cb;
+        uint16_t e = 0;
+        if (fl_hdec_find(d, i, bits, sym, cb) == 0) e = (uint16_t)(sym | (cb << 9));
+        lut[i] = e;
+    }
+    fl_wave_lds_sync();
+}
+
 __device__ __forceinline__ uint32_t fl_rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
 
 struct fl_inf_out {
     uint8_t* out;
+    FL_LDS uint8_t* ring;  // LDS copy of the last FL_INF_RING output bytes
     uint64_t cap;
     uint64_t wp;
+    uint64_t fenced;  // every output byte below this offset is visible to this wave's loads
 };
 
-// CircularBuffer.zig:44-75, spread over the wave
+// Called when wp has moved: once per FL_INF_FENCE bytes wait for the outstanding stores, so that
+// far matches may read the output buffer without waiting.
+__device__ __forceinline__ void fl_inf_advance(fl_inf_out& o) {
+    if (o.wp - o.fenced >= 2 * FL_INF_FENCE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        o.fenced = o.wp;
+    }
+}
+
+// CircularBuffer.zig:44-75, spread over the wave.  Near matches copy out of the LDS ring; far
+// ones read the output buffer, whose bytes that far back are already fenced.
 __device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint32_t distance, uint32_t lane) {
     if (o.wp < distance || length < 3 || length > 258 || distance < 1 || distance > 32768) return 11;
     if (o.wp + length > o.cap) return 100;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // earlier stores of this wave are visible
-    const uint8_t* from = o.out + o.wp - distance;
+    const uint32_t wp = (uint32_t)o.wp;
     uint8_t* to = o.out + o.wp;
-    for (uint32_t i = lane; i < length; i += 64) to[i] = from[distance >= length ? i : (i % distance)];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const bool near_ = distance <= FL_INF_NEAR;
+    if (!near_ && o.wp - distance + length > o.fenced) {  // the source is younger than the last fence
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        o.fenced = o.wp;
+    }
+    const uint8_t* from = o.out + o.wp - distance;  // far matches: distance > length, no overlap
+    for (uint32_t i0 = 0; i0 < length; i0 += 64) {  // one trip for lengths up to 64
+        const uint32_t i = i0 + lane;
+        uint32_t byte = 0;
+        if (i < length) {
+            if (near_) {
+                // the source bytes repeat with period `distance` when the match overlaps itself
+                const uint32_t si = distance >= length ? i : (i % distance);
+                byte = o.ring[(wp - distance + si) & (FL_INF_RING - 1)];
+            } else {
+                byte = from[i];
+            }
+        }
+        fl_lds_order();
+        if (i < length) {
+            to[i] = (uint8_t)byte;
+            o.ring[(wp + i) & (FL_INF_RING - 1)] = (uint8_t)byte;
+        }
+        fl_lds_order();
+    }
     o.wp += length;
+    fl_inf_advance(o);
+    return 0;
+}
+__device__ __forceinline__ int fl_inf_literal(fl_inf_out& o, uint32_t byte, uint32_t lane) {
+    if (o.wp >= o.cap) return 100;
+    if (lane == 0) {
+        o.out[o.wp] = (uint8_t)byte;
+        o.ring[(uint32_t)o.wp & (FL_INF_RING - 1)] = (uint8_t)byte;
+    }
+    o.wp++;
+    fl_inf_advance(o);
     return 0;
 }
 
@@ -198,7 +280,7 @@ __device__ __forceinline__ int fl_inf_distance(fl_bitr& r, uint32_t code, uint32
 }
 
 // inflate.zig:89-102
-__device__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
+__device__ __forceinline__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
     fl_br_align(r);
     uint32_t len, nlen;
     FL_TRY(fl_br_read(r, 16, len));
@@ -208,7 +290,18 @@ __device__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
     if (o.wp + len > o.cap) return 100;
     const uint8_t* s = r.data + (r.pos >> 3);
     for (uint32_t i = lane; i < len; i += 64) o.out[o.wp + i] = s[i];
+    // the ring mirrors the last bytes of the output
+    {
+        const uint32_t tail = len < FL_INF_RING ? len : FL_INF_RING;
+        fl_lds_order();
+        for (uint32_t i = lane; i < tail; i += 64) {
+            const uint64_t off = o.wp + len - tail + i;
+            o.ring[(uint32_t)off & (FL_INF_RING - 1)] = s[len - tail + i];
+        }
+        fl_lds_order();
+    }
     o.wp += len;
+    fl_inf_advance(o);
     r.pos += (uint64_t)len * 8;
     r.buf = 0;
     r.have = 0;
@@ -216,7 +309,7 @@ __device__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
 }
 
 // bit_reader.zig:205-217 + inflate.zig:104-121
-__device__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
+__device__ __forceinline__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
     for (;;) {
         FL_TRY(fl_br_fill(r, 9));
         const uint32_t code7 = fl_rev_bits(fl_br_peek(r, 7), 7);
@@ -238,9 +331,7 @@ __device__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
             code = ((code7 - 0x64) << 2) + e + 144;
         }
         if (code <= 255) {
-            if (o.wp >= o.cap) return 100;
-            if (lane == 0) o.out[o.wp] = (uint8_t)code;
-            o.wp++;
+            FL_TRY(fl_inf_literal(o, code, lane));
         } else if (code == 256) {
             return 0;
         } else if (code <= 285) {
@@ -258,10 +349,10 @@ __device__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t lane) {
 }
 
 // inflate.zig:188-216 + the read loops of :161-180
-__device__ int fl_inf_read_lens(fl_bitr& r, fl_inflate_ws* ws, uint32_t base, uint32_t lens_len, uint32_t want,
+__device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws* ws, uint32_t base, uint32_t lens_len, uint32_t want,
                                 uint32_t boundary, bool& crossed, uint32_t lane) {
     uint32_t pos = 0;
-    uint8_t* lens = ws->lens + base;
+    FL_LDS uint8_t* lens = ws->lens + base;
     while (pos < want) {
         FL_TRY(fl_br_fill(r, 7));
         uint32_t sym, cb;
@@ -297,7 +388,7 @@ __device__ int fl_inf_read_lens(fl_bitr& r, fl_inflate_ws* ws, uint32_t base, ui
 }
 
 // inflate.zig:144-184.  flags bit0: reference-strict Q6 (two separate length lists).
-__device__ int fl_inf_dynamic_header(fl_bitr& r, fl_inflate_ws* ws, int flags, uint32_t lane) {
+__device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_inflate_ws* ws, int flags, uint32_t lane) {
     uint32_t v;
     FL_TRY(fl_br_read(r, 5, v));
     const uint32_t hlit = v + 257;
@@ -315,7 +406,7 @@ __device__ int fl_inf_dynamic_header(fl_bitr& r, fl_inflate_ws* ws, int flags, u
         if (lane == 0) ws->cl_lens[fl_codegen_order(i)] = (uint8_t)v;
     }
     fl_wave_lds_sync();
-    FL_TRY(fl_hdec_generate(&ws->cl, ws->cl_lens, 19, 19, 7, lane));
+    FL_TRY(fl_hdec_generate(&ws->cl, ws->cl_lens, ws->offs, 19, 19, 7, lane));
     bool crossed = false;
     int rc;
     if (flags & 1) {
@@ -323,8 +414,10 @@ __device__ int fl_inf_dynamic_header(fl_bitr& r, fl_inflate_ws* ws, int flags, u
         FL_TRY(fl_inf_read_lens(r, ws, 0, 286, hlit, 0, crossed, lane));
         FL_TRY(fl_inf_read_lens(r, ws, 288, 30, hdist, 0, crossed, lane));
         fl_wave_lds_sync();
-        FL_TRY(fl_hdec_generate(&ws->lit, ws->lens, 286, 286, 15, lane));
-        FL_TRY(fl_hdec_generate(&ws->dst, ws->lens + 288, 30, 30, 15, lane));
+        FL_TRY(fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane));
+        FL_TRY(fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane));
+        fl_hdec_build_lut(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
+        fl_hdec_build_lut(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
         return 0;
     }
     rc = fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane);
@@ -338,31 +431,53 @@ __device__ int fl_inf_dynamic_header(fl_bitr& r, fl_inflate_ws* ws, int flags, u
     fl_wave_lds_sync();
     if (lane < 30) ws->lens[288 + lane] = dl;
     fl_wave_lds_sync();
-    rc = fl_hdec_generate(&ws->lit, ws->lens, 286, 286, 15, lane);
+    rc = fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane);
     if (rc) return crossed ? 14 : rc;
-    rc = fl_hdec_generate(&ws->dst, ws->lens + 288, 30, 30, 15, lane);
+    rc = fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane);
     if (rc) return crossed ? 14 : rc;
+    fl_hdec_build_lut(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
+    fl_hdec_build_lut(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
     return 0;
 }
 
-// inflate.zig:220-249
-__device__ int fl_inf_dynamic(fl_bitr& r, fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+// inflate.zig:220-249.  Codes of up to 10 / 9 bits come out of the LDS tables built after the
+// block header; longer ones (and invalid ones) take the canonical walk, which also keeps the
+// reference's order of errors: a miss in the table of the decoder is InvalidCode before the
+// bits are consumed (huffman_decoder.zig:156-175), running out of input is EndOfStream at the
+// shift (bit_reader.zig:159-163).
+__device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
     for (;;) {
         FL_TRY(fl_br_fill(r, 15));
         uint32_t sym, cb;
-        FL_TRY(fl_hdec_find(&ws->lit, fl_br_peek(r, 15), 15, sym, cb));
+        {
+            const uint32_t pk = fl_br_peek(r, 15);
+            const uint32_t e = ws->lit_lut[pk & ((1u << FL_INF_LIT_BITS) - 1)];
+            if (e) {
+                sym = e & 0x1ff;
+                cb = e >> 9;
+            } else {
+                FL_TRY(fl_hdec_find(&ws->lit, pk, 15, sym, cb));
+            }
+        }
         FL_TRY(fl_br_shift(r, cb));
         if (sym < 256) {
-            if (o.wp >= o.cap) return 100;
-            if (lane == 0) o.out[o.wp] = (uint8_t)sym;
-            o.wp++;
+            FL_TRY(fl_inf_literal(o, sym, lane));
         } else if (sym == 256) {
             return 0;
         } else {
             FL_TRY(fl_br_fill(r, 5 + 15 + 13));
             uint32_t length, distance, dsym;
             FL_TRY(fl_inf_length(r, sym - 257, length));
-            FL_TRY(fl_hdec_find(&ws->dst, fl_br_peek(r, 15), 15, dsym, cb));
+            {
+                const uint32_t pk = fl_br_peek(r, 15);
+                const uint32_t e = ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)];
+                if (e) {
+                    dsym = e & 0x1ff;
+                    cb = e >> 9;
+                } else {
+                    FL_TRY(fl_hdec_find(&ws->dst, pk, 15, dsym, cb));
+                }
+            }
             FL_TRY(fl_br_shift(r, cb));
             FL_TRY(fl_inf_distance(r, dsym, distance));
             FL_TRY(fl_inf_match(o, length, distance, lane));
@@ -371,7 +486,7 @@ __device__ int fl_inf_dynamic(fl_bitr& r, fl_inflate_ws* ws, fl_inf_out& o, uint
 }
 
 // container.zig:119-152
-__device__ int fl_inf_header(fl_bitr& r, int container) {
+__device__ __forceinline__ int fl_inf_header(fl_bitr& r, int container) {
     uint32_t v;
     if (container == 1) {
         uint32_t m1, m2, method, flags;
@@ -411,8 +526,8 @@ __device__ int fl_inf_header(fl_bitr& r, int container) {
 }
 
 // CRC-32 of out[0..n) by the whole wave (container.zig:170, inflate.zig:330)
-__device__ uint32_t fl_wave_crc32(const uint8_t* p, uint64_t n, const fl_crc_consts& cc, uint32_t* tab /*256*/,
-                                  uint32_t lane) {
+__device__ __forceinline__ uint32_t fl_wave_crc32(const uint8_t* p, uint64_t n, const fl_crc_consts& cc,
+                                                  FL_LDS uint32_t* tab /*256*/, uint32_t lane) {
     for (uint32_t t = lane; t < 256; t += 64) {
         uint32_t c = t;
         for (int k = 0; k < 8; k++) c = (c & 1) ? (FL_CRC_POLY ^ (c >> 1)) : (c >> 1);
@@ -428,7 +543,7 @@ __device__ uint32_t fl_wave_crc32(const uint8_t* p, uint64_t n, const fl_crc_con
     return fl_wave_xor(c);
 }
 // Adler-32 of out[0..n) by the whole wave
-__device__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n, uint32_t lane) {
+__device__ __forceinline__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n, uint32_t lane) {
     const uint64_t per = (n + 63) / 64;
     const uint64_t lo = min(n, lane * per), hi = min(n, lo + per);
     uint32_t A = 0, B = 0;  // a = b = 0 start
@@ -456,8 +571,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
                                                 int container, int flags, fl_crc_consts cc,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                 int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
-    __shared__ fl_inflate_ws ws;
-    __shared__ uint32_t crc_tab[256];
+    __shared__ fl_inflate_ws ws_mem;
+    __shared__ uint32_t crc_tab_mem[256];
+    FL_LDS fl_inflate_ws* ws = (FL_LDS fl_inflate_ws*)&ws_mem;
+    FL_LDS uint32_t* crc_tab = (FL_LDS uint32_t*)crc_tab_mem;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t lane = threadIdx.x;
@@ -471,8 +588,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     r.have = 0;
     fl_inf_out o;
     o.out = out + ck.out_off;
+    o.ring = ws->ring;
     o.cap = ck.out_cap;
     o.wp = 0;
+    o.fenced = 0;
 
     int rc = fl_inf_header(r, container);
     while (rc == 0) {  // inflate.zig:251-280
@@ -480,8 +599,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
         if ((rc = fl_br_read(r, 1, bfinal))) break;
         if ((rc = fl_br_read(r, 2, btype))) break;
         if (btype == 2) {
-            if ((rc = fl_inf_dynamic_header(r, &ws, flags, lane))) break;
-            rc = fl_inf_dynamic(r, &ws, o, lane);
+            if ((rc = fl_inf_dynamic_header(r, ws, flags, lane))) break;
+            rc = fl_inf_dynamic(r, ws, o, lane);
         } else if (btype == 0) {
             rc = fl_inf_stored(r, o, lane);
         } else if (btype == 1) {
