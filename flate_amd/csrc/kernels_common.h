@@ -95,10 +95,11 @@ __device__ __forceinline__ void fl_lds_order() {
 }
 
 // little-endian 32-bit load from an arbitrarily aligned global address
+// (the aligned address is derived with pointer arithmetic, not an integer round trip, so the
+// compiler keeps the global address space and emits global_load rather than flat_load)
 __device__ __forceinline__ uint32_t fl_load_u32_unaligned(const uint8_t* p) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t* w = (const uint32_t*)(p - sh);
     const uint32_t lo = w[0];
     if (sh == 0) return lo;
     const uint32_t hi = w[1];

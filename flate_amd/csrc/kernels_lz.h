@@ -86,9 +86,8 @@ __device__ __forceinline__ uint32_t fl_load_u32_clamped(const uint8_t* src, uint
     // least one valid byte: never another chunk's bytes in the key, never memory past the buffer.
     if (p >= N) return 0;
     const uint32_t nb = min(N - p, 4u);
-    const uintptr_t a = (uintptr_t)(src + p);
-    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t sh = (uint32_t)((uintptr_t)(src + p) & 3);
+    const uint32_t* w = (const uint32_t*)(src + p - sh);
     const uint32_t lo = w[0];
     const uint32_t hi = (sh + nb > 4) ? w[1] : 0u;
     uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, sh);
@@ -102,9 +101,9 @@ struct __attribute__((packed, aligned(4))) fl_u32x2 {
 // bytes p..p+3 (p <= N - 4) with a single 8-byte load whenever both dwords are inside the chunk
 __device__ __forceinline__ uint32_t fl_gather_u32(const uint8_t* src, uint32_t p, uint32_t N) {
     if (p + 8 <= N) {
-        const uintptr_t a = (uintptr_t)(src + p);
-        const fl_u32x2 w = *(const fl_u32x2*)(a & ~(uintptr_t)3);
-        return __builtin_amdgcn_alignbyte(w.b, w.a, (uint32_t)(a & 3));
+        const uint32_t sh = (uint32_t)((uintptr_t)(src + p) & 3);
+        const fl_u32x2 w = *(const fl_u32x2*)(src + p - sh);
+        return __builtin_amdgcn_alignbyte(w.b, w.a, sh);
     }
     return fl_load_u32_clamped(src, p, N);
 }
