@@ -602,13 +602,17 @@ __device__ __forceinline__ uint32_t fl_anchor_desc(const uint2* __restrict__ rec
 
 // One workgroup per chunk: which positions are anchors (visited with no pending match)?
 // Output: desc[c][p] for every position and the anchor bit set marks[c][2048].
-__global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const fl_chunk* __restrict__ chunks, fl_params prm,
-                                                                const uint32_t* __restrict__ rec_all,
-                                                                uint32_t* __restrict__ desc_all,
-                                                                uint32_t* __restrict__ marks_all) {
-    __shared__ uint16_t J[65536];
+// The chunk is handled in two halves of 32768 positions so that the pointer table is 64 KiB
+// and two workgroups (32 waves) fit a CU; the only state carried across is the next anchor.
+#define FL_PARSE_HALF 32768u
+__global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_lz_parse(const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                   const uint32_t* __restrict__ rec_all,
+                                                                   uint32_t* __restrict__ desc_all,
+                                                                   uint32_t* __restrict__ marks_all) {
+    __shared__ uint16_t J[FL_PARSE_HALF];
     __shared__ uint32_t marks[2048];
     __shared__ uint16_t entry[256];
+    __shared__ uint32_t next_anchor;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t tid = threadIdx.x;
@@ -618,79 +622,85 @@ __global__ __launch_bounds__(FL_PARSE_THREADS) void k_lz_parse(const fl_chunk* _
     uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* gmarks = marks_all + (uint64_t)c * 2048;
 
-    fl_prof_mark(16);
-    // (a) anchor function for every position, 8 positions per thread per round trip
-    for (uint32_t base = 0; base < N; base += FL_PARSE_THREADS * 8) {
-        uint2 ra[8], rb[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-            ra[u] = p < N ? rec2[p] : make_uint2(0u, 0u);
-            rb[u] = p + 1 < N ? rec2[p + 1] : make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-            if (p < N) {
-                const uint32_t d = fl_anchor_desc(rec2, p, ra[u], rb[u], prm.good, prm.lazy);
-                desc[p] = d;
-                J[p] = (uint16_t)fl_desc_next(d, p);
-            }
-        }
-    }
     for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) marks[i] = 0;
     if (tid < 256) entry[tid] = 0xffff;
-    __syncthreads();
-    fl_prof_mark(17);
-    // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
-    // lies at or beyond the end of p's segment.  Racy reads only ever see a node further along
-    // the same path, so 8 rounds (2^8 = segment length) always suffice.
-    for (int round = 0; round < 8; round++) {
-        for (uint32_t p = tid; p < N; p += FL_PARSE_THREADS) {
-            const uint32_t seg_end = min((p | 255u) + 1u, N);
-            const uint32_t j = J[p];
-            if (j < seg_end) J[p] = J[j];
+    if (tid == 0) next_anchor = 0;
+    fl_prof_mark(16);
+    for (uint32_t h0 = 0; h0 < N; h0 += FL_PARSE_HALF) {
+        const uint32_t h1 = min(h0 + FL_PARSE_HALF, N);
+        // (a) anchor function for every position, 8 positions per thread per round trip
+        for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
+            uint2 ra[8], rb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+                ra[u] = p < h1 ? rec2[p] : make_uint2(0u, 0u);
+                rb[u] = (p < h1 && p + 1 < N) ? rec2[p + 1] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+                if (p < h1) {
+                    const uint32_t d = fl_anchor_desc(rec2, p, ra[u], rb[u], prm.good, prm.lazy);
+                    desc[p] = d;
+                    J[p - h0] = (uint16_t)fl_desc_next(d, p);
+                }
+            }
         }
         __syncthreads();
-    }
-    fl_prof_mark(18);
-    // (c) first anchor of every segment: at most 256 serial steps
-    if (tid == 0) {
-        uint32_t a = 0;
-        while (a < N) {
-            entry[a >> 8] = (uint16_t)a;
-            a = J[a];
+        if (h0 == 0) fl_prof_mark(17);
+        // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
+        // lies at or beyond the end of p's segment.  Racy reads only ever see a node further along
+        // the same path, so 8 rounds (2^8 = segment length) always suffice.
+        for (int round = 0; round < 8; round++) {
+            for (uint32_t p = h0 + tid; p < h1; p += FL_PARSE_THREADS) {
+                const uint32_t seg_end = min((p | 255u) + 1u, N);
+                const uint32_t j = J[p - h0];
+                if (j < seg_end) J[p - h0] = J[j - h0];
+            }
+            __syncthreads();
         }
-    }
-    __syncthreads();
-    fl_prof_mark(19);
-    // (d) restore the one-step pointers
-    for (uint32_t base = 0; base < N; base += FL_PARSE_THREADS * 8) {
-        uint32_t d[8];
+        if (h0 == 0) fl_prof_mark(18);
+        // (c) first anchor of every segment of this half: at most 128 serial steps
+        if (tid == 0) {
+            uint32_t a = next_anchor;
+            while (a < h1) {
+                entry[a >> 8] = (uint16_t)a;
+                a = J[a - h0];
+            }
+            next_anchor = a;
+        }
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(19);
+        // (d) restore the one-step pointers
+        for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
+            uint32_t d[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-            d[u] = p < N ? desc[p] : 0;
-        }
+            for (int u = 0; u < 8; u++) {
+                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+                d[u] = p < h1 ? desc[p] : 0;
+            }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-            if (p < N) J[p] = (uint16_t)fl_desc_next(d[u], p);
+            for (int u = 0; u < 8; u++) {
+                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+                if (p < h1) J[p - h0] = (uint16_t)fl_desc_next(d[u], p);
+            }
         }
-    }
-    __syncthreads();
-    fl_prof_mark(20);
-    // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
-    if (tid < 256) {
-        uint32_t a = entry[tid];
-        const uint32_t end = min((tid + 1) << 8, N);
-        while (a < end) {
-            marks[a >> 5] |= 1u << (a & 31);
-            a = J[a];
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(20);
+        // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
+        if (tid < FL_PARSE_HALF / 256) {
+            const uint32_t seg = (h0 >> 8) + tid;
+            uint32_t a = entry[seg];
+            const uint32_t end = min((seg + 1) << 8, N);
+            while (a < end) {
+                marks[a >> 5] |= 1u << (a & 31);
+                a = J[a - h0];
+            }
         }
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(21);
     }
-    __syncthreads();
-    fl_prof_mark(21);
     for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) gmarks[i] = marks[i];
 }
 
