@@ -40,45 +40,87 @@ struct fl_inflate_ws {
     uint8_t ring[FL_INF_RING];
 };
 
+#define FL_INF_INRING 1024u  // compressed bytes staged in LDS (two 512-byte halves)
+
+// Bit reader (bit_reader.zig:18-219) in position-free form: `left` = bits of the stream not yet
+// consumed.  fill(nice) fails only when no bit at all is left (bit_reader.zig:59-67), shift(n)
+// when n exceeds what is left (:159-163); peeks beyond the end see zero bits.
 struct fl_bitr {
     const uint8_t* data;
-    uint64_t nbytes;
-    uint64_t total_bits;
-    uint64_t pos;   // bits consumed
-    uint64_t buf;   // bits [pos, pos + have), zero beyond the end of the stream
+    FL_LDS uint32_t* inring;  // stream bytes [in_loaded - 1024, in_loaded), index = offset & 1023
+    int64_t left;             // unconsumed bits
+    uint64_t buf;             // the next `have` bits, zero beyond the end of the stream
+    uint32_t nbytes;
+    uint32_t next_byte;  // stream offset of the first byte not yet in `buf`
+    uint32_t in_loaded;  // stream bytes staged in LDS so far (a multiple of 512)
+    uint32_t pf0, pf1;   // this lane's 8 bytes of the next half, already requested from memory
     uint32_t have;
+    uint32_t lane;
 };
 
-// Keep at least 33 valid bits in the buffer (the most one decode step consumes between two
-// refills, bit_reader.zig:46-68 fills for 5 + 15 + 13).  (pos + have) is always a byte boundary.
-__device__ __forceinline__ void fl_br_refill(fl_bitr& r) {
-    if (r.have <= 32) {
-        const uint64_t byte = (r.pos + r.have) >> 3;
-        uint32_t w;
-        if (byte + 8 <= r.nbytes) {
-            w = fl_load_u32_unaligned(r.data + byte);
-        } else {  // near the end: byte by byte, zero beyond the stream
-            w = 0;
-            for (uint32_t k = 0; k < 4; k++)
-                if (byte + k < r.nbytes) w |= (uint32_t)r.data[byte + k] << (8 * k);
+// this lane's 8 bytes at stream offset `off` (zero beyond the stream)
+__device__ __forceinline__ void fl_br_fetch8(const fl_bitr& r, uint32_t off, uint32_t& a, uint32_t& b) {
+    a = 0;
+    b = 0;
+    if ((uint64_t)off + 12 <= r.nbytes) {
+        const uint8_t* p = r.data + off;
+        const uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+        const uint32_t* w = (const uint32_t*)(p - sh);
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        a = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        b = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    } else {
+        for (uint32_t k = 0; k < 4; k++) {
+            if ((uint64_t)off + k < r.nbytes) a |= (uint32_t)r.data[off + k] << (8 * k);
+            if ((uint64_t)off + 4 + k < r.nbytes) b |= (uint32_t)r.data[off + 4 + k] << (8 * k);
         }
-        r.buf |= (uint64_t)w << r.have;
-        r.have += 32;
     }
 }
-// bit_reader.zig:46-68: fill() fails only when no bit at all is left
+// stage the 512-byte half that `pf` holds and request the one after it
+__device__ __forceinline__ void fl_br_commit_half(fl_bitr& r) {
+    const uint32_t slot = ((r.in_loaded & (FL_INF_INRING - 1)) >> 2) + 2 * r.lane;
+    r.inring[slot] = r.pf0;
+    r.inring[slot + 1] = r.pf1;
+    r.in_loaded += 512;
+    fl_br_fetch8(r, r.in_loaded + 8 * r.lane, r.pf0, r.pf1);
+    fl_lds_order();
+}
+// (re)start reading at stream byte `byte` with an empty bit buffer
+__device__ __forceinline__ void fl_br_seek(fl_bitr& r, uint32_t byte) {
+    fl_lds_order();
+    r.buf = 0;
+    r.have = 0;
+    r.next_byte = byte;
+    r.in_loaded = byte & ~511u;
+    fl_br_fetch8(r, r.in_loaded + 8 * r.lane, r.pf0, r.pf1);
+    fl_br_commit_half(r);
+}
+
+// Keep at least 33 valid bits in the buffer (the most one decode step consumes between two
+// refills, bit_reader.zig:46-68 fills for 5 + 15 + 13).  The bytes come from the LDS staging
+// ring; the next half is always already on its way.
+__device__ __forceinline__ void fl_br_refill(fl_bitr& r) {
+    if (r.have <= 32) {
+        if (r.next_byte + 8 > r.in_loaded) fl_br_commit_half(r);
+        const uint32_t i = (r.next_byte & (FL_INF_INRING - 1)) >> 2;
+        const uint32_t lo = r.inring[i], hi = r.inring[(i + 1) & (FL_INF_INRING / 4 - 1)];
+        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, r.next_byte & 3);
+        r.buf |= (uint64_t)w << r.have;
+        r.have += 32;
+        r.next_byte += 4;
+    }
+}
 __device__ __forceinline__ int fl_br_fill(const fl_bitr& r, uint32_t nice) {
-    return (nice > 0 && r.pos >= r.total_bits) ? 1 : 0;  // EndOfStream
+    return (nice > 0 && r.left <= 0) ? 1 : 0;  // EndOfStream
 }
 __device__ __forceinline__ uint32_t fl_br_peek(fl_bitr& r, uint32_t n) {  // n <= 32
     fl_br_refill(r);
     return (uint32_t)(r.buf & ((1ull << n) - 1));
 }
-// bit_reader.zig:159-163
 __device__ __forceinline__ int fl_br_shift(fl_bitr& r, uint32_t n) {
-    if (n > r.total_bits - r.pos) return 1;
+    if ((int64_t)n > r.left) return 1;
     fl_br_refill(r);
-    r.pos += n;
+    r.left -= n;
     r.buf >>= n;
     r.have -= n;
     return 0;
@@ -89,13 +131,18 @@ __device__ __forceinline__ int fl_br_read(fl_bitr& r, uint32_t n, uint32_t& v) {
     return fl_br_shift(r, n);
 }
 __device__ __forceinline__ void fl_br_align(fl_bitr& r) {  // bit_reader.zig:189-192
-    const uint32_t k = (uint32_t)((8 - (r.pos & 7)) & 7);
+    const uint32_t k = (uint32_t)r.left & 7;  // the stream is a whole number of bytes
     if (k) {
         fl_br_refill(r);
-        r.pos += k;
+        r.left -= k;
         r.buf >>= k;
         r.have -= k;
     }
+}
+// bytes consumed so far, rounded up
+__device__ __forceinline__ uint64_t fl_br_consumed(const fl_bitr& r) {
+    const uint64_t pos = (uint64_t)r.nbytes * 8 - (uint64_t)r.left;
+    return (pos + 7) >> 3;
 }
 
 // huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order).  Runs on all
@@ -242,12 +289,10 @@ __device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint
 }
 __device__ __forceinline__ int fl_inf_literal(fl_inf_out& o, uint32_t byte, uint32_t lane) {
     if (o.wp >= o.cap) return 100;
-    if (lane == 0) {
-        o.out[o.wp] = (uint8_t)byte;
-        o.ring[(uint32_t)o.wp & (FL_INF_RING - 1)] = (uint8_t)byte;
-    }
+    // every lane stores the same byte to the same address: one transaction, no exec juggling
+    o.out[o.wp] = (uint8_t)byte;
+    o.ring[(uint32_t)o.wp & (FL_INF_RING - 1)] = (uint8_t)byte;
     o.wp++;
-    fl_inf_advance(o);
     return 0;
 }
 
@@ -286,9 +331,10 @@ __device__ __forceinline__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t
     FL_TRY(fl_br_read(r, 16, len));
     FL_TRY(fl_br_read(r, 16, nlen));
     if (len != ((~nlen) & 0xffff)) return 13;
-    if ((uint64_t)len * 8 > r.total_bits - r.pos) return 1;
+    if ((int64_t)len * 8 > r.left) return 1;
     if (o.wp + len > o.cap) return 100;
-    const uint8_t* s = r.data + (r.pos >> 3);
+    const uint32_t src_off = (uint32_t)fl_br_consumed(r);  // byte aligned here
+    const uint8_t* s = r.data + src_off;
     for (uint32_t i = lane; i < len; i += 64) o.out[o.wp + i] = s[i];
     // the ring mirrors the last bytes of the output
     {
@@ -302,9 +348,8 @@ __device__ __forceinline__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t
     }
     o.wp += len;
     fl_inf_advance(o);
-    r.pos += (uint64_t)len * 8;
-    r.buf = 0;
-    r.have = 0;
+    r.left -= (int64_t)len * 8;
+    fl_br_seek(r, src_off + len);
     return 0;
 }
 
@@ -573,6 +618,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
                                                 int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
     __shared__ fl_inflate_ws ws_mem;
     __shared__ uint32_t crc_tab_mem[256];
+    __shared__ uint32_t inring_mem[FL_INF_INRING / 4];
     FL_LDS fl_inflate_ws* ws = (FL_LDS fl_inflate_ws*)&ws_mem;
     FL_LDS uint32_t* crc_tab = (FL_LDS uint32_t*)crc_tab_mem;
     const uint32_t c = blockIdx.x;
@@ -582,10 +628,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     fl_bitr r;
     r.data = in + ck.in_off;
     r.nbytes = ck.in_len;
-    r.total_bits = (uint64_t)ck.in_len * 8;
-    r.pos = 0;
-    r.buf = 0;
-    r.have = 0;
+    r.left = (int64_t)ck.in_len * 8;
+    r.lane = lane;
+    r.inring = (FL_LDS uint32_t*)inring_mem;
+    fl_br_seek(r, 0);
     fl_inf_out o;
     o.out = out + ck.out_off;
     o.ring = ws->ring;
@@ -634,6 +680,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     if (lane == 0) {
         out_len[c] = o.wp;
         status[c] = rc;
-        if (consumed) consumed[c] = (r.pos + 7) >> 3;
+        if (consumed) consumed[c] = fl_br_consumed(r);
     }
 }
