@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--container", type=int, default=0, help="0 raw, 1 gzip, 2 zlib")
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL reassembly of the output")
+    ap.add_argument("--force-gather", action="store_true", help="run the reassembly path even with one rank (test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chunks", type=int, default=4096)
     ap.add_argument("--no-verify", action="store_true")
@@ -67,8 +68,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from flate_amd import Engine, synth
@@ -93,7 +97,7 @@ def main():
     out_len = torch.zeros(n_chunks, dtype=torch.int64, device=device)
     status = torch.zeros(n_chunks, dtype=torch.int32, device=device)
     gather = None
-    if world > 1 and not args.no_gather:
+    if (world > 1 or args.force_gather) and not args.no_gather:
         gather = sharded.OutputGather(world, rank, device, int(out_off_np[-1]))
 
     def step():
@@ -103,7 +107,7 @@ def main():
             gather.run(out, out_off, out_len)
 
     def fence():
-        if world > 1:
+        if world > 1 or args.force_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +210,14 @@ def main():
         }
         print(json.dumps(result))
         sys.stdout.flush()
-    if world > 1:
+    if gather is not None and rank == 0:
+        # the reassembled shard of this rank must be the packed streams themselves
+        sizes = gather.run(out, out_off, out_len)
+        torch.cuda.synchronize()
+        assert sizes[rank] == n_out and torch.equal(gather.shard(rank, sizes), comp[:n_out]), "gather mismatch"
+    elif gather is not None:
+        gather.run(out, out_off, out_len)
+    if world > 1 or args.force_gather:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -54,18 +54,23 @@ def compact(out, out_slot_start, out_len, dst, dst_off, engine=None):
 
 
 class OutputGather:
-    """Reassemble the compressed output of all ranks on every rank."""
+    """Reassemble the compressed output of all ranks on every rank.
+
+    Every rank packs its streams back to back, the packed sizes are all-gathered (one int64
+    per rank), and the shards are exchanged with ONE all-gather of equal-sized slices (each
+    padded to the largest shard): on xGMI every GPU has a direct link to every peer, so all
+    shards move concurrently.  `gathered[r, :sizes[r]]` is rank r's packed output afterwards.
+    """
 
     def __init__(self, world, rank, device, local_cap, engine=None):
         import torch
         from .engine import default_engine
         self.world, self.rank, self.device = world, rank, device
         self.engine = engine if engine is not None else (default_engine() if device.type == "cuda" else None)
-        self.local_cap = int(local_cap)
-        self.packed = torch.empty(self.local_cap + 8, dtype=torch.uint8, device=device)
+        self.local_cap = (int(local_cap) + 15) & ~15
+        self.packed = torch.empty(self.local_cap + 16, dtype=torch.uint8, device=device)
         self.sizes = torch.zeros(world, dtype=torch.int64, device=device)
-        self.bufs = [self.packed if r == rank else torch.empty(self.local_cap + 8, dtype=torch.uint8, device=device)
-                     for r in range(world)]
+        self.gathered = torch.empty((world, self.local_cap), dtype=torch.uint8, device=device)
         self.dst_off = None
 
     def run(self, out, out_off, out_len):
@@ -80,9 +85,10 @@ class OutputGather:
         parts = [self.sizes[r:r + 1] for r in range(self.world)]
         dist.all_gather(parts, mine)
         sizes = [int(x) for x in self.sizes.cpu().tolist()]
-        works = []
-        for r in range(self.world):
-            works.append(dist.broadcast(self.bufs[r][:sizes[r]], src=r, async_op=True))
-        for w in works:
-            w.wait()
+        width = (max(sizes) + 15) & ~15  # same slice width on every rank
+        views = [self.gathered[r, :width] for r in range(self.world)]
+        dist.all_gather(views, self.packed[:width])
         return sizes
+
+    def shard(self, r, sizes):
+        return self.gathered[r, :sizes[r]]
