@@ -178,7 +178,8 @@ def main():
         algo_bytes = n_in + n_out  # read every input byte once, write every output byte once
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": measured_traffic(args, n_in, dom[0]),
                     "kernel_ms": round(dom_ms, 4),
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}}
         cpu = None
@@ -221,6 +222,23 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def measured_traffic(args, n_in, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (FETCH_SIZE + WRITE_SIZE, two separate
+    rocprofv3 --pmc runs of this very command; profiles/r01_hbm_traffic_1gib.json), when the workload matches;
+    PMC counters cannot be read from inside an un-profiled run, so otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_1gib.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["workload"] == args.workload and t["bytes_per_gpu"] == n_in and t["mode"] == args.mode and \
+                args.chunk == CHUNK and kernel in t["kernels"]:
+            k = t["kernels"][kernel]
+            return k["fetch_bytes"] + k["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def _oracle():
