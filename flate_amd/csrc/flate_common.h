@@ -148,7 +148,7 @@ struct fl_block_plan {
     uint32_t tok_start;  // chunk-relative token index (token blocks) / byte index (huffman-only)
     uint32_t tok_count;
     uint32_t valid;
-    uint32_t pad_;
+    uint32_t no_input;   // token blocks: the raw input slice is gone (window slide since the last flush)
     uint64_t bit_off;  // absolute bit offset in `out`, filled by the offset scan
     uint8_t hdr[FL_HDR_BYTES];
     fl_hcode lit[FL_NUM_LIT];

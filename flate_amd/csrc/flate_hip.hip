@@ -16,6 +16,7 @@
 #include "kernels_common.h"
 #include "kernels_inflate.h"
 #include "kernels_lz.h"
+#include "kernels_stream.h"
 
 namespace {
 
@@ -27,6 +28,8 @@ enum KernelId {
     K_LZ_MATCH,
     K_LZ_PARSE,
     K_LZ_EMIT,
+    K_ST_PARSE,
+    K_ST_EMIT,
     K_PLAN,
     K_OFFSETS,
     K_ENCODE,
@@ -35,8 +38,8 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_parse", "k_lz_emit",   "k_plan",     "k_offsets", "k_encode",
-                                           "k_inflate",  "k_gather"};
+                                           "k_lz_parse", "k_lz_emit",   "k_st_parse", "k_st_emit", "k_plan",
+                                           "k_offsets",  "k_encode",    "k_inflate",  "k_gather"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -54,10 +57,12 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
+    DevBuf tiles, segs, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
     uint32_t dbg_first_chunk = 0;
+    std::vector<uint64_t> dbg_pos_off;
     // profiling
     bool prof = false;
     struct Pending {
@@ -174,6 +179,82 @@ size_t pass_chunk_limit() {
     return 32768;
 }
 
+// whole-stream passes: uncompressed bytes per pass (about 30 bytes of scratch per input byte)
+uint64_t stream_pass_byte_limit() {
+    const char* e = getenv("FLATE_HIP_MAX_STREAM_PASS_MIB");
+    if (e && atoll(e) > 0) return (uint64_t)atoll(e) << 20;
+    return 4096ull << 20;
+}
+
+// Levels 4..9, inputs longer than 65535 bytes: tokenizer kernels of one whole-stream pass
+// (kernels_stream.h).  Leaves tokens, histograms and the block table for the shared back end.
+int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
+                         uint64_t npos, const std::vector<fl_tile>& tiles, const std::vector<fl_seg>& segs) {
+    hipStream_t st = h->stream;
+    int rc;
+    const uint32_t nseg = (uint32_t)segs.size();
+    const size_t tile_limit = pass_chunk_limit();
+    const size_t tiles_per_launch = std::min(tiles.size(), tile_limit);
+    if ((rc = ensure(h, h->tiles, sizeof(fl_tile) * tiles.size()))) return rc;
+    if ((rc = ensure(h, h->segs, sizeof(fl_seg) * segs.size()))) return rc;
+    if ((rc = ensure(h, h->S, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(h, h->NC, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->rec, npos * 2 * sizeof(uint32_t) + 64))) return rc;
+    if ((rc = ensure(h, h->desc, npos * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->tokens, npos * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->jmp, npos * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(h, h->marks, npos / 8))) return rc;
+    if ((rc = ensure(h, h->exitmap, (size_t)nseg * FL_SEG_ENTRIES * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(h, h->entry, sizeof(uint32_t) * nseg))) return rc;
+    if ((rc = ensure(h, h->segtok, sizeof(uint32_t) * nseg))) return rc;
+    if ((rc = ensure(h, h->tokbase, sizeof(uint32_t) * nseg))) return rc;
+    if ((rc = ensure(h, h->bound, sizeof(uint32_t) * nb))) return rc;
+    if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
+    HIP_OK(h, hipMemcpyAsync(h->tiles.p, tiles.data(), sizeof(fl_tile) * tiles.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(h->segs.p, segs.data(), sizeof(fl_seg) * segs.size(), hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemsetAsync(h->hist.p, 0, sizeof(uint32_t) * 320 * (size_t)nb, st));
+    HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
+
+    const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
+    const fl_seg* dsg = (const fl_seg*)h->segs.p;
+    for (size_t t0 = 0; t0 < tiles.size(); t0 += tiles_per_launch) {
+        const uint32_t nt = (uint32_t)std::min(tiles_per_launch, tiles.size() - t0);
+        const fl_tile* dti = (const fl_tile*)h->tiles.p + t0;
+        {
+            ProfScope ps(h, K_LZ_SORT);
+            hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti,
+                               (uint16_t*)h->S.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_MATCH);
+            hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, prm,
+                               (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+        }
+    }
+    {
+        ProfScope ps(h, K_ST_PARSE);
+        hipLaunchKernelGGL(k_st_parse1, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dsg, prm,
+                           (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint16_t*)h->jmp.p,
+                           (uint16_t*)h->exitmap.p);
+        hipLaunchKernelGGL(k_st_stitch, dim3((nc + 63) / 64), dim3(64), 0, st, dch, nc,
+                           (const uint16_t*)h->exitmap.p, (uint32_t*)h->entry.p);
+        hipLaunchKernelGGL(k_st_parse2, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dsg,
+                           (const uint32_t*)h->desc.p, (const uint16_t*)h->jmp.p, (const uint32_t*)h->entry.p,
+                           (uint32_t*)h->marks.p, (uint32_t*)h->segtok.p);
+    }
+    {
+        ProfScope ps(h, K_ST_EMIT);
+        hipLaunchKernelGGL(k_st_scan, dim3(nc), dim3(64), 0, st, dch, (const uint32_t*)h->segtok.p,
+                           (uint32_t*)h->tokbase.p, (uint32_t*)h->ntok.p);
+        hipLaunchKernelGGL(k_st_emit, dim3(nseg), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, dsg, prm,
+                           (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (const uint32_t*)h->tokbase.p,
+                           (uint32_t*)h->tokens.p, (uint32_t*)h->hist.p, (uint32_t*)h->bound.p);
+        hipLaunchKernelGGL(k_st_blocks, dim3(nc), dim3(64), 0, st, dch, (const uint32_t*)h->ntok.p,
+                           (const uint32_t*)h->bound.p, (fl_block_plan*)h->plans.p);
+    }
+    return FLATE_HIP_OK;
+}
+
 // Fetch the n+1 offsets to the host (the block tables are built there).
 int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind, std::vector<uint64_t>& host) {
     host.resize((size_t)n + 1);
@@ -243,7 +324,8 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
+                      &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->jmp, &h->exitmap, &h->entry, &h->segtok, &h->tokbase,
+                      &h->bound, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
@@ -359,10 +441,8 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         c.skip = 0;
         if (len > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
         c.in_len = (uint32_t)len;
-        if (mode >= 4 && len > FLATE_HIP_MAX_LZ_CHUNK) {
-            c.skip = 1;
-            init_status[i] = FLATE_HIP_ST_CHUNK_TOO_LARGE;
-        }
+        c.pos_off = 0;
+        c.seg0 = c.n_seg = 0;
     }
     HIP_OK(h, hipMemcpyAsync(d_outlen, init_len.data(), sizeof(uint64_t) * n_chunks, hipMemcpyHostToDevice, st));
     HIP_OK(h, hipMemcpyAsync(d_status, init_status.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
@@ -373,21 +453,49 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         HIP_OK(h, hipMemsetAsync(d_out + (out_lo - out_shift), 0, out_hi - out_lo, st));
     }
 
+    // A pass is a run of consecutive chunks of one kind: at levels 4..9 inputs of up to 65535 bytes
+    // take the chunk path (kernels_lz.h), longer ones the whole-stream path (kernels_stream.h).
     const size_t pass_limit = pass_chunk_limit();
-    for (uint32_t c0 = 0; c0 < n_chunks; c0 += (uint32_t)pass_limit) {
-        const uint32_t nc = (uint32_t)std::min<size_t>(pass_limit, n_chunks - c0);
+    const uint64_t stream_pass_bytes = stream_pass_byte_limit();
+    uint32_t nc = 0;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
+        const bool stream = mode >= 4 && chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK;
+        uint64_t pass_bytes = 0;
+        for (nc = 0; c0 + nc < n_chunks; nc++) {
+            const fl_chunk& c = chunks[c0 + nc];
+            if ((mode >= 4 && c.in_len > FLATE_HIP_MAX_LZ_CHUNK) != stream) break;
+            if (stream ? (nc > 0 && pass_bytes + c.in_len > stream_pass_bytes) : nc >= pass_limit) break;
+            pass_bytes += c.in_len;
+        }
         // block table of this pass
         std::vector<uint32_t> blk_chunk;
+        std::vector<fl_tile> tiles;
+        std::vector<fl_seg> segs;
         uint32_t nb = 0;
+        uint64_t npos = 0;
         for (uint32_t i = 0; i < nc; i++) {
             fl_chunk& c = chunks[c0 + i];
             c.first_block = nb;
-            c.n_blocks = mode >= 4 ? 2u : (uint32_t)(c.in_len / FL_BLOCK_BYTES + 1);  // deflate.zig:498-511, 480-484
+            if (stream) {
+                // deflate.zig:227-230: a block per 32768 tokens (<= one token per byte) + the final one
+                c.n_blocks = c.in_len / FL_SEG + 2;
+                c.pos_off = npos;
+                c.seg0 = (uint32_t)segs.size();
+                c.n_seg = (c.in_len + FL_SEG - 1) / FL_SEG;
+                npos += (uint64_t)c.n_seg * FL_SEG;
+                for (uint32_t sg = 0; sg < c.n_seg; sg++) segs.push_back(fl_seg{i, sg});
+                tiles.push_back(fl_tile{i, 0u, 0u, 0u});
+                for (uint32_t w0 = FL_SEG; w0 + FL_SEG < c.in_len; w0 += FL_SEG) tiles.push_back(fl_tile{i, w0, FL_SEG, 0u});
+            } else {
+                c.n_blocks = mode >= 4 ? 2u : (uint32_t)(c.in_len / FL_BLOCK_BYTES + 1);  // deflate.zig:498-511, 480-484
+                c.pos_off = (uint64_t)i * FL_CHUNK_STRIDE;
+            }
             for (uint32_t k = 0; k < c.n_blocks; k++) blk_chunk.push_back(i);
             nb += c.n_blocks;
         }
         prm.n_chunks = nc;
         prm.n_blocks = nb;
+        prm.stream = stream ? 1u : 0u;
         if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * nc))) return rc;
         if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * nb))) return rc;
         if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)nb))) return rc;
@@ -408,7 +516,13 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             ProfScope ps(h, K_CHECKSUM);
             hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, prm, h->crc, dcks);
         }
-        if (mode >= 4) {
+        if (stream) {
+            if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, npos, tiles, segs))) return rc;
+            h->dbg_pass_chunks = nc;
+            h->dbg_first_chunk = c0;
+            h->dbg_pos_off.resize(nc);
+            for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = chunks[c0 + i].pos_off;
+        } else if (mode >= 4) {
             const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
             if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
@@ -419,12 +533,14 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
             {
                 ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch, (uint16_t*)h->S.p);
+                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (uint16_t*)h->S.p);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                hipLaunchKernelGGL(k_lz_match, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);
@@ -439,6 +555,8 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             }
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;
+            h->dbg_pos_off.resize(nc);
+            for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = (uint64_t)i * FL_CHUNK_STRIDE;
         } else if (mode == 1) {
             ProfScope ps(h, K_BYTE_HIST);
             hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dhist);
@@ -593,7 +711,7 @@ int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tok
     if (hipMemcpy(&n, (uint32_t*)h->ntok.p + local, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
         return FLATE_HIP_E_LAUNCH;
     const uint64_t k = std::min<uint64_t>(n, cap);
-    if (k && hipMemcpy(tokens, (uint32_t*)h->tokens.p + (size_t)local * FL_CHUNK_STRIDE, k * sizeof(uint32_t),
+    if (k && hipMemcpy(tokens, (uint32_t*)h->tokens.p + h->dbg_pos_off[local], k * sizeof(uint32_t),
                        hipMemcpyDeviceToHost) != hipSuccess)
         return FLATE_HIP_E_LAUNCH;
     return (int64_t)n;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
     const uint32_t lane = threadIdx.x;
     if (ck.skip) return;
     uint32_t start, len;
-    if (prm.mode >= 4) {
+    if (prm.mode >= 4 && !prm.stream) {
         if (b != ck.first_block) return;  // level 4..9: the chunk (<= 65535 bytes) is one checksum unit
         start = 0;
         len = ck.in_len;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t b = blockIdx.x * FL_PLAN_WAVES + wave;
     if (b >= prm.n_blocks) return;
-    if (prm.mode >= 4) {
+    if (prm.mode >= 4 && !prm.stream) {
         // two plan slots per chunk and the second one is rarely used: visit all first slots
         // before the second ones, so that resident waves are waves with work
         const uint32_t half = prm.n_blocks >> 1;
@@ -179,7 +179,9 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         for (uint32_t i = lane; i < FL_NUM_LIT; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         if (lane < FL_NUM_DIST) ws.dist_freq[lane] = (uint16_t)hist[(uint64_t)b * 320 + 286 + lane];
         fl_wave_lds_sync();
-        if (lane == 0) fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);
+        // no_input: a window slide since the previous flush took the raw bytes away
+        // (SlidingWindow.zig:119-123): only whole-stream passes ever set it
+        if (lane == 0) fl_plan_token_block(&ws, plan, plan->no_input ? FL_NO_INPUT : plan->in_len, plan->final_block);
     }
 }
 
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
     // checksum over the whole chunk: fold the per-block parts (lane 0, serial Horner)
     uint32_t cks = 0;
     if (prm.container != 0 && lane == 0) {
-        if (prm.mode >= 4) {
+        if (prm.mode >= 4 && !prm.stream) {
             cks = cks_part[2 * (uint64_t)ck.first_block];
             if (prm.container == 2) {
                 const uint32_t A = cks & 0xffff, B = cks >> 16, n = ck.in_len;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
     const uint32_t n_sym = plan->tok_count;
     const uint32_t n_items = n_hdr + n_sym + 1;
     const uint8_t* bytes = src + plan->tok_start;
-    const uint32_t* toks = TOKENS ? tokens + (uint64_t)cidx * FL_CHUNK_STRIDE + plan->tok_start : nullptr;
+    const uint32_t* toks = TOKENS ? tokens + ck.pos_off + plan->tok_start : nullptr;
     const uint8_t* hdr = plan->hdr;
 
     // contiguous item range of this wave, a multiple of 64 items

@@ -14,10 +14,28 @@ struct fl_chunk {
     uint64_t in_off;   // byte offset of the chunk in `in`
     uint64_t out_off;  // byte offset of the chunk's output slot in `out`
     uint64_t out_cap;  // slot size in bytes
+    uint64_t pos_off;  // levels 4..9: base index of the chunk in the per-position scratch arrays
     uint32_t in_len;
     uint32_t first_block;  // index of the chunk's first fl_block_plan
-    uint32_t n_blocks;     // huffman/store: in_len / 65535 + 1; levels 4..9: 2 slots
+    uint32_t n_blocks;     // huffman/store: in_len / 65535 + 1; levels 4..9: 2 slots (chunk), in_len / 32768 + 2 (stream)
     uint32_t skip;         // non-zero: chunk is not processed (status already set by the host)
+    uint32_t seg0;         // whole-stream passes: index of the chunk's first 32 KiB segment in the pass
+    uint32_t n_seg;        // whole-stream passes: number of segments
+};
+
+// Whole-stream passes (inputs longer than 65535 bytes at levels 4..9): one match-finder tile is
+// a 64 KiB window of the stream whose positions >= tgt0 are searched ("targets"); the others are
+// only history (SlidingWindow.zig:36-44 keeps 32 KiB of history across a slide).
+struct fl_tile {
+    uint32_t chunk;  // index into the pass's chunk table
+    uint32_t w0;     // stream-relative position of the window start (multiple of 32768)
+    uint32_t tgt0;   // window-relative position of the first target (0 or 32768)
+    uint32_t pad_;
+};
+// one 32768-position piece of a stream for the parse / emit kernels
+struct fl_seg {
+    uint32_t chunk;
+    uint32_t s;  // segment number inside the stream
 };
 
 // call-wide constants
@@ -28,7 +46,8 @@ struct fl_params {
     int32_t mode;       // 0 store, 1 huffman, 4..9
     // level args (deflate.zig:41-52)
     uint32_t good, lazy, nice, chain;
-    uint32_t dbg;  // tuning experiments only (FLATE_HIP_DBG), 0 in production
+    uint32_t dbg;     // tuning experiments only (FLATE_HIP_DBG), 0 in production
+    uint32_t stream;  // non-zero: whole-stream pass (kernels_stream.h)
 };
 
 // CRC-32 helper constants computed on the host once (reflected representation,

@@ -135,20 +135,25 @@ __device__ __forceinline__ void fl_scan_counters(uint32_t (*cnt)[NDIG], uint32_t
     __syncthreads();
 }
 
+// STREAM: the unit is a tile of a long stream (fl_tile): the window starts w0 bytes into the
+// chunk, N is what is left of the stream from there and at most 65536 positions are sorted.
+template <bool STREAM>
 __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
+                                                              const fl_tile* __restrict__ tiles,
                                                               uint16_t* __restrict__ S) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
     __shared__ uint32_t wsum[FL_SORT_WAVES];
     const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
+    const uint32_t w0 = STREAM ? tiles[c].w0 : 0u;
+    const fl_chunk ck = chunks[STREAM ? tiles[c].chunk : c];
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t N = ck.in_len;
-    const uint32_t M = N >= 4 ? N - 3 : 0;
-    const uint8_t* src = in + ck.in_off;
+    const uint32_t N = ck.in_len - w0;
+    const uint32_t M = min(N >= 4 ? N - 3 : 0u, 65536u);
+    const uint8_t* src = in + ck.in_off + w0;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t slice0 = wave * FL_SORT_SLICE;
@@ -305,34 +310,50 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 //    their first four bytes, because the hash is a function of those bytes).
 //  * the best match so far is one 32-bit key  len << 16 | (65535 - dist):  a longer match
 //    wins, and for equal length the nearer one, which is the one the reference met first.
+//
+// STREAM (whole-stream passes): the unit is a tile (fl_tile).  Only entries at window positions
+// >= tgt0 are searched; the window carries 288 bytes of lookahead past its 65536 positions so
+// that a match of the last target can run its full 258 bytes; N is what is left of the stream.
+// After the reference slides its window (deflate.zig:291-294, Lookup.zig:43-51) everything at or
+// below the new window start is gone from the chains: positions visited after slide number j
+// (those at buffer offsets >= 65274 = 65536 - min_lookahead, SlidingWindow.zig:56-60, provided
+// the window did fill up, i.e. N >= 65536) may only use candidates above window offset 32768.
+#define FL_WIN_DW_CHUNK (16384 + 8)
+#define FL_WIN_DW_STREAM (16384 + 72)
+#define FL_ZONE_START (65536u - (FL_MAX_MATCH + 4u))  // deflate.zig:159-163 min_lookahead = 262
+template <bool STREAM>
 __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
-                                                                  const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                  const fl_chunk* __restrict__ chunks,
+                                                                  const fl_tile* __restrict__ tiles, fl_params prm,
                                                                   const uint16_t* __restrict__ S,
                                                                   uint32_t* __restrict__ NQ,
                                                                   uint32_t* __restrict__ rec_all) {
-    __shared__ uint32_t win32[16384 + 8];
+    constexpr uint32_t WIN_DW = STREAM ? FL_WIN_DW_STREAM : FL_WIN_DW_CHUNK;
+    __shared__ uint32_t win32[WIN_DW];
     __shared__ uint2 tW[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint16_t tS[FL_MATCH_WAVES][FL_TILE];
     __shared__ uint32_t wlast[FL_MATCH_WAVES];
     const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
+    const uint32_t w0 = STREAM ? tiles[c].w0 : 0u;
+    const uint32_t tgt0 = STREAM ? tiles[c].tgt0 : 0u;
+    const fl_chunk ck = chunks[STREAM ? tiles[c].chunk : c];
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t N = ck.in_len;
-    const uint32_t M = N >= 4 ? N - 3 : 0;
-    const uint8_t* src = in + ck.in_off;
+    const uint32_t N = ck.in_len - w0;
+    const uint32_t M = min(N >= 4 ? N - 3 : 0u, 65536u);
+    const uint8_t* src = in + ck.in_off + w0;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* NQc = NQ + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint2* rec2 = (uint2*)(rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE);
+    uint2* rec2 = (uint2*)rec_all + ck.pos_off + w0;
     const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
 
     fl_prof_mark(8);
-    // stage the chunk in LDS (zero padded)
-    const uint32_t ndw = (N + 3) >> 2;
-    for (uint32_t i = tid; i < 16384 + 8; i += FL_MATCH_THREADS)
+    // stage the window in LDS (zero padded)
+    const uint32_t ndw = (min(N, WIN_DW * 4u) + 3) >> 2;
+    for (uint32_t i = tid; i < WIN_DW; i += FL_MATCH_THREADS)
         win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
     // positions without a hash entry never match (Lookup.zig:24)
-    for (uint32_t p = M + tid; p < N; p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
+    for (uint32_t p = M + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
     __syncthreads();
     fl_prof_mark(9);
 
@@ -422,12 +443,13 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     }
     for (uint32_t batch = wave; batch < nbatch; batch += FL_MATCH_WAVES) {
         const uint32_t i0 = batch << 6, i = i0 + lane;
-        const bool active = i < M;
         const uint32_t p = nx_p;
+        const bool active = i < M && (!STREAM || p >= tgt0);
         uint32_t n = active ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only)
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248),
         // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
         uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
+        if (STREAM && p >= FL_ZONE_START && N >= 65536u) lov = max(lov, FL_MAX_DIST + 1u);
         if (n == 0) lov = 0x7fffffffu;
         // positions of the first tile's entries (slots lane and lane + 64 < FL_TILE), fetched a batch ahead
         uint32_t tq0 = nx_tq0, tq1 = nx_tq1;
@@ -618,9 +640,9 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_lz_parse(const fl_chunk
     const uint32_t tid = threadIdx.x;
     if (ck.skip) return;
     const uint32_t N = ck.in_len;
-    const uint2* rec2 = (const uint2*)(rec_all + (uint64_t)c * 2 * FL_CHUNK_STRIDE);
-    uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* gmarks = marks_all + (uint64_t)c * 2048;
+    const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
+    uint32_t* desc = desc_all + ck.pos_off;
+    uint32_t* gmarks = marks_all + (ck.pos_off >> 5);
 
     for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) marks[i] = 0;
     if (tid < 256) entry[tid] = 0xffff;
@@ -745,9 +767,9 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __re
     }
     const uint32_t N = ck.in_len;
     const uint8_t* src = in + ck.in_off;
-    const uint32_t* desc = desc_all + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint32_t* gmarks = marks_all + (uint64_t)c * 2048;
-    uint32_t* tokens = tokens_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t* desc = desc_all + ck.pos_off;
+    const uint32_t* gmarks = marks_all + (ck.pos_off >> 5);
+    uint32_t* tokens = tokens_all + ck.pos_off;
 
     fl_prof_mark(24);
     const uint32_t ndw = (N + 3) >> 2;
@@ -830,6 +852,8 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __re
     if (tid == 0) {
         ntok_all[c] = total;
         const uint32_t v1 = v1_sh;
+        plan0->no_input = 0;
+        plan1->no_input = 0;
         if (nblk == 1) {
             plan0->valid = 1;
             plan0->tok_start = 0;

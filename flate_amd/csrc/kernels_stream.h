@@ -1,0 +1,332 @@
+// kernels_stream.h -- levels 4..9 for inputs longer than 65535 bytes: ONE deflate stream per
+// input, byte-identical to what the reference produces when the whole input goes through
+// Deflate.compress (deflate.zig:304-321) with its sliding 64 KiB window.
+//
+// What changes against the chunk path (kernels_lz.h):
+//  * match finding runs on overlapping 64 KiB tiles (k_lz_sort<true>, k_lz_match<true>): a tile
+//    searches 32 KiB of new positions against 32 KiB of history, which is exactly what the
+//    reference's window holds after a slide (SlidingWindow.zig:36-44, Lookup.zig:43-51).  The
+//    records go to one per-stream array indexed by the absolute position.
+//  * the lazy-matching automaton (deflate.zig:154-205) is a chain through the whole stream.  It
+//    is cut into 32768-position segments: every segment resolves "anchor -> first anchor beyond
+//    the segment" for each of the <= 512 offsets a predecessor can hand over (k_st_parse1), one
+//    thread per stream then walks segment to segment (k_st_stitch), and with its entry anchor
+//    known each segment marks its anchors and counts its tokens (k_st_parse2).
+//  * tokens are numbered through the whole stream; a block ends every 32768 tokens
+//    (deflate.zig:227-230), wherever that falls (k_st_scan, k_st_emit, k_st_blocks).
+//  * the raw input slice a block may be stored from (SlidingWindow.zig:119-123) is lost when the
+//    window slid since the previous flush: fl_block_plan::no_input.
+//
+// The block planner, the offset scan and the bit packer (kernels_block.h) are shared.
+#pragma once
+#include "kernels_lz.h"
+
+#define FL_SEG 32768u
+#define FL_SEG_ENTRIES 512u  // next anchor <= previous + 254 literals + 258: hand-over offsets < 512
+
+// number of slides the reference has done when it visits stream position v, for a stream of
+// n bytes: slide j happens once the window is full (n >= 65536 + 32768 (j-1), deflate.zig:
+// 306-311) and the tokenizer has come within min_lookahead of its end (SlidingWindow.zig:56-60)
+__device__ __forceinline__ uint32_t fl_total_slides(uint32_t n) {
+    return n >= 65536u ? (n - 65536u) / FL_SEG + 1u : 0u;
+}
+__device__ __forceinline__ uint32_t fl_slides_before(uint32_t v, uint32_t n) {
+    const uint32_t by_pos = v >= FL_ZONE_START ? (v - FL_ZONE_START) / FL_SEG + 1u : 0u;
+    return min(by_pos, fl_total_slides(n));
+}
+
+// ------------------------------------------------------------------ k_st_parse1
+// One workgroup per segment.  desc[] for every position (as k_lz_parse phase a), the pointer
+// table jumped inside 256-position pieces (phase b) saved to jmp[], and the exit map
+// exitmap[seg][e] = first anchor >= segment end on the path that enters at offset e.
+__global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse1(const fl_chunk* __restrict__ chunks,
+                                                                    const fl_seg* __restrict__ segs, fl_params prm,
+                                                                    const uint32_t* __restrict__ rec_all,
+                                                                    uint32_t* __restrict__ desc_all,
+                                                                    uint16_t* __restrict__ jmp_all,
+                                                                    uint16_t* __restrict__ exitmap) {
+    __shared__ uint16_t J[FL_SEG];
+    const fl_seg sg = segs[blockIdx.x];
+    const fl_chunk ck = chunks[sg.chunk];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = ck.in_len;
+    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
+    uint32_t* desc = desc_all + ck.pos_off;
+    uint16_t* jmp = jmp_all + ck.pos_off + h0;
+
+    for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
+        uint2 ra[8], rb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            ra[u] = p < h1 ? rec2[p] : make_uint2(0u, 0u);
+            rb[u] = (p < h1 && p + 1 < N) ? rec2[p + 1] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t p = base + u * FL_PARSE_THREADS + tid;
+            if (p < h1) {
+                const uint32_t d = fl_anchor_desc(rec2, p, ra[u], rb[u], prm.good, prm.lazy);
+                desc[p] = d;
+                J[p - h0] = (uint16_t)(fl_desc_next(d, p) - h0);
+            }
+        }
+    }
+    __syncthreads();
+    for (int round = 0; round < 8; round++) {
+        for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) {
+            const uint32_t piece_end = min((r | 255u) + 1u, len);
+            const uint32_t j = J[r];
+            if (j < piece_end) J[r] = J[j];
+        }
+        __syncthreads();
+    }
+    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) jmp[r] = J[r];
+    if (tid < FL_SEG_ENTRIES && tid < len) {
+        uint32_t a = tid;
+        while (a < len) a = J[a];
+        exitmap[(uint64_t)blockIdx.x * FL_SEG_ENTRIES + tid] = (uint16_t)a;
+    }
+}
+
+// ------------------------------------------------------------------ k_st_stitch
+// One thread per stream: the entry anchor of every segment (segment-relative).
+__global__ __launch_bounds__(64) void k_st_stitch(const fl_chunk* __restrict__ chunks, uint32_t n_chunks,
+                                                  const uint16_t* __restrict__ exitmap,
+                                                  uint32_t* __restrict__ entry) {
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_chunks) return;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    uint32_t a = 0;
+    for (uint32_t s = 0; s < ck.n_seg; s++) {
+        entry[ck.seg0 + s] = a;
+        if (s + 1 < ck.n_seg) a = (uint32_t)exitmap[(uint64_t)(ck.seg0 + s) * FL_SEG_ENTRIES + a] - FL_SEG;
+    }
+}
+
+// ------------------------------------------------------------------ k_st_parse2
+// One workgroup per segment: anchors of the segment (k_lz_parse phases c-e) from its entry
+// anchor, and the number of tokens they emit.
+__global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chunk* __restrict__ chunks,
+                                                                    const fl_seg* __restrict__ segs,
+                                                                    const uint32_t* __restrict__ desc_all,
+                                                                    const uint16_t* __restrict__ jmp_all,
+                                                                    const uint32_t* __restrict__ entry,
+                                                                    uint32_t* __restrict__ marks_all,
+                                                                    uint32_t* __restrict__ segtok) {
+    __shared__ uint16_t J[FL_SEG];
+    __shared__ uint32_t marks[FL_SEG / 32];
+    __shared__ uint16_t piece_entry[FL_SEG / 256];
+    __shared__ uint32_t wsum[FL_PARSE_THREADS / 64];
+    const fl_seg sg = segs[blockIdx.x];
+    const fl_chunk ck = chunks[sg.chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t N = ck.in_len;
+    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint32_t* desc = desc_all + ck.pos_off + h0;
+    const uint16_t* jmp = jmp_all + ck.pos_off + h0;
+    uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
+
+    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) J[r] = jmp[r];
+    for (uint32_t i = tid; i < FL_SEG / 32; i += FL_PARSE_THREADS) marks[i] = 0;
+    if (tid < FL_SEG / 256) piece_entry[tid] = 0xffff;
+    __syncthreads();
+    if (tid == 0) {  // first anchor of every 256-position piece: at most 128 serial steps
+        uint32_t a = entry[blockIdx.x];
+        while (a < len) {
+            piece_entry[a >> 8] = (uint16_t)a;
+            a = J[a];
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) J[r] = (uint16_t)(fl_desc_next(desc[r], r));
+    __syncthreads();
+    if (tid < FL_SEG / 256) {
+        uint32_t a = piece_entry[tid];
+        const uint32_t end = min((tid + 1) << 8, len);
+        while (a < end) {
+            marks[a >> 5] |= 1u << (a & 31);
+            a = J[a];
+        }
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) {
+        if ((marks[r >> 5] >> (r & 31)) & 1) {
+            const uint32_t d = desc[r];
+            cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
+        }
+    }
+    for (uint32_t i = tid; i < FL_SEG / 32; i += FL_PARSE_THREADS) gmarks[i] = marks[i];
+    cnt = fl_wave_sum(cnt);
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < FL_PARSE_THREADS / 64; w++) t += wsum[w];
+        segtok[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------ k_st_scan
+// One wave per stream: index of every segment's first token, and the stream's token count.
+__global__ __launch_bounds__(64) void k_st_scan(const fl_chunk* __restrict__ chunks,
+                                                const uint32_t* __restrict__ segtok,
+                                                uint32_t* __restrict__ tokbase, uint32_t* __restrict__ ntok) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) {
+        if (lane == 0) ntok[c] = 0;
+        return;
+    }
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < ck.n_seg; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const uint32_t v = s < ck.n_seg ? segtok[ck.seg0 + s] : 0;
+        const uint32_t inc = fl_wave_incl_scan(v, lane);
+        if (s < ck.n_seg) tokbase[ck.seg0 + s] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) ntok[c] = run;
+}
+
+// ------------------------------------------------------------------ k_st_emit
+// One workgroup per segment: tokens, per-block histograms (added into hist_all, which the host
+// cleared) and the stream position at which each full block was flushed (bound[]).
+#define FL_STE_SPAN (FL_SEG / FL_EMIT_WAVES)
+#define FL_STE_WIN_DW (FL_SEG / 4 + 72)
+__global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __restrict__ in,
+                                                              const fl_chunk* __restrict__ chunks,
+                                                              const fl_seg* __restrict__ segs, fl_params prm,
+                                                              const uint32_t* __restrict__ desc_all,
+                                                              const uint32_t* __restrict__ marks_all,
+                                                              const uint32_t* __restrict__ tokbase,
+                                                              uint32_t* __restrict__ tokens_all,
+                                                              uint32_t* __restrict__ hist_all,
+                                                              uint32_t* __restrict__ bound) {
+    __shared__ uint32_t win32[FL_STE_WIN_DW];
+    __shared__ uint32_t marks[FL_SEG / 32];
+    __shared__ uint32_t hist[2][320];
+    __shared__ uint32_t wtot[FL_EMIT_WAVES];
+    const fl_seg sg = segs[blockIdx.x];
+    const fl_chunk ck = chunks[sg.chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t N = ck.in_len;
+    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint8_t* src = in + ck.in_off + h0;
+    const uint32_t* desc = desc_all + ck.pos_off + h0;
+    const uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
+    uint32_t* tokens = tokens_all + ck.pos_off;
+
+    const uint32_t nleft = N - h0;
+    const uint32_t ndw = (min(nleft, FL_STE_WIN_DW * 4u) + 3) >> 2;
+    for (uint32_t i = tid; i < FL_STE_WIN_DW; i += FL_EMIT_THREADS)
+        win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, nleft) : 0u;
+    for (uint32_t i = tid; i < FL_SEG / 32; i += FL_EMIT_THREADS) marks[i] = gmarks[i];
+    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t span0 = wave * FL_STE_SPAN;
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < FL_STE_SPAN / 64; r += 4) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            d[u] = p < len ? desc[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            cnt += mk ? (d[u] ? ((d[u] >> 23) & 0xff) + 1 : 1) : 0;
+        }
+    }
+    cnt = fl_wave_sum(cnt);
+    if (lane == 0) wtot[wave] = cnt;
+    __syncthreads();
+    const uint32_t tb = tokbase[blockIdx.x];
+    const uint32_t blk0 = tb >> 15;  // stream block holding this segment's first token
+    uint32_t run = tb;
+    for (uint32_t w = 0; w < wave; w++) run += wtot[w];
+    for (uint32_t r = 0; r < FL_STE_SPAN / 64; r += 4) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            d[u] = p < len ? desc[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = span0 + (r + u) * 64 + lane;
+            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            const uint32_t dd = d[u];
+            const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;
+            const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
+            const uint32_t incl = fl_wave_incl_scan(nt, lane);
+            uint32_t idx = run + incl - nt;
+            run += __shfl(incl, 63, 64);
+            for (uint32_t x = 0; x < nl; x++) {
+                const uint32_t byte = fl_win_byte(win32, p + x);
+                tokens[idx] = FL_TOK_LIT(byte);
+                atomicAdd(&hist[(idx >> 15) - blk0][byte], 1u);
+                // a literal goes out at the visit of the next position (deflate.zig:214-216)
+                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
+                    bound[ck.first_block + (idx >> 15) + 1] = h0 + p + x + 1;
+                idx++;
+            }
+            if (mk && dd) {
+                const uint32_t ll = (dd >> 15) & 0xff, d0 = dd & 0x7fff;
+                tokens[idx] = (1u << 23) | (ll << 15) | d0;
+                atomicAdd(&hist[(idx >> 15) - blk0][257 + fl_len_index(ll)], 1u);
+                atomicAdd(&hist[(idx >> 15) - blk0][286 + fl_dist_code(d0)], 1u);
+                // a match of at least `lazy` goes out at its own visit, a shorter one at the next
+                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
+                    bound[ck.first_block + (idx >> 15) + 1] = h0 + p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS) {
+        const uint32_t v = (&hist[0][0])[i];
+        if (v) atomicAdd(&hist_all[(uint64_t)(ck.first_block + blk0 + i / 320) * 320 + i % 320], v);
+    }
+}
+
+// ------------------------------------------------------------------ k_st_blocks
+// One wave per stream: the block table (deflate.zig:268-288): block k holds tokens
+// [32768 k, 32768 (k+1)); there is always a final block, possibly empty.
+__global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ chunks,
+                                                  const uint32_t* __restrict__ ntok,
+                                                  const uint32_t* __restrict__ bound,
+                                                  fl_block_plan* __restrict__ plans) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) {
+        for (uint32_t k = lane; k < ck.n_blocks; k += 64) plans[ck.first_block + k].valid = 0;
+        return;
+    }
+    const uint32_t N = ck.in_len, total = ntok[c];
+    const uint32_t nblk = total / FL_MAX_TOKENS + 1;
+    for (uint32_t k = lane; k < ck.n_blocks; k += 64) {
+        fl_block_plan* plan = &plans[ck.first_block + k];
+        if (k >= nblk) {
+            plan->valid = 0;
+            continue;
+        }
+        const bool last = k + 1 == nblk;
+        const uint32_t start = k ? bound[ck.first_block + k] : 0u;
+        const uint32_t end = last ? N : bound[ck.first_block + k + 1];
+        // window start when the block is flushed: inside the visit of `end` for a full block,
+        // after everything (including a slide that no data followed) for the final one
+        const uint32_t slides = last ? fl_total_slides(N) : fl_slides_before(end, N);
+        plan->valid = 1;
+        plan->tok_start = k * FL_MAX_TOKENS;
+        plan->tok_count = last ? total - k * FL_MAX_TOKENS : FL_MAX_TOKENS;
+        plan->in_start = start;
+        plan->in_len = end - start;
+        plan->final_block = last ? 1 : 0;
+        plan->no_input = start < slides * FL_SEG ? 1 : 0;  // SlidingWindow.zig:40, 119-123: fp went negative
+    }
+}

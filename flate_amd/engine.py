@@ -146,6 +146,9 @@ class Engine:
         """Token list the tokenizer kernels produced for `chunk` of the last level 4..9 call."""
         buf = np.zeros(65536, dtype=np.uint32)
         n = self._L.flate_hip_debug_tokens(self._h, int(chunk), buf.ctypes.data, buf.size)
+        if n > buf.size:  # whole-stream pass: the count comes back even when the buffer is short
+            buf = np.zeros(n, dtype=np.uint32)
+            n = self._L.flate_hip_debug_tokens(self._h, int(chunk), buf.ctypes.data, buf.size)
         if n < 0:
             raise FlateHipError("flate_hip_debug_tokens failed with %d" % n)
         return buf[:n].copy()

@@ -145,11 +145,13 @@ def test_q1_token_flush_input_slice():
             assert got == O.compress(d, 0, level)
 
 
-def test_chunk_too_large_is_reported_not_hidden():
+def test_long_chunk_takes_the_whole_stream_path():
+    # levels 4..9: inputs of more than 65535 bytes are no longer refused (tests/test_gpu_stream.py)
     eng = engine()
     outs, st = eng.compress_many([bytes(65536), b"ok"], 0, 6)
-    assert st[0] == 101 and outs[0] == b""
-    assert st[1] == 0 and outs[1] == O.compress(b"ok", 0, 6)
+    assert st == [0, 0]
+    assert outs[0] == O.compress(bytes(65536), 0, 6)
+    assert outs[1] == O.compress(b"ok", 0, 6)
 
 
 def test_output_too_small_status():

@@ -1,0 +1,197 @@
+"""GPU parity tests of the whole-stream path (levels 4..9, inputs longer than 65535 bytes):
+one deflate stream per input, byte-identical to the reference's sliding-window compressor
+(deflate.zig:304-321, SlidingWindow.zig:36-44, Lookup.zig:43-51) as restated by the oracle."""
+import zlib as pyzlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpu_util import engine
+
+pytestmark = pytest.mark.gpu
+
+WBITS = {0: -15, 1: 31, 2: 15}
+ZONE = 65536 - 262  # first buffer offset the tokenizer leaves for after the slide
+
+
+def _cases():
+    from flate_amd import synth
+    rng = np.random.default_rng(77)
+    text = synth.text(synth.SEED_TEXT + 5, 1 << 20).tobytes()
+    rnd = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()
+    noise4 = rng.integers(97, 101, 300000, dtype=np.uint8).tobytes()
+    blk = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    cases = {
+        "zeros65536": bytes(65536),
+        "zeros65537": bytes(65537),
+        "zeros98304": bytes(98304),
+        "zeros200k": bytes(200000),
+        "text65536": text[:65536],
+        "text_zone": text[:ZONE + 40],
+        "text98303": text[:98303],
+        "text98304": text[:98304],
+        "text98305": text[:98305],
+        "text131072": text[:131072],
+        "text300k": text[7:300007],
+        "text1m": text,
+        "rand100k": rnd[:100000],          # stored blocks; raw slice lost after slides
+        "rand65536": rnd[:65536],
+        "rand300k": rnd,
+        "noise4": noise4,                   # ~1 token per 2 bytes: block ends anywhere
+        "period32768": blk * 5,             # matches at distance exactly 32768 across slides
+        "period32767": (blk[:32767] * 6)[:190000],
+        "period32769": ((blk + b"x") * 6)[:190000],
+        "period16": (bytes(range(16)) * 20000)[:250000],
+        "mix": text[:70000] + rnd[:50000] + bytes(40000) + text[1000:90000] + noise4[:60000],
+        "sparse": bytes(b if (i % 97 == 0) else 0
+                        for i, b in enumerate(rng.integers(0, 256, 150000, dtype=np.uint8))),
+    }
+    # lengths around every place where the window fills up or the tokenizer stops for a slide
+    for k in (0, 1):
+        for d in (-1, 0, 1):
+            n = 65536 + 32768 * k + d
+            cases["text_fill%d%+d" % (k, d)] = text[333:333 + n]
+            n = ZONE + 32768 * k + d
+            cases["noise_zone%d%+d" % (k, d)] = noise4[:n] if n > 65535 else noise4[:65536 + k + d + 1]
+    return cases
+
+
+CASES = _cases()
+
+
+def test_stream_tokens_match_oracle():
+    eng = engine()
+    # debug_tokens sees the last pass only: keep to inputs that all take the whole-stream path
+    names = [n for n in CASES if len(CASES[n]) > 65535]
+    for level in (4, 6, 9):
+        outs, st = eng.compress_many([CASES[n] for n in names], O.RAW, level)
+        assert st == [0] * len(names)
+        for i, n in enumerate(names):
+            want = O.tokenize(CASES[n], level)
+            got = eng.debug_tokens(i)
+            assert len(got) == len(want), (n, level, len(got), len(want))
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (n, level, int(bad[0]), O.tok_decode(got[bad[0]]), O.tok_decode(want[bad[0]]))
+
+
+@pytest.mark.parametrize("level", [4, 5, 6, 7, 8, 9])
+def test_stream_bytes_match_oracle(level):
+    eng = engine()
+    names = [n for n in CASES if level in (6, 9) or not n.startswith(("text_fill", "noise_zone"))]
+    outs, st = eng.compress_many([CASES[n] for n in names], O.RAW, level)
+    assert st == [0] * len(names)
+    for n, got in zip(names, outs):
+        want = O.compress(CASES[n], O.RAW, level)
+        assert got == want, (n, level, len(got), len(want))
+        assert pyzlib.decompress(got, -15) == CASES[n]
+
+
+@pytest.mark.parametrize("container", [1, 2])
+def test_stream_containers(container):
+    eng = engine()
+    names = ["text300k", "rand100k", "zeros200k", "mix", "period32768"]
+    outs, st = eng.compress_many([CASES[n] for n in names], container, 6)
+    assert st == [0] * len(names)
+    for n, got in zip(names, outs):
+        assert got == O.compress(CASES[n], container, 6), n
+        assert pyzlib.decompress(got, WBITS[container]) == CASES[n]
+
+
+def test_mixed_batch_of_chunks_and_streams():
+    # short inputs (chunk path) and long ones (whole-stream path) interleaved in one call
+    eng = engine()
+    datas = [b"", CASES["text131072"], b"abc" * 100, CASES["text98304"][:65535], CASES["rand100k"], bytes(70000),
+             CASES["text300k"][:4000]]
+    for container in (0, 1):
+        outs, st = eng.compress_many(datas, container, 6)
+        assert st == [0] * len(datas)
+        for d, got in zip(datas, outs):
+            assert got == O.compress(d, container, 6), len(d)
+
+
+def test_stream_roundtrip_on_gpu_inflate():
+    eng = engine()
+    names = ["text1m", "mix", "rand300k"]
+    outs, st = eng.compress_many([CASES[n] for n in names], 1, 6)
+    assert st == [0] * len(names)
+    dec, dst, _ = eng.decompress_many(outs, 1, 0, [len(CASES[n]) for n in names])
+    assert dst == [0] * len(names)
+    for n, d in zip(names, dec):
+        assert d == CASES[n]
+
+
+def test_big_single_stream_roundtrip():
+    # 64 MiB in one stream: too long for the oracle in a unit test; inflate must give it back
+    # and the result must not depend on how many tiles one launch takes
+    import os
+    eng = engine()
+    from flate_amd import synth
+    data = synth.text(synth.SEED_TEXT + 9, 64 << 20).tobytes()
+    outs, st = eng.compress_many([data], 1, 6)
+    assert st == [0]
+    assert pyzlib.decompress(outs[0], 31) == data
+    head = data[:3 << 20]
+    a, st = eng.compress_many([head], 0, 6)
+    os.environ["FLATE_HIP_MAX_PASS_CHUNKS"] = "7"
+    try:
+        b, st2 = eng.compress_many([head], 0, 6)
+    finally:
+        del os.environ["FLATE_HIP_MAX_PASS_CHUNKS"]
+    assert st == [0] and st2 == [0] and a[0] == b[0]
+    assert a[0] == O.compress(head, 0, 6)
+
+
+def _fuzz_input(seed):
+    """Long inputs built from literal runs and copies whose distances cluster around the
+    window size, so that candidates sit on both sides of every slide boundary."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(65536, 400000))
+    out = bytearray(rng.integers(0, 256, int(rng.integers(300, 40000)), dtype=np.uint8).tobytes())
+    while len(out) < n:
+        kind = int(rng.integers(0, 6))
+        if kind == 0:
+            out += rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes()
+        elif kind == 1:
+            out += bytes(int(rng.integers(1, 2000)))
+        elif kind == 2:
+            out += rng.integers(97, 100, int(rng.integers(1, 3000)), dtype=np.uint8).tobytes()
+        else:
+            d = int(rng.choice([32768, 32767, 32769, 32768 - 262, 32506, 32505, 65536, 1, 4, 300,
+                                int(rng.integers(1, 33000)), 32768 - int(rng.integers(0, 600))]))
+            d = min(d, len(out))
+            ln = int(rng.integers(4, 700))
+            for _ in range(ln):
+                out.append(out[-d])
+    return bytes(out[:n])
+
+
+def test_stream_fuzz_against_oracle():
+    eng = engine()
+    datas = [_fuzz_input(1000 + i) for i in range(24)]
+    for level in (4, 6, 8, 9):
+        outs, st = eng.compress_many(datas, O.RAW, level)
+        assert st == [0] * len(datas)
+        for i, (d, got) in enumerate(zip(datas, outs)):
+            if got != O.compress(d, O.RAW, level):
+                want = O.tokenize(d, level)
+                toks = eng.debug_tokens(i)
+                m = min(len(toks), len(want))
+                bad = np.nonzero(toks[:m] != want[:m])[0]
+                first = int(bad[0]) if bad.size else m
+                raise AssertionError((i, level, len(d), "first differing token", first,
+                                      O.tok_decode(toks[first]) if first < len(toks) else None,
+                                      O.tok_decode(want[first]) if first < len(want) else None))
+
+
+def test_config1_vector_on_gpu():
+    # BASELINE.json configs[0]: gzip level 6 of a 4 MiB all-zero buffer (SURVEY.md 8c vector)
+    import hashlib
+    eng = engine()
+    z = bytes(4 << 20)
+    outs, st = eng.compress_many([z], O.GZIP, 6)
+    assert st == [0] and len(outs[0]) == 4098
+    assert hashlib.sha256(outs[0]).hexdigest() == "ead941ecab79abb0d46919b9bfcb699490a1d47de07ae41b3d97a0f4f3d10b06"
+    for level in (4, 9):
+        o, st = eng.compress_many([z], O.GZIP, level)
+        assert st == [0] and o[0][10:-8] == outs[0][10:-8]
