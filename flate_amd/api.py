@@ -14,9 +14,9 @@ behaviour, over the C ABI of libflate_hip.so.
 Errors are FlateError subclasses named after the reference's error set
 (inflate.zig:72-78, huffman_decoder.zig:35-40, container.zig:45-51, bit_reader.zig:29).
 
-Scope of this round: one-shot streams.  Levels 4..9 take inputs of at
-most 65535 bytes per stream (larger inputs raise ChunkTooLarge -- whole-stream mode
-is SURVEY.md 8f-2); huffman-only and store-only streams have no size limit.  The
+Scope of this round: one-shot streams of any length.  At levels 4..9 an
+input longer than 65535 bytes is compressed as ONE stream by the whole-stream path
+(SURVEY.md 8f-2), byte-identical to the reference's sliding-window compressor.  The
 history-preserving sync flush of Compressor.flush (deflate.zig:335-337) is not on
 the GPU path yet and raises NotImplementedError.
 """

@@ -656,8 +656,18 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     HIP_OK(h, hipStreamSynchronize(st));
     {
         ProfScope ps(h, K_INFLATE);
-        hipLaunchKernelGGL(k_inflate, dim3(n_chunks), dim3(64), 0, st, d_in, (const fl_chunk*)h->chunks.p, container,
-                           flags, h->crc, d_out, d_outlen, d_status, d_consumed);
+        // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
+        // many streams: the small ring keeps 13 per CU in flight
+        const char* e = getenv("FLATE_HIP_INFLATE_RING");
+        const bool large = e ? atoi(e) >= (int)FL_INF_RING_LARGE : n_chunks <= 3u * 256u;
+        if (large)
+            hipLaunchKernelGGL(k_inflate<FL_INF_RING_LARGE>, dim3(n_chunks), dim3(64), 0, st, d_in,
+                               (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
+                               d_consumed);
+        else
+            hipLaunchKernelGGL(k_inflate<FL_INF_RING_SMALL>, dim3(n_chunks), dim3(64), 0, st, d_in,
+                               (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
+                               d_consumed);
     }
     HIP_OK(h, hipGetLastError());
     if (memkind == FLATE_HIP_MEM_HOST) {

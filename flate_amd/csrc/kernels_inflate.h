@@ -26,18 +26,22 @@ struct fl_hdec {
 
 #define FL_INF_LIT_BITS 10
 #define FL_INF_DST_BITS 9
-#define FL_INF_RING 2048u                       // recent output kept in LDS (power of two)
-#define FL_INF_NEAR (FL_INF_RING - 258u - 2u)   // matches up to this distance are served from it
-#define FL_INF_FENCE 512u                       // output bytes between two "stores are visible" fences
+// Recent output kept in LDS (power of two); matches up to ring - 260 back are served from it.
+// Large batches run the small ring (13 streams per CU in flight); small batches, where the
+// latency of one stream is what counts, the large one: every match is then an LDS copy.
+#define FL_INF_RING_SMALL 2048u
+#define FL_INF_RING_LARGE 32768u
 
 struct fl_inflate_ws {
     fl_hdec lit, dst, cl;
-    uint16_t lit_lut[1u << FL_INF_LIT_BITS];  // symbol | code_bits << 9, 0 = not in the table
-    uint16_t dst_lut[1u << FL_INF_DST_BITS];
+    // symbol | code_bits << 9 | extra_bits << 13 | value << 17, 0 = not in the table.  value: the
+    // byte of a literal, base length of a length code (inflate.zig:123-131), base distance of a
+    // distance code (:133-140); extra_bits = 15 marks a symbol that is not a valid code
+    uint32_t lit_lut[1u << FL_INF_LIT_BITS];
+    uint32_t dst_lut[1u << FL_INF_DST_BITS];
     uint8_t lens[320];
     uint8_t cl_lens[20];
     uint16_t offs[18];
-    uint8_t ring[FL_INF_RING];
 };
 
 #define FL_INF_INRING 1024u  // compressed bytes staged in LDS (two 512-byte halves)
@@ -221,12 +225,29 @@ __device__ __forceinline__ int fl_hdec_find(const FL_LDS fl_hdec* d, uint32_t pe
 // Fill a 2^bits-entry table: entry[i] = the symbol whose code is a prefix of i (stream bit
 // order) when that code has at most `bits` bits, else 0.  Every lane decodes its share of the
 // indices with the same walk as fl_hdec_find, so table and walk cannot disagree.
-__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS fl_hdec* d, FL_LDS uint16_t* lut, int bits,
+template <bool DIST>
+__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS fl_hdec* d, FL_LDS uint32_t* lut, int bits,
                                                   uint32_t lane) {
     for (uint32_t i = lane; i < (1u << bits); i += 64) {
         uint32_t sym, cb;
-        uint16_t e = 0;
-        if (fl_hdec_find(d, i, bits, sym, cb) == 0) e = (uint16_t)(sym | (cb << 9));
+        uint32_t e = 0;
+        if (fl_hdec_find(d, i, bits, sym, cb) == 0) {
+            uint32_t eb, val;
+            if (DIST) {
+                eb = sym <= 29 ? fl_dist_extra_bits(sym) : 15u;
+                val = sym <= 29 ? fl_dist_base_scaled(sym) + 1 : 0u;
+            } else if (sym < 256) {
+                eb = 0;
+                val = sym;
+            } else if (sym == 256) {
+                eb = 0;
+                val = 0;
+            } else {
+                eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
+                val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
+            }
+            e = sym | (cb << 9) | (eb << 13) | (val << 17);
+        }
         lut[i] = e;
     }
     fl_wave_lds_sync();
@@ -234,65 +255,101 @@ __device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS fl_hdec* d, FL_LD
 
 __device__ __forceinline__ uint32_t fl_rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
 
+// Output of one stream.  Decoded bytes go to an LDS ring only; whenever 1 KiB has piled up the
+// wave stores the finished 512-byte lines to the caller's buffer with 8-byte stores (one byte
+// store per literal made the memory pipe, not the decoder, the limit).  Output byte k lives in
+// ring[(k + bias) & (RING - 1)], bias = low 3 bits of the output address, so that an 8-byte
+// aligned global address is an 8-byte aligned ring index.
 struct fl_inf_out {
     uint8_t* out;
-    FL_LDS uint8_t* ring;  // LDS copy of the last FL_INF_RING output bytes
+    FL_LDS uint8_t* ring;
     uint64_t cap;
     uint64_t wp;
-    uint64_t fenced;  // every output byte below this offset is visible to this wave's loads
+    uint64_t flushed;  // output bytes [0, flushed) have been stored to `out`
+    uint64_t fenced;   // ... and [0, fenced) are known to have landed: loads of this wave see them
+    uint32_t bias;
+    uint32_t rmask;     // ring size - 1
+    uint32_t near_max;  // ring size - 260
 };
 
-// Called when wp has moved: once per FL_INF_FENCE bytes wait for the outstanding stores, so that
-// far matches may read the output buffer without waiting.
-__device__ __forceinline__ void fl_inf_advance(fl_inf_out& o) {
-    if (o.wp - o.fenced >= 2 * FL_INF_FENCE) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        o.fenced = o.wp;
-    }
+// wave-uniform values the compiler cannot prove uniform (anything derived from an LDS load)
+__device__ __forceinline__ uint32_t fl_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t fl_uni64(uint64_t v) {
+    return (uint64_t)fl_uni((uint32_t)v) | ((uint64_t)fl_uni((uint32_t)(v >> 32)) << 32);
 }
 
-// CircularBuffer.zig:44-75, spread over the wave.  Near matches copy out of the LDS ring; far
-// ones read the output buffer, whose bytes that far back are already fenced.
+// store output bytes [flushed, upto) from the ring
+__device__ __forceinline__ void fl_inf_flush(fl_inf_out& o, uint64_t upto, uint32_t lane) {
+    const uint64_t a = o.flushed;
+    if (upto <= a) return;
+    fl_lds_order();
+    const uint64_t va = a + o.bias, vb = upto + o.bias;  // same low bits as the global addresses
+    const uint64_t w0 = (va + 7) >> 3, w1 = vb >> 3;     // whole 8-byte words [w0, w1)
+    uint8_t* base = o.out - o.bias;                      // 8-byte aligned
+    if (w0 <= w1) {
+        const uint32_t nh = (uint32_t)(w0 * 8 - va), nt = (uint32_t)(vb - w1 * 8);
+        if (lane < nh) base[va + lane] = o.ring[(uint32_t)(va + lane) & o.rmask];
+        for (uint64_t w = w0 + lane; w < w1; w += 64) {
+            const FL_LDS uint32_t* rw = (const FL_LDS uint32_t*)(o.ring + ((uint32_t)(w * 8) & o.rmask));
+            *(uint2*)(base + w * 8) = make_uint2(rw[0], rw[1]);
+        }
+        if (lane < nt) base[w1 * 8 + lane] = o.ring[(uint32_t)(w1 * 8 + lane) & o.rmask];
+    } else if (lane < (uint32_t)(vb - va)) {  // inside one word
+        base[va + lane] = o.ring[(uint32_t)(va + lane) & o.rmask];
+    }
+    fl_lds_order();
+    o.flushed = upto;
+}
+// Called when wp has moved: keeps less than FL_INF_PILE + 258 bytes unflushed (the ring holds
+// at least 2048 and near matches reach ring - 260 back: nothing live is ever overwritten).
+#define FL_INF_PILE 1024u
+__device__ __forceinline__ void fl_inf_advance(fl_inf_out& o, uint32_t lane) {
+    if ((uint32_t)(o.wp - o.flushed) >= FL_INF_PILE)
+        fl_inf_flush(o, ((o.wp + o.bias) & ~(uint64_t)511) - o.bias, lane);
+}
+
+// CircularBuffer.zig:44-75, spread over the wave.  Near matches copy inside the LDS ring; far
+// ones read the output buffer: that far back everything has been flushed (see fl_inf_advance),
+// the wave only has to wait for those stores if they are younger than the last wait.
 __device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint32_t distance, uint32_t lane) {
     if (o.wp < distance || length < 3 || length > 258 || distance < 1 || distance > 32768) return 11;
     if (o.wp + length > o.cap) return 100;
-    const uint32_t wp = (uint32_t)o.wp;
-    uint8_t* to = o.out + o.wp;
-    const bool near_ = distance <= FL_INF_NEAR;
-    if (!near_ && o.wp - distance + length > o.fenced) {  // the source is younger than the last fence
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        o.fenced = o.wp;
-    }
-    const uint8_t* from = o.out + o.wp - distance;  // far matches: distance > length, no overlap
-    for (uint32_t i0 = 0; i0 < length; i0 += 64) {  // one trip for lengths up to 64
-        const uint32_t i = i0 + lane;
-        uint32_t byte = 0;
-        if (i < length) {
-            if (near_) {
+    const uint32_t vp = (uint32_t)o.wp + o.bias;  // ring positions only need the low bits
+    if (distance <= o.near_max) {
+        for (uint32_t i0 = 0; i0 < length; i0 += 64) {  // one trip for lengths up to 64
+            const uint32_t i = i0 + lane;
+            uint32_t byte = 0;
+            if (i < length) {
                 // the source bytes repeat with period `distance` when the match overlaps itself
                 const uint32_t si = distance >= length ? i : (i % distance);
-                byte = o.ring[(wp - distance + si) & (FL_INF_RING - 1)];
-            } else {
-                byte = from[i];
+                byte = o.ring[(vp - distance + si) & o.rmask];
             }
+            fl_lds_order();
+            if (i < length) o.ring[(vp + i) & o.rmask] = (uint8_t)byte;
+            fl_lds_order();
         }
-        fl_lds_order();
-        if (i < length) {
-            to[i] = (uint8_t)byte;
-            o.ring[(wp + i) & (FL_INF_RING - 1)] = (uint8_t)byte;
+    } else {
+        if (o.wp - distance + length > o.fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            o.fenced = o.flushed;
+        }
+        const uint8_t* from = o.out + o.wp - distance;  // distance > length: no overlap
+        for (uint32_t i0 = 0; i0 < length; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            if (i < length) o.ring[(vp + i) & o.rmask] = from[i];
         }
         fl_lds_order();
     }
     o.wp += length;
-    fl_inf_advance(o);
+    fl_inf_advance(o, lane);
     return 0;
 }
 __device__ __forceinline__ int fl_inf_literal(fl_inf_out& o, uint32_t byte, uint32_t lane) {
     if (o.wp >= o.cap) return 100;
-    // every lane stores the same byte to the same address: one transaction, no exec juggling
-    o.out[o.wp] = (uint8_t)byte;
-    o.ring[(uint32_t)o.wp & (FL_INF_RING - 1)] = (uint8_t)byte;
+    // every lane stores the same byte to the same LDS address
+    o.ring[((uint32_t)o.wp + o.bias) & o.rmask] = (uint8_t)byte;
     o.wp++;
+    fl_inf_advance(o, lane);
     return 0;
 }
 
@@ -335,19 +392,20 @@ __device__ __forceinline__ int fl_inf_stored(fl_bitr& r, fl_inf_out& o, uint32_t
     if (o.wp + len > o.cap) return 100;
     const uint32_t src_off = (uint32_t)fl_br_consumed(r);  // byte aligned here
     const uint8_t* s = r.data + src_off;
+    fl_inf_flush(o, o.wp, lane);  // what the ring still holds goes out first
     for (uint32_t i = lane; i < len; i += 64) o.out[o.wp + i] = s[i];
     // the ring mirrors the last bytes of the output
     {
-        const uint32_t tail = len < FL_INF_RING ? len : FL_INF_RING;
+        const uint32_t tail = len < o.rmask + 1 ? len : o.rmask + 1;
         fl_lds_order();
         for (uint32_t i = lane; i < tail; i += 64) {
             const uint64_t off = o.wp + len - tail + i;
-            o.ring[(uint32_t)off & (FL_INF_RING - 1)] = s[len - tail + i];
+            o.ring[((uint32_t)off + o.bias) & o.rmask] = s[len - tail + i];
         }
         fl_lds_order();
     }
     o.wp += len;
-    fl_inf_advance(o);
+    o.flushed = o.wp;
     r.left -= (int64_t)len * 8;
     fl_br_seek(r, src_off + len);
     return 0;
@@ -461,8 +519,8 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
         fl_wave_lds_sync();
         FL_TRY(fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane));
         FL_TRY(fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane));
-        fl_hdec_build_lut(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
-        fl_hdec_build_lut(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+        fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
+        fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
         return 0;
     }
     rc = fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane);
@@ -480,53 +538,245 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
     if (rc) return crossed ? 14 : rc;
     rc = fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane);
     if (rc) return crossed ? 14 : rc;
-    fl_hdec_build_lut(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
-    fl_hdec_build_lut(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+    fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
+    fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
     return 0;
 }
 
-// inflate.zig:220-249.  Codes of up to 10 / 9 bits come out of the LDS tables built after the
-// block header; longer ones (and invalid ones) take the canonical walk, which also keeps the
-// reference's order of errors: a miss in the table of the decoder is InvalidCode before the
-// bits are consumed (huffman_decoder.zig:156-175), running out of input is EndOfStream at the
-// shift (bit_reader.zig:159-163).
-__device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
-    for (;;) {
-        FL_TRY(fl_br_fill(r, 15));
-        uint32_t sym, cb;
+// Restart the symbol-at-a-time reader at the stream position that `left` says we are at.
+__device__ __forceinline__ void fl_br_resync(fl_bitr& r) {
+    const uint64_t pos = (uint64_t)r.nbytes * 8 - (uint64_t)r.left;
+    r.buf = 0;
+    r.have = 0;
+    r.next_byte = (uint32_t)(pos >> 3);
+    const uint32_t k = (uint32_t)pos & 7;
+    if (k) {
+        fl_br_refill(r);
+        r.buf >>= k;
+        r.have -= k;
+    }
+}
+
+// One fast round of a dynamic block.  Every lane decodes, from the LDS tables, the literal /
+// length code and the distance code that would start at "current bit + lane"; the wave then
+// walks the chain of real symbol starts with scalar reads of those per-lane results, so the
+// serial part of a symbol is a handful of scalar instructions instead of two dependent LDS
+// round trips.  Anything out of the ordinary (a code longer than the tables, an invalid symbol
+// or match, the end of the input or of the output slot in sight) is left to the symbol-at-a-time
+// path, which owns the reference's error order.  Returns 0 = go on, 1 = end of block,
+// 2 = the next symbol needs the slow path, >= 7 a match error code.
+#ifdef FL_INF_COUNT
+#define FL_T0() const uint64_t t0_ = __builtin_readcyclecounter()
+#define FL_TACC(slot)                                                                          \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && lane == 0) g_fl_prof[slot] += __builtin_readcyclecounter() - t0_; \
+    } while (0)
+#else
+#define FL_T0()
+#define FL_TACC(slot)
+#endif
+#define FL_INF_FAST_MIN_BITS 160  // a round looks at 64 + 32 bits and consumes at most 63 + 48
+__device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+    FL_T0();
+    const uint64_t pos = (uint64_t)r.nbytes * 8 - (uint64_t)r.left;
+    const uint32_t byte0 = (uint32_t)(pos >> 3);
+    if (byte0 + 16 > r.in_loaded) fl_br_commit_half(r);
+    // the 32 stream bits that start at pos + lane
+    const uint32_t bp = ((byte0 & (FL_INF_INRING - 1)) << 3) + ((uint32_t)pos & 7) + lane;  // bit index in the ring
+    const uint32_t di = bp >> 5;
+    const uint32_t lo = r.inring[di & (FL_INF_INRING / 4 - 1)], hi = r.inring[(di + 1) & (FL_INF_INRING / 4 - 1)];
+    const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, bp & 31);
+    const uint32_t le = ws->lit_lut[w & ((1u << FL_INF_LIT_BITS) - 1)];
+    const uint32_t de = ws->dst_lut[w & ((1u << FL_INF_DST_BITS) - 1)];
+    // literal / length result of this start: kind << 30 | value << 8 | bits up to the distance code
+    uint32_t lp = 0;
+    {
+        const uint32_t sym = le & 511, cb = (le >> 9) & 15, eb = (le >> 13) & 15, val = le >> 17;
+        if (le != 0 && eb != 15) {
+            if (sym < 256)
+                lp = (1u << 30) | (val << 8) | cb;
+            else if (sym == 256)
+                lp = (2u << 30) | cb;
+            else
+                lp = (3u << 30) | ((val + ((w >> cb) & ((1u << eb) - 1))) << 8) | (cb + eb);
+        }
+    }
+    // distance result: 1 << 31 | distance << 8 | bits
+    uint32_t dp = 0;
+    {
+        const uint32_t cb = (de >> 9) & 15, eb = (de >> 13) & 15, val = de >> 17;
+        if (de != 0 && eb != 15) dp = (1u << 31) | ((val + ((w >> cb) & ((1u << eb) - 1))) << 8) | (cb + eb);
+    }
+    // The walk below is wave-uniform; the compiler cannot see that for anything that came out of
+    // LDS, so the state is pinned to scalar registers explicitly.
+    uint64_t wp = fl_uni64(o.wp);
+    const uint64_t cap = fl_uni64(o.cap);
+    uint32_t room = (uint32_t)(cap - wp < 0x40000000ull ? cap - wp : 0x40000000ull);  // output bytes left (saturated)
+    if (room < 64) return 2;  // a round emits at most 64 literals: no per-literal check below
+    uint32_t unfl = fl_uni((uint32_t)(wp - o.flushed));
+    const uint32_t bias = fl_uni(o.bias), rmask = fl_uni(o.rmask), near_max = fl_uni(o.near_max);
+    const uint32_t my_byte = (lp >> 8) & 0xff;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint64_t lits = 0;  // start lanes of the literals met since the last match: they go out together
+    uint32_t p = 0;
+    int rc = 0;
+#ifdef FL_INF_COUNT  // tuning build only (tools/inflate_probe.py): cycles of the table lookups vs the walk
+    if (__builtin_amdgcn_readlane((int)lp, 0) == 0x7fffffff) rc = 5;  // wait for lp
+    FL_TACC(44);
+    const uint64_t t1_ = __builtin_readcyclecounter();
+#endif
+    // the literals collected in `lits` are written by their own lanes, in chain order
+#define FL_INF_PUT_LITS()                                                              \
+    do {                                                                               \
+        if (lits) {                                                                    \
+            const uint32_t nl_ = (uint32_t)__popcll(lits);                             \
+            if ((lits >> lane) & 1)                                                    \
+                o.ring[((uint32_t)wp + bias + (uint32_t)__popcll(lits & lt_mask)) & rmask] = (uint8_t)my_byte; \
+            wp += nl_;                                                                 \
+            room -= nl_;                                                               \
+            unfl += nl_;                                                               \
+            lits = 0;                                                                  \
+        }                                                                              \
+    } while (0)
+    while (p < 64) {
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
+        const uint32_t kind = l >> 30;
+        if (kind == 1) {
+            lits |= 1ull << p;
+            p += l & 0xff;
+            continue;
+        }
+        if (kind == 3) {
+            const uint32_t p2 = p + (l & 0xff);
+            if (p2 >= 64) break;  // the distance code starts beyond this round's lanes
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dp, (int)p2);
+            const uint32_t length = (l >> 8) & 0x1ff, distance = (d >> 8) & 0xffff;
+            FL_INF_PUT_LITS();
+            if (d == 0 || (wp < 32768 && distance > (uint32_t)wp) || length > room) {
+                rc = 2;
+                break;
+            }
+            const uint32_t vp = (uint32_t)wp + bias;
+            if (distance <= near_max) {
+                for (uint32_t i0 = 0; i0 < length; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    uint32_t byte = 0;
+                    if (i < length) {
+                        const uint32_t si = distance >= length ? i : (i % distance);
+                        byte = o.ring[(vp - distance + si) & rmask];
+                    }
+                    fl_lds_order();
+                    if (i < length) o.ring[(vp + i) & rmask] = (uint8_t)byte;
+                    fl_lds_order();
+                }
+            } else {
+                if (wp - distance + length > fl_uni64(o.fenced)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    o.fenced = o.flushed;
+                }
+                const uint8_t* from = o.out + wp - distance;
+                for (uint32_t i0 = 0; i0 < length; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < length) o.ring[(vp + i) & rmask] = from[i];
+                }
+                fl_lds_order();
+            }
+            wp += length;
+            room -= length;
+            unfl += length;
+            p = p2 + (d & 0xff);
+            if (unfl >= FL_INF_PILE) {
+                o.wp = wp;
+                fl_inf_flush(o, ((wp + bias) & ~(uint64_t)511) - bias, lane);
+                unfl = (uint32_t)(wp - o.flushed);
+            }
+            if (room < 64) break;  // keep the guarantee for the literals of the rest of the round
+            continue;
+        }
+        if (kind == 2) {
+            p += l & 0xff;
+            rc = 1;
+        } else {
+            rc = 2;
+        }
+        break;
+    }
+    FL_INF_PUT_LITS();
+#undef FL_INF_PUT_LITS
+    fl_lds_order();
+#ifdef FL_INF_COUNT
+    if (blockIdx.x == 0 && lane == 0) g_fl_prof[45] += __builtin_readcyclecounter() - t1_;
+#endif
+    o.wp = wp;
+    if (unfl >= FL_INF_PILE) fl_inf_flush(o, ((wp + bias) & ~(uint64_t)511) - bias, lane);
+    r.left -= p;
+    return rc;
+}
+
+// one symbol, inflate.zig:220-249.  Codes of up to 10 / 9 bits come out of the LDS tables built
+// after the block header; longer ones (and invalid ones) take the canonical walk, which also
+// keeps the reference's order of errors: a miss in the table of the decoder is InvalidCode
+// before the bits are consumed (huffman_decoder.zig:156-175), running out of input is
+// EndOfStream at the shift (bit_reader.zig:159-163).  Returns -1 at the end of the block.
+__device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+    FL_TRY(fl_br_fill(r, 15));
+    uint32_t sym, cb;
+    {
+        const uint32_t pk = fl_br_peek(r, 15);
+        const uint32_t e = ws->lit_lut[pk & ((1u << FL_INF_LIT_BITS) - 1)];
+        if (e) {
+            sym = e & 0x1ff;
+            cb = (e >> 9) & 15;
+        } else {
+            FL_TRY(fl_hdec_find(&ws->lit, pk, 15, sym, cb));
+        }
+    }
+    FL_TRY(fl_br_shift(r, cb));
+    if (sym < 256) {
+        FL_TRY(fl_inf_literal(o, sym, lane));
+    } else if (sym == 256) {
+        return -1;
+    } else {
+        FL_TRY(fl_br_fill(r, 5 + 15 + 13));
+        uint32_t length, distance, dsym;
+        FL_TRY(fl_inf_length(r, sym - 257, length));
         {
             const uint32_t pk = fl_br_peek(r, 15);
-            const uint32_t e = ws->lit_lut[pk & ((1u << FL_INF_LIT_BITS) - 1)];
+            const uint32_t e = ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)];
             if (e) {
-                sym = e & 0x1ff;
-                cb = e >> 9;
+                dsym = e & 0x1ff;
+                cb = (e >> 9) & 15;
             } else {
-                FL_TRY(fl_hdec_find(&ws->lit, pk, 15, sym, cb));
+                FL_TRY(fl_hdec_find(&ws->dst, pk, 15, dsym, cb));
             }
         }
         FL_TRY(fl_br_shift(r, cb));
-        if (sym < 256) {
-            FL_TRY(fl_inf_literal(o, sym, lane));
-        } else if (sym == 256) {
-            return 0;
-        } else {
-            FL_TRY(fl_br_fill(r, 5 + 15 + 13));
-            uint32_t length, distance, dsym;
-            FL_TRY(fl_inf_length(r, sym - 257, length));
-            {
-                const uint32_t pk = fl_br_peek(r, 15);
-                const uint32_t e = ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)];
-                if (e) {
-                    dsym = e & 0x1ff;
-                    cb = e >> 9;
-                } else {
-                    FL_TRY(fl_hdec_find(&ws->dst, pk, 15, dsym, cb));
-                }
-            }
-            FL_TRY(fl_br_shift(r, cb));
-            FL_TRY(fl_inf_distance(r, dsym, distance));
-            FL_TRY(fl_inf_match(o, length, distance, lane));
+        FL_TRY(fl_inf_distance(r, dsym, distance));
+        FL_TRY(fl_inf_match(o, length, distance, lane));
+    }
+    return 0;
+}
+
+__device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+    for (;;) {
+        if (r.left >= FL_INF_FAST_MIN_BITS) {
+            int rc;
+            do {
+                rc = fl_inf_fast_round(r, ws, o, lane);
+#ifdef FL_INF_COUNT
+                if (blockIdx.x == 0 && lane == 0) { g_fl_prof[40]++; if (rc == 2) g_fl_prof[41]++; }
+#endif
+            } while (rc == 0 && r.left >= FL_INF_FAST_MIN_BITS);
+            fl_br_resync(r);
+            if (rc == 1) return 0;
+            if (rc > 2) return rc;
         }
+        const int rc = fl_inf_dynamic_symbol(r, ws, o, lane);
+#ifdef FL_INF_COUNT
+        if (blockIdx.x == 0 && lane == 0) g_fl_prof[42]++;
+#endif
+        if (rc < 0) return 0;
+        if (rc) return rc;
     }
 }
 
@@ -612,11 +862,13 @@ __device__ __forceinline__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n
 }
 
 // One wave per stream.
+template <uint32_t RING>
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
                                                 int container, int flags, fl_crc_consts cc,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                 int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
     __shared__ fl_inflate_ws ws_mem;
+    __shared__ alignas(8) uint8_t ring_mem[RING];
     __shared__ uint32_t crc_tab_mem[256];
     __shared__ uint32_t inring_mem[FL_INF_INRING / 4];
     FL_LDS fl_inflate_ws* ws = (FL_LDS fl_inflate_ws*)&ws_mem;
@@ -634,10 +886,14 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
     fl_br_seek(r, 0);
     fl_inf_out o;
     o.out = out + ck.out_off;
-    o.ring = ws->ring;
+    o.ring = (FL_LDS uint8_t*)ring_mem;
+    o.rmask = RING - 1;
+    o.near_max = RING - 260;
     o.cap = ck.out_cap;
     o.wp = 0;
+    o.flushed = 0;
     o.fenced = 0;
+    o.bias = (uint32_t)((uintptr_t)o.out & 7);
 
     int rc = fl_inf_header(r, container);
     while (rc == 0) {  // inflate.zig:251-280
@@ -658,6 +914,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
         if (bfinal) {
             fl_br_align(r);
             // container.zig:154-166
+            fl_inf_flush(o, o.wp, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             uint32_t v;
             if (container == 1) {
@@ -677,6 +934,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, 
             break;
         }
     }
+    fl_inf_flush(o, o.wp, lane);  // also after an error: what was decoded before it is delivered
     if (lane == 0) {
         out_len[c] = o.wp;
         status[c] = rc;

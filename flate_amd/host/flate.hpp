@@ -17,9 +17,9 @@
 // met by looping).  Writer: anything with  void write(const uint8_t* buf, size_t n).
 // Errors: flate_hip::Error carrying the reference's error name (inflate.zig:72-78 etc.).
 //
-// One-shot semantics run on the GPU.  Level 4..9 streams take at most 65535 input bytes
-// (ChunkTooLarge otherwise; whole-stream mode is the next row of SURVEY.md 8f); huffman-only and
-// store-only streams have no limit.  Compressor::flush (history-preserving sync flush,
+// One-shot semantics run on the GPU, for inputs of any length: at levels 4..9 an input longer than
+// 65535 bytes is compressed as one stream by the whole-stream path (same bytes as the reference's
+// sliding-window compressor).  Compressor::flush (history-preserving sync flush,
 // deflate.zig:335-337) is not on the GPU path and throws.  There is no CPU fallback.
 #pragma once
 #include <cstdint>

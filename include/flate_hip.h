@@ -56,7 +56,7 @@ enum {
     FLATE_HIP_E_INVALID_ARG = -2,
     FLATE_HIP_E_ALLOC = -3,       /* workspace allocation failed */
     FLATE_HIP_E_LAUNCH = -4,      /* a HIP call failed; see flate_hip_last_error */
-    FLATE_HIP_E_UNSUPPORTED = -5  /* e.g. a level 4..9 chunk longer than 65535 bytes */
+    FLATE_HIP_E_UNSUPPORTED = -5  /* reserved */
 };
 
 /* per-chunk status: the reference's error names, same numbering as the oracle */
@@ -77,7 +77,7 @@ enum {
     FLATE_HIP_ST_WRONG_STORED_BLOCK_NLEN = 13,
     FLATE_HIP_ST_INVALID_DYNAMIC_BLOCK_HEADER = 14,
     FLATE_HIP_ST_OUTPUT_TOO_SMALL = 100,
-    FLATE_HIP_ST_CHUNK_TOO_LARGE = 101 /* level 4..9 chunk > 65535 bytes (whole-stream mode: next round) */
+    FLATE_HIP_ST_CHUNK_TOO_LARGE = 101 /* reserved; not produced any more: long inputs take the whole-stream path */
 };
 
 /* decompress flags.  bit0: reference-strict dynamic block header (quirk Q6,
@@ -86,7 +86,10 @@ enum {
  * own encoder emits it).  Default 0: such a header is accepted when valid. */
 enum { FLATE_HIP_INFLATE_STRICT_Q6 = 1 };
 
-/* largest level-4..9 chunk this build compresses (no window slide inside a chunk) */
+/* Levels 4..9: an input of up to this many bytes never slides the reference's window and takes
+ * the batched chunk path (one workgroup per input); a longer one is compressed as ONE stream by
+ * the whole-stream path, byte-identical to Deflate.compress over the whole input
+ * (deflate.zig:304-321 with SlidingWindow.zig:36-44, Lookup.zig:43-51). */
 #define FLATE_HIP_MAX_LZ_CHUNK 65535u
 
 int flate_hip_create(int device, flate_hip_handle* h);

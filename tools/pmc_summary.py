@@ -8,6 +8,11 @@ import json
 import sys
 
 
+def kname(full):
+    k = full.split("(")[0]
+    return k[5:] if k.startswith("void ") else k   # template instances: "void k_x<...>"
+
+
 def main(d, out):
     res = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -15,7 +20,7 @@ def main(d, out):
         meta = {}
         n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = kname(r["Kernel_Name"])
             if not k.startswith("k_"):
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -29,7 +34,7 @@ def main(d, out):
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         dur = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = kname(r["Kernel_Name"])
             if k.startswith("k_"):
                 dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         for k, v in dur.items():
