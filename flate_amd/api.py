@@ -16,9 +16,11 @@ Errors are FlateError subclasses named after the reference's error set
 
 Scope of this round: one-shot streams of any length.  At levels 4..9 an
 input longer than 65535 bytes is compressed as ONE stream by the whole-stream path
-(SURVEY.md 8f-2), byte-identical to the reference's sliding-window compressor.  The
-history-preserving sync flush of Compressor.flush (deflate.zig:335-337) is not on
-the GPU path yet and raises NotImplementedError.
+(SURVEY.md 8f-2), byte-identical to the reference's sliding-window compressor.
+Compressor.flush (deflate.zig:335-337, levels 4..9) is a sync flush that keeps the LZ
+history: the object re-runs the stream so far with its flush points on the GPU and
+hands the writer only the new bytes (the output of a prefix of the calls is a prefix
+of the output).
 """
 import enum
 import io
@@ -94,6 +96,8 @@ class _Compressor:
         self._container, self._mode, self._wrt = container, int(mode), writer
         self._eng = engine or default_engine()
         self._buf = bytearray()
+        self._flushes = []   # stream positions at which flush() was called
+        self._emitted = 0    # bytes of the stream already handed to the writer
         self._done = False
 
     def write(self, data):  # deflate.zig:363-367
@@ -106,9 +110,19 @@ class _Compressor:
     def writer(self):  # deflate.zig:369-371
         return self
 
-    def flush(self):  # deflate.zig:335-337
-        raise NotImplementedError("sync flush keeps LZ history across calls; not on the GPU path in this round "
-                                  "(SURVEY.md 8f-1)")
+    def _run(self, finish):
+        if self._mode < 4:
+            raise NotImplementedError("sync flush of the huffman-only / store-only compressors "
+                                      "(deflate.zig:474-478) is not on the GPU path")
+        out, st = self._eng.compress_flush(bytes(self._buf), self._flushes, finish, self._container, self._mode)
+        raise_for_status(st)
+        # the stream so far is a prefix of the stream after more calls: hand over only what is new
+        self._wrt.write(out[self._emitted:])
+        self._emitted = len(out)
+
+    def flush(self):  # deflate.zig:335-337: pending tokens out, then an empty stored block; history stays
+        self._flushes.append(len(self._buf))
+        self._run(False)
 
     def set_writer(self, new_writer):  # deflate.zig:351-354
         self._wrt = new_writer
@@ -116,9 +130,12 @@ class _Compressor:
     def finish(self):  # deflate.zig:344-347
         if self._done:
             return
-        outs, st = self._eng.compress_many([bytes(self._buf)], self._container, self._mode)
-        raise_for_status(st[0])
-        self._wrt.write(outs[0])
+        if self._flushes:
+            self._run(True)
+        else:
+            outs, st = self._eng.compress_many([bytes(self._buf)], self._container, self._mode)
+            raise_for_status(st[0])
+            self._wrt.write(outs[0])
         self._done = True
 
 

@@ -57,12 +57,14 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
-    DevBuf tiles, segs, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
+    DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
     uint32_t dbg_first_chunk = 0;
     std::vector<uint64_t> dbg_pos_off;
+    std::vector<fl_chunk> dbg_chunks;   // whole-stream pass: chunk and piece tables of the last pass
+    std::vector<fl_piece> dbg_pieces;
     // profiling
     bool prof = false;
     struct Pending {
@@ -186,17 +188,100 @@ uint64_t stream_pass_byte_limit() {
     return 4096ull << 20;
 }
 
-// Levels 4..9, inputs longer than 65535 bytes: tokenizer kernels of one whole-stream pass
-// (kernels_stream.h).  Leaves tokens, histograms and the block table for the shared back end.
+// Sync-flush points of one stream (flate_hip_compress_flush); absent for ordinary batches.
+struct FlushSpec {
+    const uint64_t* pos;
+    uint32_t n;
+    bool finish;
+};
+
+// Host-built tables of one whole-stream pass (kernels_stream.h).
+struct StreamTables {
+    std::vector<fl_tile> tiles;
+    std::vector<fl_piece> pieces;
+    std::vector<fl_seg> segs;
+    std::vector<uint32_t> fpts;   // flush points of all chunks
+    std::vector<uint32_t> zones;  // per chunk: first position visited after slide j
+    uint64_t npos = 0;
+    bool any_flush = false;
+};
+
+// Adds chunk `i` (pass-local index) to the tables; fills the chunk's stream fields and n_blocks.
+void add_stream_chunk(StreamTables& t, fl_chunk& c, uint32_t i, uint32_t first_block, const FlushSpec* fs) {
+    const uint32_t N = c.in_len;
+    c.pos_off = t.npos;
+    t.npos += ((uint64_t)N + FL_SEG - 1) / FL_SEG * FL_SEG + FL_SEG;
+    // flush points
+    c.flush_off = (uint32_t)t.fpts.size();
+    c.n_flush = fs ? fs->n : 0;
+    for (uint32_t k = 0; k < c.n_flush; k++) t.fpts.push_back((uint32_t)fs->pos[k]);
+    if (c.n_flush) t.any_flush = true;
+    // slide j happens when the window is full for the j-th time; position p is visited after it
+    // iff p is within min_lookahead of the window end (SlidingWindow.zig:56-60) -- unless a flush
+    // that came before the window was full ran the tokenizer up to its own position first
+    c.zone_off = (uint32_t)t.zones.size();
+    c.n_slides = N >= 65536u ? (N - 65536u) / FL_SEG + 1 : 0;
+    for (uint32_t j = 1; j <= c.n_slides; j++) {
+        const uint32_t full = 65536u + FL_SEG * (j - 1);
+        uint32_t z = full - (FL_MAX_MATCH + 4);
+        for (uint32_t k = 0; k < c.n_flush; k++) {
+            const uint32_t f = t.fpts[c.flush_off + k];
+            if (f < full && f > z) z = f;
+        }
+        t.zones.push_back(z);
+    }
+    auto zone_of = [&](uint32_t j, uint32_t w0) -> uint32_t {  // window-relative, 65536 = no such slide
+        if (j > c.n_slides) return 65536u;
+        return t.zones[c.zone_off + j - 1] - w0;
+    };
+    t.tiles.push_back(fl_tile{i, 0u, 0u, zone_of(1, 0)});
+    for (uint32_t w0 = FL_SEG; w0 + FL_SEG < N; w0 += FL_SEG)
+        t.tiles.push_back(fl_tile{i, w0, FL_SEG, zone_of(w0 / FL_SEG + 1, w0)});
+    // pieces, their blocks and segments
+    c.piece0 = (uint32_t)t.pieces.size();
+    uint32_t nb = 0;
+    auto add_piece = [&](uint32_t start, uint32_t end, uint32_t flags) {
+        fl_piece pc{};
+        pc.chunk = i;
+        pc.start = start;
+        pc.end = end;
+        pc.first_block = first_block + nb;
+        pc.n_blocks = (end - start) / FL_SEG + 1 + ((flags & 2) ? 1 : 0);  // deflate.zig:227-230 (+ marker)
+        pc.seg0 = (uint32_t)t.segs.size();
+        pc.flags = flags;
+        const uint32_t pi = (uint32_t)t.pieces.size();
+        for (uint64_t h0 = start & ~(FL_SEG - 1); h0 < end; h0 += FL_SEG) t.segs.push_back(fl_seg{pi, (uint32_t)h0});
+        pc.n_seg = (uint32_t)t.segs.size() - pc.seg0;
+        nb += pc.n_blocks;
+        t.pieces.push_back(pc);
+    };
+    uint32_t prev = 0;
+    for (uint32_t k = 0; k < c.n_flush; k++) {
+        const uint32_t f = t.fpts[c.flush_off + k];
+        add_piece(prev, f, 2u);
+        prev = f;
+    }
+    if (!fs || fs->finish) add_piece(prev, N, 1u);
+    c.n_piece = (uint32_t)t.pieces.size() - c.piece0;
+    c.n_blocks = nb;
+}
+
+// Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
+// histograms and the block table for the shared back end.
 int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
-                         uint64_t npos, const std::vector<fl_tile>& tiles, const std::vector<fl_seg>& segs) {
+                         const StreamTables& t) {
     hipStream_t st = h->stream;
     int rc;
-    const uint32_t nseg = (uint32_t)segs.size();
+    const uint32_t nseg = (uint32_t)t.segs.size(), npc = (uint32_t)t.pieces.size();
+    const uint64_t npos = t.npos;
     const size_t tile_limit = pass_chunk_limit();
-    const size_t tiles_per_launch = std::min(tiles.size(), tile_limit);
-    if ((rc = ensure(h, h->tiles, sizeof(fl_tile) * tiles.size()))) return rc;
-    if ((rc = ensure(h, h->segs, sizeof(fl_seg) * segs.size()))) return rc;
+    const size_t tiles_per_launch = std::min(t.tiles.size(), tile_limit);
+    if ((rc = ensure(h, h->tiles, sizeof(fl_tile) * t.tiles.size()))) return rc;
+    if ((rc = ensure(h, h->segs, sizeof(fl_seg) * (t.segs.size() + 1)))) return rc;
+    if ((rc = ensure(h, h->pieces, sizeof(fl_piece) * npc))) return rc;
+    if ((rc = ensure(h, h->fpts, sizeof(uint32_t) * (t.fpts.size() + 1)))) return rc;
+    if ((rc = ensure(h, h->zones, sizeof(uint32_t) * (t.zones.size() + 1)))) return rc;
+    if ((rc = ensure(h, h->nsorted, sizeof(uint32_t) * tiles_per_launch))) return rc;
     if ((rc = ensure(h, h->S, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(h, h->NC, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->rec, npos * 2 * sizeof(uint32_t) + 64))) return rc;
@@ -204,54 +289,68 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     if ((rc = ensure(h, h->tokens, npos * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->jmp, npos * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(h, h->marks, npos / 8))) return rc;
-    if ((rc = ensure(h, h->exitmap, (size_t)nseg * FL_SEG_ENTRIES * sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(h, h->entry, sizeof(uint32_t) * nseg))) return rc;
-    if ((rc = ensure(h, h->segtok, sizeof(uint32_t) * nseg))) return rc;
-    if ((rc = ensure(h, h->tokbase, sizeof(uint32_t) * nseg))) return rc;
+    if ((rc = ensure(h, h->exitmap, ((size_t)nseg + 1) * FL_SEG_ENTRIES * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(h, h->entry, sizeof(uint32_t) * (nseg + 1)))) return rc;
+    if ((rc = ensure(h, h->segtok, sizeof(uint32_t) * (nseg + 1)))) return rc;
+    if ((rc = ensure(h, h->tokbase, sizeof(uint32_t) * (nseg + 1)))) return rc;
     if ((rc = ensure(h, h->bound, sizeof(uint32_t) * nb))) return rc;
-    if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
-    HIP_OK(h, hipMemcpyAsync(h->tiles.p, tiles.data(), sizeof(fl_tile) * tiles.size(), hipMemcpyHostToDevice, st));
-    HIP_OK(h, hipMemcpyAsync(h->segs.p, segs.data(), sizeof(fl_seg) * segs.size(), hipMemcpyHostToDevice, st));
+    if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * npc))) return rc;
+    HIP_OK(h, hipMemcpyAsync(h->tiles.p, t.tiles.data(), sizeof(fl_tile) * t.tiles.size(), hipMemcpyHostToDevice, st));
+    if (nseg) HIP_OK(h, hipMemcpyAsync(h->segs.p, t.segs.data(), sizeof(fl_seg) * nseg, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(h->pieces.p, t.pieces.data(), sizeof(fl_piece) * npc, hipMemcpyHostToDevice, st));
+    if (!t.fpts.empty())
+        HIP_OK(h, hipMemcpyAsync(h->fpts.p, t.fpts.data(), sizeof(uint32_t) * t.fpts.size(), hipMemcpyHostToDevice, st));
+    if (!t.zones.empty())
+        HIP_OK(h, hipMemcpyAsync(h->zones.p, t.zones.data(), sizeof(uint32_t) * t.zones.size(), hipMemcpyHostToDevice, st));
     HIP_OK(h, hipMemsetAsync(h->hist.p, 0, sizeof(uint32_t) * 320 * (size_t)nb, st));
+    HIP_OK(h, hipMemsetAsync(h->marks.p, 0, npos / 8, st));
+    // positions a flush keeps out of the hash table get no record from the match finder
+    if (t.any_flush) HIP_OK(h, hipMemsetAsync(h->rec.p, 0, npos * 2 * sizeof(uint32_t), st));
     HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
 
     const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
     const fl_seg* dsg = (const fl_seg*)h->segs.p;
-    for (size_t t0 = 0; t0 < tiles.size(); t0 += tiles_per_launch) {
-        const uint32_t nt = (uint32_t)std::min(tiles_per_launch, tiles.size() - t0);
+    const fl_piece* dpc = (const fl_piece*)h->pieces.p;
+    const uint32_t* dfp = (const uint32_t*)h->fpts.p;
+    for (size_t t0 = 0; t0 < t.tiles.size(); t0 += tiles_per_launch) {
+        const uint32_t nt = (uint32_t)std::min(tiles_per_launch, t.tiles.size() - t0);
         const fl_tile* dti = (const fl_tile*)h->tiles.p + t0;
         {
             ProfScope ps(h, K_LZ_SORT);
-            hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti,
-                               (uint16_t*)h->S.p);
+            hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti, dfp,
+                               (uint32_t*)h->nsorted.p, (uint16_t*)h->S.p);
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, prm,
-                               (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+            hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
+                               (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                               (uint32_t*)h->rec.p);
         }
     }
-    {
+    if (nseg) {
         ProfScope ps(h, K_ST_PARSE);
-        hipLaunchKernelGGL(k_st_parse1, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dsg, prm,
+        hipLaunchKernelGGL(k_st_parse1, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg, prm,
                            (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint16_t*)h->jmp.p,
                            (uint16_t*)h->exitmap.p);
-        hipLaunchKernelGGL(k_st_stitch, dim3((nc + 63) / 64), dim3(64), 0, st, dch, nc,
+        hipLaunchKernelGGL(k_st_stitch, dim3((npc + 63) / 64), dim3(64), 0, st, dpc, npc, dsg,
                            (const uint16_t*)h->exitmap.p, (uint32_t*)h->entry.p);
-        hipLaunchKernelGGL(k_st_parse2, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dsg,
+        hipLaunchKernelGGL(k_st_parse2, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg,
                            (const uint32_t*)h->desc.p, (const uint16_t*)h->jmp.p, (const uint32_t*)h->entry.p,
                            (uint32_t*)h->marks.p, (uint32_t*)h->segtok.p);
     }
     {
         ProfScope ps(h, K_ST_EMIT);
-        hipLaunchKernelGGL(k_st_scan, dim3(nc), dim3(64), 0, st, dch, (const uint32_t*)h->segtok.p,
+        hipLaunchKernelGGL(k_st_scan, dim3(npc), dim3(64), 0, st, dpc, (const uint32_t*)h->segtok.p,
                            (uint32_t*)h->tokbase.p, (uint32_t*)h->ntok.p);
-        hipLaunchKernelGGL(k_st_emit, dim3(nseg), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, dsg, prm,
-                           (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (const uint32_t*)h->tokbase.p,
-                           (uint32_t*)h->tokens.p, (uint32_t*)h->hist.p, (uint32_t*)h->bound.p);
-        hipLaunchKernelGGL(k_st_blocks, dim3(nc), dim3(64), 0, st, dch, (const uint32_t*)h->ntok.p,
-                           (const uint32_t*)h->bound.p, (fl_block_plan*)h->plans.p);
+        if (nseg)
+            hipLaunchKernelGGL(k_st_emit, dim3(nseg), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, dpc, dsg, prm,
+                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p,
+                               (const uint32_t*)h->tokbase.p, (uint32_t*)h->tokens.p, (uint32_t*)h->hist.p,
+                               (uint32_t*)h->bound.p);
+        hipLaunchKernelGGL(k_st_blocks, dim3(npc), dim3(64), 0, st, dch, dpc, (const uint32_t*)h->ntok.p,
+                           (const uint32_t*)h->bound.p, (const uint32_t*)h->zones.p, (fl_block_plan*)h->plans.p);
     }
+    (void)nc;
     return FLATE_HIP_OK;
 }
 
@@ -324,8 +423,8 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->jmp, &h->exitmap, &h->entry, &h->segtok, &h->tokbase,
-                      &h->bound, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
+                      &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
@@ -382,9 +481,12 @@ int flate_hip_profile_read(flate_hip_handle h, const char** names, double* total
     return n;
 }
 
-int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
-                             int container, int mode, uint8_t* out, const uint64_t* out_off, uint64_t* out_len,
-                             int32_t* status, int memkind) {
+}  // extern "C"
+
+namespace {
+int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks, int container,
+                  int mode, uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int memkind,
+                  const FlushSpec* fs) {
     if (!h || !in_off || !out_off || !out_len || !status) return FLATE_HIP_E_INVALID_ARG;
     if (container < 0 || container > 2) return FLATE_HIP_E_INVALID_ARG;
     fl_params prm{};
@@ -442,7 +544,9 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         if (len > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
         c.in_len = (uint32_t)len;
         c.pos_off = 0;
-        c.seg0 = c.n_seg = 0;
+        c.piece0 = c.n_piece = c.flush_off = c.n_flush = c.zone_off = c.n_slides = 0;
+        c.unfinished = (fs && !fs->finish) ? 1u : 0u;
+        c.pad_ = 0;
     }
     HIP_OK(h, hipMemcpyAsync(d_outlen, init_len.data(), sizeof(uint64_t) * n_chunks, hipMemcpyHostToDevice, st));
     HIP_OK(h, hipMemcpyAsync(d_status, init_status.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
@@ -459,33 +563,23 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
     const uint64_t stream_pass_bytes = stream_pass_byte_limit();
     uint32_t nc = 0;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
-        const bool stream = mode >= 4 && chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK;
+        const bool stream = mode >= 4 && (fs || chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK);
         uint64_t pass_bytes = 0;
         for (nc = 0; c0 + nc < n_chunks; nc++) {
             const fl_chunk& c = chunks[c0 + nc];
-            if ((mode >= 4 && c.in_len > FLATE_HIP_MAX_LZ_CHUNK) != stream) break;
+            if ((mode >= 4 && (fs || c.in_len > FLATE_HIP_MAX_LZ_CHUNK)) != stream) break;
             if (stream ? (nc > 0 && pass_bytes + c.in_len > stream_pass_bytes) : nc >= pass_limit) break;
             pass_bytes += c.in_len;
         }
         // block table of this pass
         std::vector<uint32_t> blk_chunk;
-        std::vector<fl_tile> tiles;
-        std::vector<fl_seg> segs;
+        StreamTables tabs;
         uint32_t nb = 0;
-        uint64_t npos = 0;
         for (uint32_t i = 0; i < nc; i++) {
             fl_chunk& c = chunks[c0 + i];
             c.first_block = nb;
             if (stream) {
-                // deflate.zig:227-230: a block per 32768 tokens (<= one token per byte) + the final one
-                c.n_blocks = c.in_len / FL_SEG + 2;
-                c.pos_off = npos;
-                c.seg0 = (uint32_t)segs.size();
-                c.n_seg = (c.in_len + FL_SEG - 1) / FL_SEG;
-                npos += (uint64_t)c.n_seg * FL_SEG;
-                for (uint32_t sg = 0; sg < c.n_seg; sg++) segs.push_back(fl_seg{i, sg});
-                tiles.push_back(fl_tile{i, 0u, 0u, 0u});
-                for (uint32_t w0 = FL_SEG; w0 + FL_SEG < c.in_len; w0 += FL_SEG) tiles.push_back(fl_tile{i, w0, FL_SEG, 0u});
+                add_stream_chunk(tabs, c, i, nb, fs);
             } else {
                 c.n_blocks = mode >= 4 ? 2u : (uint32_t)(c.in_len / FL_BLOCK_BYTES + 1);  // deflate.zig:498-511, 480-484
                 c.pos_off = (uint64_t)i * FL_CHUNK_STRIDE;
@@ -517,11 +611,12 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, prm, h->crc, dcks);
         }
         if (stream) {
-            if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, npos, tiles, segs))) return rc;
+            if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, tabs))) return rc;
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;
-            h->dbg_pos_off.resize(nc);
-            for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = chunks[c0 + i].pos_off;
+            h->dbg_pos_off.clear();
+            h->dbg_chunks.assign(chunks.begin() + c0, chunks.begin() + c0 + nc);
+            h->dbg_pieces = tabs.pieces;
         } else if (mode >= 4) {
             const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
             if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
@@ -534,13 +629,14 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             {
                 ProfScope ps(h, K_LZ_SORT);
                 hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (uint16_t*)h->S.p);
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                   (uint16_t*)h->S.p);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
                 hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p);
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);
@@ -556,6 +652,7 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;
             h->dbg_pos_off.resize(nc);
+            h->dbg_pieces.clear();
             for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = (uint64_t)i * FL_CHUNK_STRIDE;
         } else if (mode == 1) {
             ProfScope ps(h, K_BYTE_HIST);
@@ -596,6 +693,35 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
         HIP_OK(h, hipStreamSynchronize(st));
     }
     return FLATE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
+                             int container, int mode, uint8_t* out, const uint64_t* out_off, uint64_t* out_len,
+                             int32_t* status, int memkind) {
+    return compress_impl(h, in, in_off, n_chunks, container, mode, out, out_off, out_len, status, memkind, nullptr);
+}
+
+int flate_hip_compress_flush(flate_hip_handle h, const uint8_t* in, uint64_t n, const uint64_t* flush_pos,
+                             uint32_t n_flush, int finish, int container, int mode, uint8_t* out, uint64_t out_cap,
+                             uint64_t* out_len, int32_t* status, int memkind) {
+    if (!h || !out_len || !status || (n_flush && !flush_pos)) return FLATE_HIP_E_INVALID_ARG;
+    if (mode < 4 || mode > 9) return FLATE_HIP_E_UNSUPPORTED;
+    if (memkind != FLATE_HIP_MEM_HOST) return FLATE_HIP_E_UNSUPPORTED;
+    if (n > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+    uint64_t prev = 0;
+    for (uint32_t k = 0; k < n_flush; k++) {
+        if (flush_pos[k] < prev || flush_pos[k] > n) return FLATE_HIP_E_INVALID_ARG;
+        prev = flush_pos[k];
+    }
+    // without finish() the stream ends with the marker of the last flush: nothing may follow it
+    if (!finish && (n_flush == 0 || flush_pos[n_flush - 1] != n)) return FLATE_HIP_E_INVALID_ARG;
+    const uint64_t in_off[2] = {0, n}, out_off[2] = {0, out_cap};
+    const FlushSpec fs{flush_pos, n_flush, finish != 0};
+    return compress_impl(h, in, in_off, 1, container, mode, out, out_off, out_len, status, memkind, &fs);
 }
 
 int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
@@ -716,8 +842,25 @@ int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tok
     if (chunk < h->dbg_first_chunk || chunk >= h->dbg_first_chunk + h->dbg_pass_chunks) return FLATE_HIP_E_INVALID_ARG;
     if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
     const uint32_t local = chunk - h->dbg_first_chunk;
-    uint32_t n = 0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return FLATE_HIP_E_LAUNCH;
+    if (!h->dbg_pieces.empty()) {
+        // whole-stream pass: the token lists of the chunk's pieces, one after the other
+        const fl_chunk& c = h->dbg_chunks[local];
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < c.n_piece; i++) {
+            const fl_piece& pc = h->dbg_pieces[c.piece0 + i];
+            uint32_t m = 0;
+            if (hipMemcpy(&m, (uint32_t*)h->ntok.p + c.piece0 + i, sizeof m, hipMemcpyDeviceToHost) != hipSuccess)
+                return FLATE_HIP_E_LAUNCH;
+            if (total + m <= cap && m &&
+                hipMemcpy(tokens + total, (uint32_t*)h->tokens.p + c.pos_off + pc.start, (size_t)m * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost) != hipSuccess)
+                return FLATE_HIP_E_LAUNCH;
+            total += m;
+        }
+        return (int64_t)total;
+    }
+    uint32_t n = 0;
     if (hipMemcpy(&n, (uint32_t*)h->ntok.p + local, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
         return FLATE_HIP_E_LAUNCH;
     const uint64_t k = std::min<uint64_t>(n, cap);

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         }
     } else {
         // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel
-        if (!plan->valid) return;
+        if (!plan->valid || plan->no_input == 2) return;  // 2: a sync-flush marker, already a stored block
         for (uint32_t i = lane; i < FL_NUM_LIT; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         if (lane < FL_NUM_DIST) ws.dist_freq[lane] = (uint16_t)hist[(uint64_t)b * 320 + 286 + lane];
         fl_wave_lds_sync();
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
     const uint32_t lane = threadIdx.x;
     if (ck.skip) return;  // host already wrote status / out_len
     const uint32_t hdr_bytes = prm.container == 1 ? 10u : (prm.container == 2 ? 2u : 0u);
-    const uint32_t ftr_bytes = prm.container == 1 ? 8u : (prm.container == 2 ? 4u : 0u);
+    const uint32_t ftr_bytes = ck.unfinished ? 0u : (prm.container == 1 ? 8u : (prm.container == 2 ? 4u : 0u));
     const uint64_t base = (ck.out_off + hdr_bytes) * 8;
 
     fl_offmap run;  // composition of all blocks before the current batch
@@ -349,13 +349,13 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
                 const uint8_t h[10] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0x03};
                 for (int i = 0; i < 10; i++) o[i] = h[i];
                 uint8_t* f = out + body_end;  // container.zig:92-96
-                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks >> (8 * i));
-                for (int i = 0; i < 4; i++) f[4 + i] = (uint8_t)(ck.in_len >> (8 * i));
+                for (int i = 0; i < 4 && ftr_bytes; i++) f[i] = (uint8_t)(cks >> (8 * i));
+                for (int i = 0; i < 4 && ftr_bytes; i++) f[4 + i] = (uint8_t)(ck.in_len >> (8 * i));
             } else if (prm.container == 2) {  // container.zig:78, 104
                 o[0] = 0x78;
                 o[1] = 0x9c;
                 uint8_t* f = out + body_end;
-                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks >> (8 * (3 - i)));
+                for (int i = 0; i < 4 && ftr_bytes; i++) f[i] = (uint8_t)(cks >> (8 * (3 - i)));
             }
         }
     }

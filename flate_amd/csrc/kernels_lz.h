@@ -66,6 +66,22 @@ __device__ __forceinline__ void fl_wave_excl_scan_lds(uint32_t* cnt, uint32_t n,
     }
 }
 
+// smallest sync-flush point > pos, else n (fp ascending).  A flush at F ends the lookahead of
+// everything before it: matches stop at F and positions F-3 .. F-1 never enter the hash table
+// (deflate.zig:196-203 runs the tokenizer dry, Lookup.zig:23-27 needs 4 bytes).
+__device__ __forceinline__ uint32_t fl_next_flush(const uint32_t* __restrict__ fp, uint32_t n_flush, uint32_t pos,
+                                                  uint32_t n) {
+    uint32_t lo = 0, hi = n_flush;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (fp[mid] > pos)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo < n_flush ? fp[lo] : n;
+}
+
 // ------------------------------------------------------------------ k_lz_sort
 // One workgroup (16 waves) per chunk.  Output: S[c][0..M) = the positions 0..M-1
 // (M = in_len - 3: those with 4 bytes left, Lookup.zig:24) sorted by (hash, position).
@@ -141,6 +157,8 @@ template <bool STREAM>
 __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
                                                               const fl_tile* __restrict__ tiles,
+                                                              const uint32_t* __restrict__ fpts,
+                                                              uint32_t* __restrict__ n_sorted,
                                                               uint16_t* __restrict__ S) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
@@ -152,11 +170,21 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = ck.in_len - w0;
-    const uint32_t M = min(N >= 4 ? N - 3 : 0u, 65536u);
+    const uint32_t M = min(N >= 4 ? N - 3 : 0u, 65536u);  // positions with 4 bytes left in the stream
     const uint8_t* src = in + ck.in_off + w0;
     uint16_t* So = S + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t slice0 = wave * FL_SORT_SLICE;
+    // sync-flush points inside the window take the 3 positions before them out of the table
+    const uint32_t* fp = STREAM ? fpts + ck.flush_off : nullptr;
+    const bool has_fl = STREAM && ck.n_flush && fl_next_flush(fp, ck.n_flush, w0, ck.in_len) <= w0 + M + 2;
+    auto hashed = [&](uint32_t p) -> bool {
+        if (p >= M) return false;
+        if (!STREAM || !has_fl) return true;
+        return fl_next_flush(fp, ck.n_flush, w0 + p, ck.in_len) - (w0 + p) >= 4;
+    };
+    __shared__ uint32_t n_hashed;
+    if (tid == 0) n_hashed = 0;
 
     fl_prof_mark(0);
     for (uint32_t i = tid; i < FL_SORT_WAVES * 256; i += FL_SORT_THREADS) (&cnt1[0][0])[i] = 0;
@@ -170,11 +198,21 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t p = slice0 + (r + u) * 64 + lane;
             w[u] = p < M ? fl_load_u32_unaligned(src + p) : 0;
         }
+        uint32_t nv = 0;
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            if (slice0 + (r + u) * 64 + lane < M) atomicAdd(&cnt1[wave][fl_hash_le(w[u]) & 255], 1u);
+            if (hashed(slice0 + (r + u) * 64 + lane)) {
+                atomicAdd(&cnt1[wave][fl_hash_le(w[u]) & 255], 1u);
+                nv++;
+            }
+        if (STREAM) {
+            nv = fl_wave_sum(nv);
+            if (lane == 0 && nv) atomicAdd(&n_hashed, nv);
+        }
     }
     __syncthreads();
+    const uint32_t Ms = STREAM ? n_hashed : M;  // entries of the sorted array
+    if (STREAM && tid == 0) n_sorted[c] = Ms;
     fl_prof_mark(1);
     fl_scan_counters<256, 4>(cnt1, wsum, tid);
     fl_prof_mark(2);
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = slice0 + (r + u) * 64 + lane;
-            const bool valid = p < M;
+            const bool valid = hashed(p);
             const uint32_t h = fl_hash_le(w[u]);
             const uint32_t d = h & 255;
             const uint64_t peers = fl_match_any<8>(d, __ballot(valid));
@@ -221,8 +259,8 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const uint32_t e = slice0 + u * 64 + lane;
-        ppn[u] = e < M ? tmp[e] : 0;
-        a0n[u] = e < M ? fl_gather_u32(src, ppn[u], N) : 0;
+        ppn[u] = e < Ms ? tmp[e] : 0;
+        a0n[u] = e < Ms ? fl_gather_u32(src, ppn[u], N) : 0;
     }
     for (uint32_t r = 0; r < FL_SORT_SLICE / 64; r += 4) {
         uint32_t pp[4], a0[4];
@@ -234,14 +272,14 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // next group's gathers fly while this one is ranked
             const uint32_t e = slice0 + (r + 4 + u) * 64 + lane;
-            const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < M;
+            const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < Ms;
             ppn[u] = okn ? tmp[e] : 0;
             a0n[u] = okn ? fl_gather_u32(src, ppn[u], N) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t e = slice0 + (r + u) * 64 + lane;
-            const bool valid = e < M;
+            const bool valid = e < Ms;
             const uint32_t d = fl_hash_le(a0[u]) >> 8;
             const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
@@ -324,7 +362,9 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 template <bool STREAM>
 __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks,
-                                                                  const fl_tile* __restrict__ tiles, fl_params prm,
+                                                                  const fl_tile* __restrict__ tiles,
+                                                                  const uint32_t* __restrict__ fpts,
+                                                                  const uint32_t* __restrict__ n_sorted, fl_params prm,
                                                                   const uint16_t* __restrict__ S,
                                                                   uint32_t* __restrict__ NQ,
                                                                   uint32_t* __restrict__ rec_all) {
@@ -339,8 +379,12 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     const fl_chunk ck = chunks[STREAM ? tiles[c].chunk : c];
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t zone = STREAM ? tiles[c].zone : 65536u;
     const uint32_t N = ck.in_len - w0;
-    const uint32_t M = min(N >= 4 ? N - 3 : 0u, 65536u);
+    const uint32_t Mpos = min(N >= 4 ? N - 3 : 0u, 65536u);  // positions with 4 bytes left in the stream
+    const uint32_t M = STREAM ? n_sorted[c] : Mpos;            // entries of the sorted array
+    const uint32_t* fp = STREAM ? fpts + ck.flush_off : nullptr;
+    const bool has_fl = STREAM && ck.n_flush && fl_next_flush(fp, ck.n_flush, w0, ck.in_len) <= w0 + Mpos + 2;
     const uint8_t* src = in + ck.in_off + w0;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* NQc = NQ + (uint64_t)c * FL_CHUNK_STRIDE;
@@ -353,7 +397,8 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     for (uint32_t i = tid; i < WIN_DW; i += FL_MATCH_THREADS)
         win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
     // positions without a hash entry never match (Lookup.zig:24)
-    for (uint32_t p = M + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
+    // (with flush points in the stream the host has cleared all records beforehand)
+    for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
     __syncthreads();
     fl_prof_mark(9);
 
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248),
         // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
         uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
-        if (STREAM && p >= FL_ZONE_START && N >= 65536u) lov = max(lov, FL_MAX_DIST + 1u);
+        if (STREAM && p >= zone) lov = max(lov, FL_MAX_DIST + 1u);
         if (n == 0) lov = 0x7fffffffu;
         // positions of the first tile's entries (slots lane and lane + 64 < FL_TILE), fetched a batch ahead
         uint32_t tq0 = nx_tq0, tq1 = nx_tq1;
@@ -465,7 +510,8 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         }
         uint32_t p0, p1;
         fl_lds_load8(win32, p, p0, p1);
-        const uint32_t maxlen = min(N - p, FL_MAX_MATCH);
+        uint32_t maxlen = min(N - p, FL_MAX_MATCH);
+        if (STREAM && has_fl) maxlen = min(maxlen, fl_next_flush(fp, ck.n_flush, w0 + p, ck.in_len) - (w0 + p));
         const uint32_t cp = 0xffffu - p;  // key low half = 65535 - (p - q) = q + cp
         uint32_t key = 0, qkey = 0;
         // A candidate can beat the lane's best only if its first best+1 bytes agree with p's.

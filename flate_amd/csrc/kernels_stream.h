@@ -1,19 +1,23 @@
-// kernels_stream.h -- levels 4..9 for inputs longer than 65535 bytes: ONE deflate stream per
-// input, byte-identical to what the reference produces when the whole input goes through
-// Deflate.compress (deflate.zig:304-321) with its sliding 64 KiB window.
+// kernels_stream.h -- levels 4..9 for inputs longer than 65535 bytes and for inputs with
+// sync-flush points: ONE deflate stream per input, byte-identical to what the reference produces
+// when the input goes through Deflate.write / flush / finish (deflate.zig:304-371) with its
+// sliding 64 KiB window.
 //
 // What changes against the chunk path (kernels_lz.h):
 //  * match finding runs on overlapping 64 KiB tiles (k_lz_sort<true>, k_lz_match<true>): a tile
 //    searches 32 KiB of new positions against 32 KiB of history, which is exactly what the
 //    reference's window holds after a slide (SlidingWindow.zig:36-44, Lookup.zig:43-51).  The
 //    records go to one per-stream array indexed by the absolute position.
-//  * the lazy-matching automaton (deflate.zig:154-205) is a chain through the whole stream.  It
-//    is cut into 32768-position segments: every segment resolves "anchor -> first anchor beyond
-//    the segment" for each of the <= 512 offsets a predecessor can hand over (k_st_parse1), one
-//    thread per stream then walks segment to segment (k_st_stitch), and with its entry anchor
-//    known each segment marks its anchors and counts its tokens (k_st_parse2).
-//  * tokens are numbered through the whole stream; a block ends every 32768 tokens
-//    (deflate.zig:227-230), wherever that falls (k_st_scan, k_st_emit, k_st_blocks).
+//  * a sync flush (deflate.zig:335-337) cuts the stream into pieces: the tokenizer runs dry at the
+//    flush point (no match crosses it, the 3 positions before it are never hashed), the pending
+//    tokens go out as a block of their own and an empty stored block follows.  History survives.
+//  * inside a piece the lazy-matching automaton (deflate.zig:154-205) is one chain.  It is cut
+//    into segments of at most 32768 positions: every segment resolves "anchor -> first anchor
+//    beyond the segment" for each of the <= 512 offsets a predecessor can hand over
+//    (k_st_parse1), one thread per piece then walks segment to segment (k_st_stitch), and with
+//    its entry anchor known each segment marks its anchors and counts its tokens (k_st_parse2).
+//  * tokens are numbered through the piece; a block ends every 32768 tokens (deflate.zig:227-230),
+//    wherever that falls (k_st_scan, k_st_emit, k_st_blocks).
 //  * the raw input slice a block may be stored from (SlidingWindow.zig:119-123) is lost when the
 //    window slid since the previous flush: fl_block_plan::no_input.
 //
@@ -24,22 +28,27 @@
 #define FL_SEG 32768u
 #define FL_SEG_ENTRIES 512u  // next anchor <= previous + 254 literals + 258: hand-over offsets < 512
 
-// number of slides the reference has done when it visits stream position v, for a stream of
-// n bytes: slide j happens once the window is full (n >= 65536 + 32768 (j-1), deflate.zig:
-// 306-311) and the tokenizer has come within min_lookahead of its end (SlidingWindow.zig:56-60)
-__device__ __forceinline__ uint32_t fl_total_slides(uint32_t n) {
-    return n >= 65536u ? (n - 65536u) / FL_SEG + 1u : 0u;
+// How many window slides the reference has done when `written` bytes of the stream have gone
+// into the window: slide j happens as soon as the window is full for the j-th time
+// (65536 + 32768 (j-1) bytes, deflate.zig:306-311).
+__device__ __forceinline__ uint32_t fl_slides_when_written(uint32_t written) {
+    return written >= 65536u ? (written - 65536u) / FL_SEG + 1u : 0u;
 }
-__device__ __forceinline__ uint32_t fl_slides_before(uint32_t v, uint32_t n) {
-    const uint32_t by_pos = v >= FL_ZONE_START ? (v - FL_ZONE_START) / FL_SEG + 1u : 0u;
-    return min(by_pos, fl_total_slides(n));
+// ... and when it visits stream position v: zone[j-1] is the first position visited after slide j
+// (the host folds the lookahead rule of SlidingWindow.zig:56-60 and the flush points into it).
+__device__ __forceinline__ uint32_t fl_slides_before(uint32_t v, const uint32_t* __restrict__ zone, uint32_t n_slides) {
+    uint32_t j = v >= FL_ZONE_START ? (v - FL_ZONE_START) / FL_SEG + 1u : 0u;
+    j = min(j, n_slides);
+    if (j && v < zone[j - 1]) j--;
+    return j;
 }
 
 // ------------------------------------------------------------------ k_st_parse1
 // One workgroup per segment.  desc[] for every position (as k_lz_parse phase a), the pointer
-// table jumped inside 256-position pieces (phase b) saved to jmp[], and the exit map
-// exitmap[seg][e] = first anchor >= segment end on the path that enters at offset e.
+// table jumped inside 256-position runs (phase b) saved to jmp[], and the exit map
+// exitmap[seg][e] = first anchor >= segment end on the path that enters at offset max(e, lo).
 __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse1(const fl_chunk* __restrict__ chunks,
+                                                                    const fl_piece* __restrict__ pieces,
                                                                     const fl_seg* __restrict__ segs, fl_params prm,
                                                                     const uint32_t* __restrict__ rec_all,
                                                                     uint32_t* __restrict__ desc_all,
@@ -47,15 +56,17 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse1(const fl_chun
                                                                     uint16_t* __restrict__ exitmap) {
     __shared__ uint16_t J[FL_SEG];
     const fl_seg sg = segs[blockIdx.x];
-    const fl_chunk ck = chunks[sg.chunk];
+    const fl_piece pc = pieces[sg.piece];
+    const fl_chunk ck = chunks[pc.chunk];
     const uint32_t tid = threadIdx.x;
     const uint32_t N = ck.in_len;
-    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint32_t h0 = sg.h0, lo = max(h0, pc.start), h1 = min(h0 + FL_SEG, pc.end);
+    const uint32_t rlo = lo - h0, len = h1 - h0;  // window-relative [rlo, len)
     const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
     uint32_t* desc = desc_all + ck.pos_off;
     uint16_t* jmp = jmp_all + ck.pos_off + h0;
 
-    for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
+    for (uint32_t base = lo; base < h1; base += FL_PARSE_THREADS * 8) {
         uint2 ra[8], rb[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -75,41 +86,47 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse1(const fl_chun
     }
     __syncthreads();
     for (int round = 0; round < 8; round++) {
-        for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) {
-            const uint32_t piece_end = min((r | 255u) + 1u, len);
+        for (uint32_t r = rlo + tid; r < len; r += FL_PARSE_THREADS) {
+            const uint32_t run_end = min((r | 255u) + 1u, len);
             const uint32_t j = J[r];
-            if (j < piece_end) J[r] = J[j];
+            if (j < run_end) J[r] = J[j];
         }
         __syncthreads();
     }
-    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) jmp[r] = J[r];
-    if (tid < FL_SEG_ENTRIES && tid < len) {
-        uint32_t a = tid;
+    for (uint32_t r = rlo + tid; r < len; r += FL_PARSE_THREADS) jmp[r] = J[r];
+    if (tid < FL_SEG_ENTRIES) {
+        uint32_t a = max(tid, rlo);
         while (a < len) a = J[a];
         exitmap[(uint64_t)blockIdx.x * FL_SEG_ENTRIES + tid] = (uint16_t)a;
     }
 }
 
 // ------------------------------------------------------------------ k_st_stitch
-// One thread per stream: the entry anchor of every segment (segment-relative).
-__global__ __launch_bounds__(64) void k_st_stitch(const fl_chunk* __restrict__ chunks, uint32_t n_chunks,
+// One thread per piece: the entry anchor of every segment (relative to the segment's h0).
+__global__ __launch_bounds__(64) void k_st_stitch(const fl_piece* __restrict__ pieces, uint32_t n_pieces,
+                                                  const fl_seg* __restrict__ segs,
                                                   const uint16_t* __restrict__ exitmap,
                                                   uint32_t* __restrict__ entry) {
-    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= n_chunks) return;
-    const fl_chunk ck = chunks[c];
-    if (ck.skip) return;
-    uint32_t a = 0;
-    for (uint32_t s = 0; s < ck.n_seg; s++) {
-        entry[ck.seg0 + s] = a;
-        if (s + 1 < ck.n_seg) a = (uint32_t)exitmap[(uint64_t)(ck.seg0 + s) * FL_SEG_ENTRIES + a] - FL_SEG;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_pieces) return;
+    const fl_piece pc = pieces[i];
+    uint32_t a = pc.start;  // the tokenizer restarts at the piece start with nothing pending
+    for (uint32_t s = 0; s < pc.n_seg; s++) {
+        const uint32_t h0 = segs[pc.seg0 + s].h0;
+        const uint32_t rel = a - h0;
+        entry[pc.seg0 + s] = rel;
+        // an entry at or before the segment's first position is slot 0 of the map
+        const uint32_t slot = h0 >= pc.start ? rel : 0u;
+        if (s + 1 < pc.n_seg) a = h0 + (uint32_t)exitmap[(uint64_t)(pc.seg0 + s) * FL_SEG_ENTRIES + slot];
     }
 }
 
 // ------------------------------------------------------------------ k_st_parse2
 // One workgroup per segment: anchors of the segment (k_lz_parse phases c-e) from its entry
-// anchor, and the number of tokens they emit.
+// anchor, and the number of tokens they emit.  marks_all was cleared by the host: segments of
+// neighbouring pieces may share a word.
 __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chunk* __restrict__ chunks,
+                                                                    const fl_piece* __restrict__ pieces,
                                                                     const fl_seg* __restrict__ segs,
                                                                     const uint32_t* __restrict__ desc_all,
                                                                     const uint16_t* __restrict__ jmp_all,
@@ -118,33 +135,34 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chun
                                                                     uint32_t* __restrict__ segtok) {
     __shared__ uint16_t J[FL_SEG];
     __shared__ uint32_t marks[FL_SEG / 32];
-    __shared__ uint16_t piece_entry[FL_SEG / 256];
+    __shared__ uint16_t run_entry[FL_SEG / 256];
     __shared__ uint32_t wsum[FL_PARSE_THREADS / 64];
     const fl_seg sg = segs[blockIdx.x];
-    const fl_chunk ck = chunks[sg.chunk];
+    const fl_piece pc = pieces[sg.piece];
+    const fl_chunk ck = chunks[pc.chunk];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t N = ck.in_len;
-    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint32_t h0 = sg.h0, lo = max(h0, pc.start), h1 = min(h0 + FL_SEG, pc.end);
+    const uint32_t rlo = lo - h0, len = h1 - h0;
     const uint32_t* desc = desc_all + ck.pos_off + h0;
     const uint16_t* jmp = jmp_all + ck.pos_off + h0;
     uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
 
-    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) J[r] = jmp[r];
+    for (uint32_t r = rlo + tid; r < len; r += FL_PARSE_THREADS) J[r] = jmp[r];
     for (uint32_t i = tid; i < FL_SEG / 32; i += FL_PARSE_THREADS) marks[i] = 0;
-    if (tid < FL_SEG / 256) piece_entry[tid] = 0xffff;
+    if (tid < FL_SEG / 256) run_entry[tid] = 0xffff;
     __syncthreads();
-    if (tid == 0) {  // first anchor of every 256-position piece: at most 128 serial steps
+    if (tid == 0) {  // first anchor of every 256-position run: at most 128 serial steps
         uint32_t a = entry[blockIdx.x];
         while (a < len) {
-            piece_entry[a >> 8] = (uint16_t)a;
+            run_entry[a >> 8] = (uint16_t)a;
             a = J[a];
         }
     }
     __syncthreads();
-    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) J[r] = (uint16_t)(fl_desc_next(desc[r], r));
+    for (uint32_t r = rlo + tid; r < len; r += FL_PARSE_THREADS) J[r] = (uint16_t)(fl_desc_next(desc[r], r));
     __syncthreads();
     if (tid < FL_SEG / 256) {
-        uint32_t a = piece_entry[tid];
+        uint32_t a = run_entry[tid];
         const uint32_t end = min((tid + 1) << 8, len);
         while (a < end) {
             marks[a >> 5] |= 1u << (a & 31);
@@ -153,13 +171,14 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chun
     }
     __syncthreads();
     uint32_t cnt = 0;
-    for (uint32_t r = tid; r < len; r += FL_PARSE_THREADS) {
+    for (uint32_t r = rlo + tid; r < len; r += FL_PARSE_THREADS) {
         if ((marks[r >> 5] >> (r & 31)) & 1) {
             const uint32_t d = desc[r];
             cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
         }
     }
-    for (uint32_t i = tid; i < FL_SEG / 32; i += FL_PARSE_THREADS) gmarks[i] = marks[i];
+    for (uint32_t i = tid; i < FL_SEG / 32; i += FL_PARSE_THREADS)
+        if (marks[i]) atomicOr(&gmarks[i], marks[i]);
     cnt = fl_wave_sum(cnt);
     if (lane == 0) wsum[wave] = cnt;
     __syncthreads();
@@ -171,34 +190,32 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chun
 }
 
 // ------------------------------------------------------------------ k_st_scan
-// One wave per stream: index of every segment's first token, and the stream's token count.
-__global__ __launch_bounds__(64) void k_st_scan(const fl_chunk* __restrict__ chunks,
+// One wave per piece: index of every segment's first token, and the piece's token count.
+__global__ __launch_bounds__(64) void k_st_scan(const fl_piece* __restrict__ pieces,
                                                 const uint32_t* __restrict__ segtok,
-                                                uint32_t* __restrict__ tokbase, uint32_t* __restrict__ ntok) {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    const fl_chunk ck = chunks[c];
-    if (ck.skip) {
-        if (lane == 0) ntok[c] = 0;
-        return;
-    }
+                                                uint32_t* __restrict__ tokbase, uint32_t* __restrict__ piece_ntok) {
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    const fl_piece pc = pieces[i];
     uint32_t run = 0;
-    for (uint32_t s0 = 0; s0 < ck.n_seg; s0 += 64) {
+    for (uint32_t s0 = 0; s0 < pc.n_seg; s0 += 64) {
         const uint32_t s = s0 + lane;
-        const uint32_t v = s < ck.n_seg ? segtok[ck.seg0 + s] : 0;
+        const uint32_t v = s < pc.n_seg ? segtok[pc.seg0 + s] : 0;
         const uint32_t inc = fl_wave_incl_scan(v, lane);
-        if (s < ck.n_seg) tokbase[ck.seg0 + s] = run + inc - v;
+        if (s < pc.n_seg) tokbase[pc.seg0 + s] = run + inc - v;
         run += __shfl(inc, 63, 64);
     }
-    if (lane == 0) ntok[c] = run;
+    if (lane == 0) piece_ntok[i] = run;
 }
 
 // ------------------------------------------------------------------ k_st_emit
-// One workgroup per segment: tokens, per-block histograms (added into hist_all, which the host
-// cleared) and the stream position at which each full block was flushed (bound[]).
+// One workgroup per segment: tokens (token k of a piece at tokens[pos_off + piece.start + k]),
+// per-block histograms (added into hist_all, which the host cleared) and the stream position at
+// which each full block was flushed (bound[]).
 #define FL_STE_SPAN (FL_SEG / FL_EMIT_WAVES)
 #define FL_STE_WIN_DW (FL_SEG / 4 + 72)
 __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
+                                                              const fl_piece* __restrict__ pieces,
                                                               const fl_seg* __restrict__ segs, fl_params prm,
                                                               const uint32_t* __restrict__ desc_all,
                                                               const uint32_t* __restrict__ marks_all,
@@ -211,14 +228,16 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
     __shared__ uint32_t hist[2][320];
     __shared__ uint32_t wtot[FL_EMIT_WAVES];
     const fl_seg sg = segs[blockIdx.x];
-    const fl_chunk ck = chunks[sg.chunk];
+    const fl_piece pc = pieces[sg.piece];
+    const fl_chunk ck = chunks[pc.chunk];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t N = ck.in_len;
-    const uint32_t h0 = sg.s * FL_SEG, h1 = min(h0 + FL_SEG, N), len = h1 - h0;
+    const uint32_t h0 = sg.h0, lo = max(h0, pc.start), h1 = min(h0 + FL_SEG, pc.end);
+    const uint32_t rlo = lo - h0, len = h1 - h0;
     const uint8_t* src = in + ck.in_off + h0;
     const uint32_t* desc = desc_all + ck.pos_off + h0;
     const uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
-    uint32_t* tokens = tokens_all + ck.pos_off;
+    uint32_t* tokens = tokens_all + ck.pos_off + pc.start;
 
     const uint32_t nleft = N - h0;
     const uint32_t ndw = (min(nleft, FL_STE_WIN_DW * 4u) + 3) >> 2;
@@ -234,12 +253,12 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = span0 + (r + u) * 64 + lane;
-            d[u] = p < len ? desc[p] : 0;
+            d[u] = (p >= rlo && p < len) ? desc[p] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = span0 + (r + u) * 64 + lane;
-            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            const bool mk = p >= rlo && p < len && ((marks[p >> 5] >> (p & 31)) & 1);
             cnt += mk ? (d[u] ? ((d[u] >> 23) & 0xff) + 1 : 1) : 0;
         }
     }
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
     if (lane == 0) wtot[wave] = cnt;
     __syncthreads();
     const uint32_t tb = tokbase[blockIdx.x];
-    const uint32_t blk0 = tb >> 15;  // stream block holding this segment's first token
+    const uint32_t blk0 = tb >> 15;  // block of the piece holding this segment's first token
     uint32_t run = tb;
     for (uint32_t w = 0; w < wave; w++) run += wtot[w];
     for (uint32_t r = 0; r < FL_STE_SPAN / 64; r += 4) {
@@ -255,12 +274,12 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = span0 + (r + u) * 64 + lane;
-            d[u] = p < len ? desc[p] : 0;
+            d[u] = (p >= rlo && p < len) ? desc[p] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = span0 + (r + u) * 64 + lane;
-            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
+            const bool mk = p >= rlo && p < len && ((marks[p >> 5] >> (p & 31)) & 1);
             const uint32_t dd = d[u];
             const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;
             const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
                 atomicAdd(&hist[(idx >> 15) - blk0][byte], 1u);
                 // a literal goes out at the visit of the next position (deflate.zig:214-216)
                 if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
-                    bound[ck.first_block + (idx >> 15) + 1] = h0 + p + x + 1;
+                    bound[pc.first_block + (idx >> 15) + 1] = h0 + p + x + 1;
                 idx++;
             }
             if (mk && dd) {
@@ -283,50 +302,64 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __re
                 atomicAdd(&hist[(idx >> 15) - blk0][286 + fl_dist_code(d0)], 1u);
                 // a match of at least `lazy` goes out at its own visit, a shorter one at the next
                 if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
-                    bound[ck.first_block + (idx >> 15) + 1] = h0 + p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+                    bound[pc.first_block + (idx >> 15) + 1] = h0 + p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
             }
         }
     }
     __syncthreads();
     for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS) {
         const uint32_t v = (&hist[0][0])[i];
-        if (v) atomicAdd(&hist_all[(uint64_t)(ck.first_block + blk0 + i / 320) * 320 + i % 320], v);
+        if (v) atomicAdd(&hist_all[(uint64_t)(pc.first_block + blk0 + i / 320) * 320 + i % 320], v);
     }
 }
 
 // ------------------------------------------------------------------ k_st_blocks
-// One wave per stream: the block table (deflate.zig:268-288): block k holds tokens
-// [32768 k, 32768 (k+1)); there is always a final block, possibly empty.
+// One wave per piece: its block table (deflate.zig:268-288): block k holds tokens
+// [32768 k, 32768 (k+1)); the last one, possibly empty, goes out at the flush / finish that ends
+// the piece; after a sync flush an empty stored block follows (deflate.zig:276-278).
 __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ chunks,
-                                                  const uint32_t* __restrict__ ntok,
+                                                  const fl_piece* __restrict__ pieces,
+                                                  const uint32_t* __restrict__ piece_ntok,
                                                   const uint32_t* __restrict__ bound,
+                                                  const uint32_t* __restrict__ zones,
                                                   fl_block_plan* __restrict__ plans) {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    const fl_chunk ck = chunks[c];
-    if (ck.skip) {
-        for (uint32_t k = lane; k < ck.n_blocks; k += 64) plans[ck.first_block + k].valid = 0;
-        return;
-    }
-    const uint32_t N = ck.in_len, total = ntok[c];
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    const fl_piece pc = pieces[i];
+    const fl_chunk ck = chunks[pc.chunk];
+    const uint32_t total = piece_ntok[i];
     const uint32_t nblk = total / FL_MAX_TOKENS + 1;
-    for (uint32_t k = lane; k < ck.n_blocks; k += 64) {
-        fl_block_plan* plan = &plans[ck.first_block + k];
+    const uint32_t* zone = zones + ck.zone_off;
+    for (uint32_t k = lane; k < pc.n_blocks; k += 64) {
+        fl_block_plan* plan = &plans[pc.first_block + k];
+        if (k == nblk && (pc.flags & 2)) {  // the sync-flush marker: BFINAL 0, BTYPE 00, LEN 0, NLEN ffff
+            plan->valid = 1;
+            plan->type = FL_BLOCK_STORED;
+            plan->size_bits = 0;
+            plan->hdr_nbits = 0;
+            plan->final_block = 0;
+            plan->in_start = 0;
+            plan->in_len = 0;
+            plan->tok_start = 0;
+            plan->tok_count = 0;
+            plan->no_input = 2;  // k_plan leaves it alone
+            continue;
+        }
         if (k >= nblk) {
             plan->valid = 0;
             continue;
         }
         const bool last = k + 1 == nblk;
-        const uint32_t start = k ? bound[ck.first_block + k] : 0u;
-        const uint32_t end = last ? N : bound[ck.first_block + k + 1];
-        // window start when the block is flushed: inside the visit of `end` for a full block,
-        // after everything (including a slide that no data followed) for the final one
-        const uint32_t slides = last ? fl_total_slides(N) : fl_slides_before(end, N);
+        const uint32_t start = k ? bound[pc.first_block + k] : pc.start;
+        const uint32_t end = last ? pc.end : bound[pc.first_block + k + 1];
+        // window start when the block goes out: inside the visit of `end` for a full block; for
+        // the last one at the flush / finish call, when every slide the written bytes caused is done
+        const uint32_t slides = last ? fl_slides_when_written(pc.end) : fl_slides_before(end, zone, ck.n_slides);
         plan->valid = 1;
-        plan->tok_start = k * FL_MAX_TOKENS;
+        plan->tok_start = pc.start + k * FL_MAX_TOKENS;
         plan->tok_count = last ? total - k * FL_MAX_TOKENS : FL_MAX_TOKENS;
         plan->in_start = start;
         plan->in_len = end - start;
-        plan->final_block = last ? 1 : 0;
+        plan->final_block = (last && (pc.flags & 1)) ? 1 : 0;
         plan->no_input = start < slides * FL_SEG ? 1 : 0;  // SlidingWindow.zig:40, 119-123: fp went negative
     }
 }

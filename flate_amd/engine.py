@@ -73,6 +73,21 @@ class Engine:
         res = [out[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)]
         return res, [int(s) for s in status]
 
+    def compress_flush(self, data, flush_points, finish=True, container=0, mode=6):
+        """One stream with sync-flush points (Compressor.write / flush / finish, deflate.zig:335-367).
+        Returns (bytes, status)."""
+        blob = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        fp = np.array(list(flush_points), dtype=np.uint64)
+        cap = (self.compress_bound(len(data), container, mode) + 64 * (len(fp) + 1) + 7) & ~7
+        out = np.zeros(cap + 8, dtype=np.uint8)
+        out_len = np.zeros(1, dtype=np.uint64)
+        status = np.zeros(1, dtype=np.int32)
+        rc = self._L.flate_hip_compress_flush(self._h, blob.ctypes.data, len(data), fp.ctypes.data if len(fp) else None,
+                                              len(fp), 1 if finish else 0, container, mode, out.ctypes.data, cap,
+                                              out_len.ctypes.data, status.ctypes.data, MEM_HOST)
+        self._check(rc, "flate_hip_compress_flush")
+        return out[: int(out_len[0])].tobytes(), int(status[0])
+
     def decompress_many(self, streams, container=0, flags=0, caps=None):
         """streams: sequence of bytes-like.  caps: output capacity per stream (default: generous guess).
         Returns (list of bytes, list of status codes, list of consumed input bytes)."""

@@ -17,6 +17,9 @@
  *                               deflate.store.compress      deflate.zig:421-425
  *                               via flate.zig:28-30,44-47,59-62 and the gzip /
  *                               zlib twins (gzip.zig:23-25, zlib.zig:23-25)
+ *   flate_hip_compress_flush    Compressor.write / flush / finish with LZ history kept
+ *                               across flushes              deflate.zig:335-337, 344-347,
+ *                               363-367 (sync flush: 00 00 ff ff, :276-278)
  *   flate_hip_decompress_batch  inflate.decompress          inflate.zig:14-17
  *                               via flate.zig:10-12, gzip.zig:5-7, zlib.zig:5-7
  *   flate_hip_compress_bound    (no reference twin: the Zig writer grows)
@@ -121,6 +124,20 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
                              uint32_t n_chunks, int container, int mode, uint8_t* out,
                              const uint64_t* out_off, uint64_t* out_len, int32_t* status,
                              int memkind);
+
+/*
+ * One stream with sync-flush points (levels 4..9): what a Compressor of the reference has
+ * written after   write(in[0 .. p0]); flush(); write(in[p0 .. p1]); flush(); ...   and, when
+ * `finish` is non-zero, write(rest); finish().  flush_pos: n_flush ascending stream positions
+ * (<= n; equal neighbours = flush called twice).  Without `finish` the last flush point must be
+ * n and the output ends with that flush's marker.  Output of a shorter prefix of the same call
+ * sequence is a prefix of this output, so a streaming wrapper emits only what is new.
+ * The LZ77 history survives a flush (deflate.zig:335-337): matches reach back across it, but
+ * never run over it.  Host buffers only (memkind FLATE_HIP_MEM_HOST).
+ */
+int flate_hip_compress_flush(flate_hip_handle h, const uint8_t* in, uint64_t n, const uint64_t* flush_pos,
+                             uint32_t n_flush, int finish, int container, int mode, uint8_t* out,
+                             uint64_t out_cap, uint64_t* out_len, int32_t* status, int memkind);
 
 /*
  * Decompress n_chunks independent streams (same argument shape).  out_len[i] is the

@@ -1,0 +1,127 @@
+"""GPU parity tests of sync flush (Compressor.write / flush / finish, deflate.zig:335-367):
+the stream with its flush markers is byte-identical to the oracle's streaming compressor fed the
+same calls, LZ history across the flushes included."""
+import io
+import zlib as pyzlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpu_util import engine
+
+pytestmark = pytest.mark.gpu
+
+WBITS = {0: -15, 1: 31, 2: 15}
+
+
+def _oracle_stream(data, flushes, finish, container, level, tokens=False):
+    d = O.Deflate(container, level, log_tokens=tokens)
+    prev = 0
+    for f in flushes:
+        d.write(data[prev:f])
+        d.flush()
+        prev = f
+    if finish:
+        d.write(data[prev:])
+        d.finish()
+    out = d.output()
+    toks = d.tokens() if tokens else None
+    d.close()
+    return out, toks
+
+
+def _cases():
+    from flate_amd import synth
+    rng = np.random.default_rng(5)
+    text = synth.text(synth.SEED_TEXT + 11, 400000).tobytes()
+    rnd = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
+    z = 65536 - 262
+    return [
+        (b"", [0], True),
+        (b"", [0, 0], True),
+        (b"hello hello hello hello", [5], True),
+        (b"hello hello hello hello", [5, 5, 23], True),
+        (b"abcabcabcabcabcabc" * 10, [1, 2, 3, 4, 5, 6, 7, 8, 100, 179, 180], True),
+        (text[:1000], [1000], False),
+        (text[:30000], [100, 101, 5000, 29999], True),
+        (text[:70000], [40000], True),
+        (text[:70000], [65535], True),
+        (text[:70000], [65536], True),
+        (text[:70000], [z - 1], True), (text[:70000], [z], True), (text[:70000], [z + 1], True),
+        (text[:70000], [z + 100, z + 200], True),
+        (text[:140000], [z + 50, 65536 + 100, 98304 - 100, 98304, 98304 + 5], True),
+        (text, [1000, 70000, 70001, 200000, 399999], True),
+        (text, [400000], False),
+        (text[:200000], list(range(0, 200000, 7919)), True),
+        (rnd[:100000], [33333, 66666], True),
+        (bytes(150000), [1, 65000, 65536, 100000], True),
+        ((text[:3000] + rnd[:500]) * 40, [12345, 70000, 100000], True),
+    ]
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("level", [4, 6, 9])
+def test_flush_streams_match_oracle(level):
+    eng = engine()
+    for i, (data, flushes, finish) in enumerate(CASES):
+        got, st = eng.compress_flush(data, flushes, finish, O.RAW, level)
+        assert st == 0, (i, st)
+        want, wtok = _oracle_stream(data, flushes, finish, O.RAW, level, tokens=True)
+        if got != want:
+            toks = eng.debug_tokens(0)
+            m = min(len(toks), len(wtok))
+            bad = np.nonzero(toks[:m] != wtok[:m])[0]
+            first = int(bad[0]) if bad.size else m
+            raise AssertionError((i, level, len(data), flushes[:6], len(got), len(want), "first differing token", first,
+                                  O.tok_decode(toks[first]) if first < len(toks) else None,
+                                  O.tok_decode(wtok[first]) if first < len(wtok) else None))
+        if finish:
+            assert pyzlib.decompress(got, -15) == data
+
+
+@pytest.mark.parametrize("container", [1, 2])
+def test_flush_with_containers(container):
+    eng = engine()
+    for data, flushes, finish in CASES[2:12]:
+        got, st = eng.compress_flush(data, flushes, finish, container, 6)
+        assert st == 0
+        assert got == _oracle_stream(data, flushes, finish, container, 6)[0]
+        if finish:
+            assert pyzlib.decompress(got, WBITS[container]) == data
+
+
+def test_flushed_prefix_is_decodable_and_a_prefix():
+    # what a flush has pushed out must already decode to the data written so far
+    eng = engine()
+    data = CASES[15][0]
+    flushes = [1000, 70000, 200000]
+    full, st = eng.compress_flush(data, flushes, True, O.RAW, 6)
+    assert st == 0
+    for k in range(1, len(flushes) + 1):
+        part, st = eng.compress_flush(data[:flushes[k - 1]], flushes[:k], False, O.RAW, 6)
+        assert st == 0 and full.startswith(part) and part.endswith(b"\x00\x00\xff\xff")
+        d = pyzlib.decompressobj(-15)
+        assert d.decompress(part) == data[:flushes[k - 1]]
+
+
+def test_compressor_object_flush_mirror():
+    # flate.zig compressor(): write / flush / write / finish through the Python mirror
+    engine()
+    from flate_amd import gzip
+    data = CASES[15][0][:150000]
+    sink = io.BytesIO()
+    c = gzip.compressor(sink, gzip.Options(level=gzip.Level.default))
+    c.write(data[:50000])
+    c.flush()
+    n1 = len(sink.getvalue())
+    d = pyzlib.decompressobj(31)
+    assert d.decompress(sink.getvalue()) == data[:50000]
+    c.write(data[50000:])
+    c.flush()
+    c.finish()
+    out = sink.getvalue()
+    assert n1 < len(out) and pyzlib.decompress(out, 31) == data
+    assert out == _oracle_stream(data, [50000, 150000], True, O.GZIP, 6)[0]
