@@ -20,7 +20,7 @@
 // One-shot semantics run on the GPU, for inputs of any length: at levels 4..9 an input longer than
 // 65535 bytes is compressed as one stream by the whole-stream path (same bytes as the reference's
 // sliding-window compressor).  Compressor::flush (history-preserving sync flush,
-// deflate.zig:335-337) is not on the GPU path and throws.  There is no CPU fallback.
+// deflate.zig:335-337, levels 4..9) runs on the GPU as well.  There is no CPU fallback.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -78,6 +78,23 @@ class Engine {
         out.resize(out_len);
         return out;
     }
+    // the stream a Compressor has written after write/flush/.../[finish] (flate_hip_compress_flush)
+    std::vector<uint8_t> compress_flush(const std::vector<uint8_t>& in, const std::vector<uint64_t>& flushes, bool finish,
+                                        int container, int mode) {
+        const size_t cap = (flate_hip_compress_bound(in.size(), container, mode) + 64 * (flushes.size() + 1) + 7) & ~size_t(7);
+        std::vector<uint8_t> out(cap + 8);
+        uint64_t out_len = 0;
+        int32_t status = 0;
+        const uint8_t dummy = 0;
+        const int rc = flate_hip_compress_flush(h_, in.empty() ? &dummy : in.data(), in.size(),
+                                                flushes.empty() ? nullptr : flushes.data(), (uint32_t)flushes.size(),
+                                                finish ? 1 : 0, container, mode, out.data(), cap, &out_len, &status,
+                                                FLATE_HIP_MEM_HOST);
+        if (rc != FLATE_HIP_OK) throw Error(rc, std::string("flate_hip_compress_flush: ") + flate_hip_last_error(h_));
+        if (status) throw Error(status);
+        out.resize(out_len);
+        return out;
+    }
     // returns bytes consumed from `in`
     size_t decompress_one(const uint8_t* in, size_t n, int container, std::vector<uint8_t>& out) {
         size_t cap = n * 8 + (1 << 16);
@@ -131,21 +148,34 @@ class CompressorImpl {
     void compress(Reader& r) {  // deflate.zig:304-321
         read_all(r, buf_);
     }
-    void flush() {  // deflate.zig:335-337
-        throw Error(FLATE_HIP_E_UNSUPPORTED, "sync flush keeps LZ history across calls: not on the GPU path yet");
+    // deflate.zig:335-337: pending tokens out, then an empty stored block; the LZ history stays.
+    // The stream so far is re-run with its flush points; what a shorter prefix of the calls has
+    // produced is a prefix of it, so only the new bytes go to the writer.
+    void flush() {
+        if (mode_ < 4) throw Error(FLATE_HIP_E_UNSUPPORTED, "sync flush of the huffman-only / store-only compressors");
+        flushes_.push_back(buf_.size());
+        emit(Engine::instance().compress_flush(buf_, flushes_, false, container_, mode_));
     }
     void setWriter(Writer& w) { wrt_ = &w; }  // deflate.zig:351-354
     void finish() {                           // deflate.zig:344-347
         if (done_) return;
-        const std::vector<uint8_t> out = Engine::instance().compress_one(buf_, container_, mode_);
-        wrt_->write(out.data(), out.size());
+        if (flushes_.empty())
+            emit(Engine::instance().compress_one(buf_, container_, mode_));
+        else
+            emit(Engine::instance().compress_flush(buf_, flushes_, true, container_, mode_));
         done_ = true;
     }
 
    private:
+    void emit(const std::vector<uint8_t>& out) {
+        wrt_->write(out.data() + emitted_, out.size() - emitted_);
+        emitted_ = out.size();
+    }
     Writer* wrt_;
     int container_, mode_;
     std::vector<uint8_t> buf_;
+    std::vector<uint64_t> flushes_;
+    size_t emitted_ = 0;
     bool done_ = false;
 };
 

@@ -68,6 +68,24 @@ int main() {
         CHECK(c.size() < big.size() / 4);
         CHECK(run([](auto& r, auto& w) { gzip::decompress(r, w); }, c) == big);
     }
+    // write / flush / write / finish (flate.zig:33-40, deflate.zig:335-367): the flushed part decodes on its own
+    {
+        std::vector<uint8_t> big(90000);
+        for (size_t i = 0; i < big.size(); i++) big[i] = (uint8_t)("sync flush keeps history "[i % 25] + (i / 5000) % 3);
+        VectorWriter w;
+        auto c = zlib::compressor(w);
+        c.write(big.data(), 40000);
+        c.flush();
+        const size_t n1 = w.data.size();
+        CHECK(n1 > 4 && w.data[n1 - 4] == 0x00 && w.data[n1 - 3] == 0x00 && w.data[n1 - 2] == 0xff && w.data[n1 - 1] == 0xff);
+        c.write(big.data() + 40000, big.size() - 40000);
+        c.finish();
+        CHECK(w.data.size() > n1);
+        BufferReader r2(w.data.data(), w.data.size());
+        VectorWriter back;
+        zlib::decompress(r2, back);
+        CHECK(back.data == big);
+    }
     printf("facade ok\n");
     return 0;
 }
