@@ -384,7 +384,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     const uint32_t Mpos = min(N >= 4 ? N - 3 : 0u, 65536u);  // positions with 4 bytes left in the stream
     const uint32_t M = STREAM ? n_sorted[c] : Mpos;            // entries of the sorted array
     const uint32_t* fp = STREAM ? fpts + ck.flush_off : nullptr;
-    const bool has_fl = STREAM && ck.n_flush && fl_next_flush(fp, ck.n_flush, w0, ck.in_len) <= w0 + Mpos + 2;
+    // a flush point up to 258 bytes past the last position still shortens matches in this window
+    const bool has_fl =
+        STREAM && ck.n_flush && fl_next_flush(fp, ck.n_flush, w0, ck.in_len) <= w0 + Mpos + 2 + FL_MAX_MATCH;
     const uint8_t* src = in + ck.in_off + w0;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
     uint32_t* NQc = NQ + (uint64_t)c * FL_CHUNK_STRIDE;

@@ -125,3 +125,31 @@ def test_compressor_object_flush_mirror():
     out = sink.getvalue()
     assert n1 < len(out) and pyzlib.decompress(out, 31) == data
     assert out == _oracle_stream(data, [50000, 150000], True, O.GZIP, 6)[0]
+
+
+def test_flush_fuzz_against_oracle():
+    # random data structure x random flush positions (clustered around the window boundaries)
+    from test_gpu_stream import _fuzz_input
+    eng = engine()
+    rng = np.random.default_rng(99)
+    for i in range(40):
+        data = _fuzz_input(2000 + i)[: int(rng.integers(1, 250000))]
+        n = len(data)
+        marks = [65536 - 262, 65536, 98304 - 262, 98304, 131072 - 262, 131072, 32768]
+        pts = set()
+        for _ in range(int(rng.integers(1, 9))):
+            if rng.random() < 0.6:
+                pts.add(int(min(n, max(0, rng.choice(marks) + rng.integers(-300, 300)))))
+            else:
+                pts.add(int(rng.integers(0, n + 1)))
+        flushes = sorted(pts)
+        if rng.random() < 0.3:
+            flushes.append(flushes[-1])  # flush twice
+        finish = bool(rng.random() < 0.8)
+        if not finish:
+            flushes = [f for f in flushes if f < n] + [n]
+        for level in (4, 6, 9):
+            got, st = eng.compress_flush(data, flushes, finish, O.RAW, level)
+            assert st == 0
+            want = _oracle_stream(data, flushes, finish, O.RAW, level)[0]
+            assert got == want, (i, level, n, flushes, finish, len(got), len(want))

@@ -195,3 +195,18 @@ def test_config1_vector_on_gpu():
     for level in (4, 9):
         o, st = eng.compress_many([z], O.GZIP, level)
         assert st == [0] and o[0][10:-8] == outs[0][10:-8]
+
+
+def test_stream_passes_are_split_by_bytes():
+    # FLATE_HIP_MAX_STREAM_PASS_MIB bounds the scratch of one whole-stream pass: same bytes either way
+    import os
+    eng = engine()
+    names = ["text300k", "mix", "rand300k", "text1m", "zeros200k"]
+    datas = [CASES[n] for n in names]
+    a, st = eng.compress_many(datas, 1, 6)
+    os.environ["FLATE_HIP_MAX_STREAM_PASS_MIB"] = "1"
+    try:
+        b, st2 = eng.compress_many(datas, 1, 6)
+    finally:
+        del os.environ["FLATE_HIP_MAX_STREAM_PASS_MIB"]
+    assert st == [0] * 5 and st2 == [0] * 5 and a == b
