@@ -153,13 +153,13 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         b = b < half ? 2 * b : 2 * (b - half) + 1;
     }
     fl_plan_ws& ws = wss[wave];
-    const fl_chunk ck = chunks[blk_chunk[b]];
     fl_block_plan* plan = &plans[b];
-    if (ck.skip) {
-        if (lane == 0) plan->valid = 0;
-        return;
-    }
     if (prm.mode == 1) {
+        const fl_chunk ck = chunks[blk_chunk[b]];
+        if (ck.skip) {
+            if (lane == 0) plan->valid = 0;
+            return;
+        }
         const uint32_t j = b - ck.first_block;
         const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
         const uint32_t start = (uint32_t)min(s, (uint64_t)ck.in_len);
@@ -174,14 +174,15 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
             fl_plan_huffman_block(&ws, plan, len, j + 1 == ck.n_blocks);
         }
     } else {
-        // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel
-        if (!plan->valid || plan->no_input == 2) return;  // 2: a sync-flush marker, already a stored block
+        // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel,
+        // valid = 0 for the slots of skipped chunks
+        if (plan->valid != 1) return;  // 0: unused slot; 2: a sync-flush marker, already a stored block
         for (uint32_t i = lane; i < FL_NUM_LIT; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         if (lane < FL_NUM_DIST) ws.dist_freq[lane] = (uint16_t)hist[(uint64_t)b * 320 + 286 + lane];
         fl_wave_lds_sync();
-        // no_input: a window slide since the previous flush took the raw bytes away
-        // (SlidingWindow.zig:119-123): only whole-stream passes ever set it
-        if (lane == 0) fl_plan_token_block(&ws, plan, plan->no_input ? FL_NO_INPUT : plan->in_len, plan->final_block);
+        // in_len == FL_NO_INPUT: a window slide since the previous flush took the raw bytes away
+        // (SlidingWindow.zig:119-123); only whole-stream passes ever set it
+        if (lane == 0) fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);
     }
 }
 

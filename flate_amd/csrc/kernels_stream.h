@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
     for (uint32_t k = lane; k < pc.n_blocks; k += 64) {
         fl_block_plan* plan = &plans[pc.first_block + k];
         if (k == nblk && (pc.flags & 2)) {  // the sync-flush marker: BFINAL 0, BTYPE 00, LEN 0, NLEN ffff
-            plan->valid = 1;
+            plan->valid = 2;  // k_plan leaves it alone
             plan->type = FL_BLOCK_STORED;
             plan->size_bits = 0;
             plan->hdr_nbits = 0;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
             plan->in_len = 0;
             plan->tok_start = 0;
             plan->tok_count = 0;
-            plan->no_input = 2;  // k_plan leaves it alone
+            plan->no_input = 0;
             continue;
         }
         if (k >= nblk) {
@@ -357,9 +357,10 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
         plan->valid = 1;
         plan->tok_start = pc.start + k * FL_MAX_TOKENS;
         plan->tok_count = last ? total - k * FL_MAX_TOKENS : FL_MAX_TOKENS;
+        const bool no_input = start < slides * FL_SEG;  // SlidingWindow.zig:40, 119-123: fp went negative
         plan->in_start = start;
-        plan->in_len = end - start;
+        plan->in_len = no_input ? FL_NO_INPUT : end - start;  // (a block without input is never stored)
         plan->final_block = (last && (pc.flags & 1)) ? 1 : 0;
-        plan->no_input = start < slides * FL_SEG ? 1 : 0;  // SlidingWindow.zig:40, 119-123: fp went negative
+        plan->no_input = no_input ? 1 : 0;
     }
 }
