@@ -639,13 +639,16 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
         }                                                                              \
     } while (0)
     while (p < 64) {
-        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
-        const uint32_t kind = l >> 30;
-        if (kind == 1) {
+        uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
+        // a run of literals: a loop of its own so that it carries nothing but p and the mask
+        while ((l >> 30) == 1) {
             lits |= 1ull << p;
             p += l & 0xff;
-            continue;
+            if (p >= 64) break;
+            l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
         }
+        if (p >= 64) break;
+        const uint32_t kind = l >> 30;
         if (kind == 3) {
             const uint32_t p2 = p + (l & 0xff);
             if (p2 >= 64) break;  // the distance code starts beyond this round's lanes
@@ -657,18 +660,27 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
                 break;
             }
             const uint32_t vp = (uint32_t)wp + bias;
+#ifdef FL_INF_COUNT
+            const uint64_t tm_ = __builtin_readcyclecounter();
+#endif
             if (distance <= near_max) {
-                for (uint32_t i0 = 0; i0 < length; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    uint32_t byte = 0;
-                    if (i < length) {
-                        const uint32_t si = distance >= length ? i : (i % distance);
-                        byte = o.ring[(vp - distance + si) & rmask];
+                // A match that overlaps itself repeats its first `distance` bytes: every pass
+                // copies as much as is already there (no per-lane modulo), so the period doubles.
+                uint32_t have = distance, done = 0;
+                do {
+                    const uint32_t chunk = min(have, length - done);
+                    const uint32_t src0 = vp + done - have, dst0 = vp + done;
+                    for (uint32_t i0 = 0; i0 < chunk; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        uint32_t byte = 0;
+                        if (i < chunk) byte = o.ring[(src0 + i) & rmask];
+                        fl_lds_order();
+                        if (i < chunk) o.ring[(dst0 + i) & rmask] = (uint8_t)byte;
+                        fl_lds_order();
                     }
-                    fl_lds_order();
-                    if (i < length) o.ring[(vp + i) & rmask] = (uint8_t)byte;
-                    fl_lds_order();
-                }
+                    done += chunk;
+                    have += chunk;
+                } while (done < length);
             } else {
                 if (wp - distance + length > fl_uni64(o.fenced)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -685,11 +697,21 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             room -= length;
             unfl += length;
             p = p2 + (d & 0xff);
+#ifdef FL_INF_COUNT
+            if (blockIdx.x == 0 && lane == 0) {
+                g_fl_prof[46] += __builtin_readcyclecounter() - tm_;
+                g_fl_prof[47]++;
+            }
+            const uint64_t tf_ = __builtin_readcyclecounter();
+#endif
             if (unfl >= FL_INF_PILE) {
                 o.wp = wp;
                 fl_inf_flush(o, ((wp + bias) & ~(uint64_t)511) - bias, lane);
                 unfl = (uint32_t)(wp - o.flushed);
             }
+#ifdef FL_INF_COUNT
+            if (blockIdx.x == 0 && lane == 0) g_fl_prof[48] += __builtin_readcyclecounter() - tf_;
+#endif
             if (room < 64) break;  // keep the guarantee for the literals of the rest of the round
             continue;
         }
