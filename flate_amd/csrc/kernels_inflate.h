@@ -609,15 +609,18 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     }
     // The walk below is wave-uniform; the compiler cannot see that for anything that came out of
     // LDS, so the state is pinned to scalar registers explicitly.
-    uint64_t wp = fl_uni64(o.wp);
+    const uint64_t wp0 = fl_uni64(o.wp);
     const uint64_t cap = fl_uni64(o.cap);
-    uint32_t room = (uint32_t)(cap - wp < 0x40000000ull ? cap - wp : 0x40000000ull);  // output bytes left (saturated)
-    if (room < 64) return 2;  // a round emits at most 64 literals: no per-literal check below
-    uint32_t unfl = fl_uni((uint32_t)(wp - o.flushed));
+    const uint32_t room0 = (uint32_t)(cap - wp0 < 0x40000000ull ? cap - wp0 : 0x40000000ull);  // output bytes left (saturated)
+    if (room0 < 64) return 2;  // a round emits at most 64 literals: no per-literal check below
+    const uint32_t hist0 = (uint32_t)(wp0 < 0x100000ull ? wp0 : 0x100000ull);  // bytes a match may reach back (saturated)
+    int32_t unfl0 = (int32_t)fl_uni((uint32_t)(wp0 - o.flushed));                // unflushed bytes = unfl0 + adv
     const uint32_t bias = fl_uni(o.bias), rmask = fl_uni(o.rmask), near_max = fl_uni(o.near_max);
+    const uint32_t vp0 = (uint32_t)wp0 + bias;  // ring position of output byte wp0 (low bits)
     const uint32_t my_byte = (lp >> 8) & 0xff;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint64_t lits = 0;  // start lanes of the literals met since the last match: they go out together
+    uint32_t adv = 0;   // output bytes produced in this round: the only running output counter
     uint32_t p = 0;
     int rc = 0;
 #ifdef FL_INF_COUNT  // tuning build only (tools/inflate_probe.py): cycles of the table lookups vs the walk
@@ -626,17 +629,14 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     const uint64_t t1_ = __builtin_readcyclecounter();
 #endif
     // the literals collected in `lits` are written by their own lanes, in chain order
-#define FL_INF_PUT_LITS()                                                              \
-    do {                                                                               \
-        if (lits) {                                                                    \
-            const uint32_t nl_ = (uint32_t)__popcll(lits);                             \
-            if ((lits >> lane) & 1)                                                    \
-                o.ring[((uint32_t)wp + bias + (uint32_t)__popcll(lits & lt_mask)) & rmask] = (uint8_t)my_byte; \
-            wp += nl_;                                                                 \
-            room -= nl_;                                                               \
-            unfl += nl_;                                                               \
-            lits = 0;                                                                  \
-        }                                                                              \
+#define FL_INF_PUT_LITS()                                                                                \
+    do {                                                                                                 \
+        if (lits) {                                                                                      \
+            if ((lits >> lane) & 1)                                                                      \
+                o.ring[(vp0 + adv + (uint32_t)__popcll(lits & lt_mask)) & rmask] = (uint8_t)my_byte;      \
+            adv += (uint32_t)__popcll(lits);                                                             \
+            lits = 0;                                                                                    \
+        }                                                                                                \
     } while (0)
     while (p < 64) {
         uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
@@ -655,11 +655,11 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dp, (int)p2);
             const uint32_t length = (l >> 8) & 0x1ff, distance = (d >> 8) & 0xffff;
             FL_INF_PUT_LITS();
-            if (d == 0 || (wp < 32768 && distance > (uint32_t)wp) || length > room) {
+            if (d == 0 || distance > hist0 + adv || adv + length > room0) {
                 rc = 2;
                 break;
             }
-            const uint32_t vp = (uint32_t)wp + bias;
+            const uint32_t vp = vp0 + adv;
 #ifdef FL_INF_COUNT
             const uint64_t tm_ = __builtin_readcyclecounter();
 #endif
@@ -682,6 +682,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
                     have += chunk;
                 } while (done < length);
             } else {
+                const uint64_t wp = wp0 + adv;
                 if (wp - distance + length > fl_uni64(o.fenced)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     o.fenced = o.flushed;
@@ -693,26 +694,20 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
                 }
                 fl_lds_order();
             }
-            wp += length;
-            room -= length;
-            unfl += length;
+            adv += length;
             p = p2 + (d & 0xff);
 #ifdef FL_INF_COUNT
             if (blockIdx.x == 0 && lane == 0) {
                 g_fl_prof[46] += __builtin_readcyclecounter() - tm_;
                 g_fl_prof[47]++;
             }
-            const uint64_t tf_ = __builtin_readcyclecounter();
 #endif
-            if (unfl >= FL_INF_PILE) {
-                o.wp = wp;
-                fl_inf_flush(o, ((wp + bias) & ~(uint64_t)511) - bias, lane);
-                unfl = (uint32_t)(wp - o.flushed);
+            if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) {
+                o.wp = wp0 + adv;
+                fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
+                unfl0 = (int32_t)fl_uni((uint32_t)(o.wp - o.flushed)) - (int32_t)adv;
             }
-#ifdef FL_INF_COUNT
-            if (blockIdx.x == 0 && lane == 0) g_fl_prof[48] += __builtin_readcyclecounter() - tf_;
-#endif
-            if (room < 64) break;  // keep the guarantee for the literals of the rest of the round
+            if (room0 - adv < 64) break;  // keep the guarantee for the literals of the rest of the round
             continue;
         }
         if (kind == 2) {
@@ -729,8 +724,8 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
 #ifdef FL_INF_COUNT
     if (blockIdx.x == 0 && lane == 0) g_fl_prof[45] += __builtin_readcyclecounter() - t1_;
 #endif
-    o.wp = wp;
-    if (unfl >= FL_INF_PILE) fl_inf_flush(o, ((wp + bias) & ~(uint64_t)511) - bias, lane);
+    o.wp = wp0 + adv;
+    if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
     r.left -= p;
     return rc;
 }

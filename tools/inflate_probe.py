@@ -45,5 +45,4 @@ print("inflate %d x %d KiB: %.2f ms device-resident (%.1f MB/s), host path %.1f 
 if os.environ.get("PROBE_COUNTS"):
     pc = eng.phase_cycles()
     print("fast rounds", int(pc[40]), "rounds ending in slow", int(pc[41]), "slow symbols", int(pc[42]),
-          "cycles: prologue", int(pc[44]), "walk", int(pc[45]), "match copies", int(pc[46]), "n matches", int(pc[47]),
-          "flush checks", int(pc[48]))
+          "cycles: prologue", int(pc[44]), "walk", int(pc[45]), "match copies", int(pc[46]), "n matches", int(pc[47]))
