@@ -25,7 +25,6 @@
 #pragma once
 #include "kernels_lz.h"
 
-#define FL_SEG 32768u
 #define FL_SEG_ENTRIES 512u  // next anchor <= previous + 254 literals + 258: hand-over offsets < 512
 
 // How many window slides the reference has done when `written` bytes of the stream have gone

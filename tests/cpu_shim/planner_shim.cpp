@@ -49,3 +49,43 @@ void shim_tables(uint8_t* len_index /*256*/, uint8_t* len_extra /*29*/, uint8_t*
     }
 }
 }
+
+// ---- host tables of a whole-stream pass (flate_amd/csrc/stream_tables.h) ----
+#include "../../flate_amd/csrc/stream_tables.h"
+
+extern "C" {
+// Builds the tables of ONE stream of n bytes with the given flush points.  Returns the counts
+// through the out parameters; arrays are filled up to their capacities.
+int shim_stream_tables(uint32_t n, const uint64_t* flush_pos, uint32_t n_flush, int finish, uint32_t* n_blocks,
+                       uint32_t* n_slides, uint32_t* zones, uint32_t zones_cap, uint32_t* tiles /* w0,tgt0,zone */,
+                       uint32_t tiles_cap, uint32_t* n_tiles, uint32_t* pieces /* start,end,first_block,n_blocks,seg0,n_seg,flags */,
+                       uint32_t pieces_cap, uint32_t* n_pieces, uint32_t* segs /* piece,h0 */, uint32_t segs_cap,
+                       uint32_t* n_segs) {
+    StreamTables t;
+    fl_chunk c{};
+    c.in_len = n;
+    FlushSpec fs{flush_pos, n_flush, finish != 0};
+    add_stream_chunk(t, c, 0, 0, (n_flush || !finish) ? &fs : nullptr);
+    *n_blocks = c.n_blocks;
+    *n_slides = c.n_slides;
+    for (uint32_t i = 0; i < t.zones.size() && i < zones_cap; i++) zones[i] = t.zones[i];
+    *n_tiles = (uint32_t)t.tiles.size();
+    for (uint32_t i = 0; i < t.tiles.size() && i < tiles_cap; i++) {
+        tiles[3 * i] = t.tiles[i].w0;
+        tiles[3 * i + 1] = t.tiles[i].tgt0;
+        tiles[3 * i + 2] = t.tiles[i].zone;
+    }
+    *n_pieces = (uint32_t)t.pieces.size();
+    for (uint32_t i = 0; i < t.pieces.size() && i < pieces_cap; i++) {
+        const fl_piece& p = t.pieces[i];
+        const uint32_t v[7] = {p.start, p.end, p.first_block, p.n_blocks, p.seg0, p.n_seg, p.flags};
+        for (int k = 0; k < 7; k++) pieces[7 * i + k] = v[k];
+    }
+    *n_segs = (uint32_t)t.segs.size();
+    for (uint32_t i = 0; i < t.segs.size() && i < segs_cap; i++) {
+        segs[2 * i] = t.segs[i].piece;
+        segs[2 * i + 1] = t.segs[i].h0;
+    }
+    return 0;
+}
+}

@@ -28,8 +28,8 @@ class Plan(C.Structure):
 @pytest.fixture(scope="module")
 def shim():
     src = os.path.join(SHIM_DIR, "planner_shim.cpp")
-    hdr = os.path.join(ROOT, "flate_amd", "csrc", "flate_common.h")
-    if (not os.path.exists(SHIM_SO) or os.path.getmtime(SHIM_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    deps = [src] + [os.path.join(ROOT, "flate_amd", "csrc", h) for h in ("flate_common.h", "flate_layout.h", "stream_tables.h")]
+    if not os.path.exists(SHIM_SO) or os.path.getmtime(SHIM_SO) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-Wall", "-fsanitize=undefined", "-fno-sanitize-recover",
                         "-fPIC", "-shared", "-o", SHIM_SO, src], check=True)
     lib = C.CDLL(SHIM_SO)
