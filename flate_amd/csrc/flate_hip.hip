@@ -464,7 +464,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         c.out_off = hout[i] - out_shift;
         c.out_cap = hout[i + 1] - hout[i];
         c.skip = 0;
-        if (len > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+        // stream positions are 32-bit and the last match tile looks 64 KiB + 258 bytes ahead of its start
+        if (len > (mode >= 4 ? 0xfff00000ull : 0xfffffff0ull)) return FLATE_HIP_E_INVALID_ARG;
         c.in_len = (uint32_t)len;
         c.pos_off = 0;
         c.piece0 = c.n_piece = c.flush_off = c.n_flush = c.zone_off = c.n_slides = 0;
@@ -634,7 +635,7 @@ int flate_hip_compress_flush(flate_hip_handle h, const uint8_t* in, uint64_t n, 
     if (!h || !out_len || !status || (n_flush && !flush_pos)) return FLATE_HIP_E_INVALID_ARG;
     if (mode < 4 || mode > 9) return FLATE_HIP_E_UNSUPPORTED;
     if (memkind != FLATE_HIP_MEM_HOST) return FLATE_HIP_E_UNSUPPORTED;
-    if (n > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+    if (n > 0xfff00000ull) return FLATE_HIP_E_INVALID_ARG;
     uint64_t prev = 0;
     for (uint32_t k = 0; k < n_flush; k++) {
         if (flush_pos[k] < prev || flush_pos[k] > n) return FLATE_HIP_E_INVALID_ARG;

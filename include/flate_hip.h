@@ -92,7 +92,8 @@ enum { FLATE_HIP_INFLATE_STRICT_Q6 = 1 };
 /* Levels 4..9: an input of up to this many bytes never slides the reference's window and takes
  * the batched chunk path (one workgroup per input); a longer one is compressed as ONE stream by
  * the whole-stream path, byte-identical to Deflate.compress over the whole input
- * (deflate.zig:304-321 with SlidingWindow.zig:36-44, Lookup.zig:43-51). */
+ * (deflate.zig:304-321 with SlidingWindow.zig:36-44, Lookup.zig:43-51).  One level-4..9 input may be
+ * at most 0xfff00000 bytes (stream positions are 32-bit); other modes 0xfffffff0. */
 #define FLATE_HIP_MAX_LZ_CHUNK 65535u
 
 int flate_hip_create(int device, flate_hip_handle* h);
