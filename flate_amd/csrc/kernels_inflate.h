@@ -14,10 +14,14 @@
 #pragma once
 #include "kernels_common.h"
 
-struct fl_hdec {
+// canonical decoder tables (huffman_decoder.zig:71-153); NSYM = alphabet capacity
+template <int NSYM>
+struct fl_hdec_t {
     uint16_t count[16];
-    uint16_t symbol[288];
+    uint16_t symbol[NSYM];
 };
+typedef fl_hdec_t<288> fl_hdec;      // literal / length alphabet (286 used)
+typedef fl_hdec_t<32> fl_hdec_small;  // distance (30) and code-length (19) alphabets
 
 // LDS pointers are typed with their address space: with generic pointers the decoder's table
 // and ring accesses became FLAT instructions (PMC: 323 k FLAT vs 30 k LDS per wave), i.e. LDS
@@ -25,7 +29,7 @@ struct fl_hdec {
 #define FL_LDS __attribute__((address_space(3)))
 
 #define FL_INF_LIT_BITS 10
-#define FL_INF_DST_BITS 9
+#define FL_INF_DST_BITS 8
 // Recent output kept in LDS (power of two); matches up to ring - 260 back are served from it.
 // Large batches run the small ring (13 streams per CU in flight); small batches, where the
 // latency of one stream is what counts, the large one: every match is then an LDS copy.
@@ -33,7 +37,8 @@ struct fl_hdec {
 #define FL_INF_RING_LARGE 32768u
 
 struct fl_inflate_ws {
-    fl_hdec lit, dst, cl;
+    fl_hdec lit;
+    fl_hdec_small dst, cl;
     // symbol | code_bits << 9 | extra_bits << 13 | value << 17, 0 = not in the table.  value: the
     // byte of a literal, base length of a length code (inflate.zig:123-131), base distance of a
     // distance code (:133-140); extra_bits = 15 marks a symbol that is not a valid code
@@ -151,7 +156,8 @@ __device__ __forceinline__ uint64_t fl_br_consumed(const fl_bitr& r) {
 
 // huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order).  Runs on all
 // lanes redundantly except the LDS writes (lane 0).
-__device__ __forceinline__ int fl_hdec_generate(FL_LDS fl_hdec* d, const FL_LDS uint8_t* lens, FL_LDS uint16_t* offs,
+template <class H>
+__device__ __forceinline__ int fl_hdec_generate(FL_LDS H* d, const FL_LDS uint8_t* lens, FL_LDS uint16_t* offs,
                                                 int n, int alphabet, int max_code_bits, uint32_t lane) {
     if (alphabet == 286 && lens[256] == 0) return 10;  // MissingEndOfBlockCode
     uint32_t cnt[16];
@@ -202,7 +208,8 @@ __device__ __forceinline__ int fl_hdec_generate(FL_LDS fl_hdec* d, const FL_LDS 
 
 // huffman_decoder.zig:156-175: the symbol whose code is a prefix of `peek`
 // (stream bit order), or InvalidCode.
-__device__ __forceinline__ int fl_hdec_find(const FL_LDS fl_hdec* d, uint32_t peek, int max_code_bits, uint32_t& sym,
+template <class H>
+__device__ __forceinline__ int fl_hdec_find(const FL_LDS H* d, uint32_t peek, int max_code_bits, uint32_t& sym,
                                             uint32_t& code_bits) {
     int code = 0, first = 0, index = 0;
     for (int len = 1; len <= max_code_bits; len++) {
@@ -225,8 +232,8 @@ __device__ __forceinline__ int fl_hdec_find(const FL_LDS fl_hdec* d, uint32_t pe
 // Fill a 2^bits-entry table: entry[i] = the symbol whose code is a prefix of i (stream bit
 // order) when that code has at most `bits` bits, else 0.  Every lane decodes its share of the
 // indices with the same walk as fl_hdec_find, so table and walk cannot disagree.
-template <bool DIST>
-__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS fl_hdec* d, FL_LDS uint32_t* lut, int bits,
+template <bool DIST, class H>
+__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS uint32_t* lut, int bits,
                                                   uint32_t lane) {
     for (uint32_t i = lane; i < (1u << bits); i += 64) {
         uint32_t sym, cb;
@@ -730,7 +737,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     return rc;
 }
 
-// one symbol, inflate.zig:220-249.  Codes of up to 10 / 9 bits come out of the LDS tables built
+// one symbol, inflate.zig:220-249.  Codes of up to 10 / 8 bits come out of the LDS tables built
 // after the block header; longer ones (and invalid ones) take the canonical walk, which also
 // keeps the reference's order of errors: a miss in the table of the decoder is InvalidCode
 // before the bits are consumed (huffman_decoder.zig:156-175), running out of input is
@@ -880,16 +887,16 @@ __device__ __forceinline__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n
 
 // One wave per stream.
 template <uint32_t RING>
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
+__global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
                                                 int container, int flags, fl_crc_consts cc,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                 int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
     __shared__ fl_inflate_ws ws_mem;
     __shared__ alignas(8) uint8_t ring_mem[RING];
-    __shared__ uint32_t crc_tab_mem[256];
     __shared__ uint32_t inring_mem[FL_INF_INRING / 4];
     FL_LDS fl_inflate_ws* ws = (FL_LDS fl_inflate_ws*)&ws_mem;
-    FL_LDS uint32_t* crc_tab = (FL_LDS uint32_t*)crc_tab_mem;
+    // the CRC-32 table is only needed after the last block: it takes the place of the literal table
+    FL_LDS uint32_t* crc_tab = (FL_LDS uint32_t*)ws->lit_lut;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t lane = threadIdx.x;
