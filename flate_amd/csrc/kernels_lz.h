@@ -779,7 +779,7 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_lz_parse(const fl_chunk
 // per-block symbol histograms (block_writer.zig:455-462) and the block boundaries
 // (32768 tokens per block, deflate.zig:227-230, 268-288).  Lane = position: descriptors are
 // read coalesced, literal bytes come from the LDS window, token offsets from wave prefix sums.
-#define FL_EMIT_WAVES 8
+#define FL_EMIT_WAVES 16
 #define FL_EMIT_THREADS (64 * FL_EMIT_WAVES)
 #define FL_EMIT_SPAN (65536u / FL_EMIT_WAVES)  // positions per wave
 
@@ -787,7 +787,7 @@ __device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t 
     return (win32[off >> 2] >> (8 * (off & 3))) & 0xff;
 }
 
-__global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_lz_emit(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks, fl_params prm,
                                                               const uint32_t* __restrict__ desc_all,
                                                               const uint32_t* __restrict__ marks_all,
@@ -831,6 +831,7 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __re
     const uint32_t span0 = wave * FL_EMIT_SPAN;
     // pass 1: tokens per wave
     uint32_t cnt = 0;
+#pragma unroll 1  // (the compiler would unroll all 16 rounds and spill the descriptors it hoists)
     for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
         uint32_t d[4];
 #pragma unroll
@@ -855,6 +856,7 @@ __global__ __launch_bounds__(FL_EMIT_THREADS) void k_lz_emit(const uint8_t* __re
         total += wtot[w];
     }
     // pass 2: emit
+#pragma unroll 1
     for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
         uint32_t d[4];
 #pragma unroll

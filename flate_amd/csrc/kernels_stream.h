@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_st_scan(const fl_piece* __restrict__ pie
 // which each full block was flushed (bound[]).
 #define FL_STE_SPAN (FL_SEG / FL_EMIT_WAVES)
 #define FL_STE_WIN_DW (FL_SEG / 4 + 72)
-__global__ __launch_bounds__(FL_EMIT_THREADS) void k_st_emit(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_st_emit(const uint8_t* __restrict__ in,
                                                               const fl_chunk* __restrict__ chunks,
                                                               const fl_piece* __restrict__ pieces,
                                                               const fl_seg* __restrict__ segs, fl_params prm,
