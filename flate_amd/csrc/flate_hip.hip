@@ -59,6 +59,7 @@ struct flate_hip_ctx {
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
+    DevBuf sgroups, sgroup0, gmap, gentry;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
@@ -255,8 +256,40 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         hipLaunchKernelGGL(k_st_parse1, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg, prm,
                            (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint16_t*)h->jmp.p,
                            (uint16_t*)h->exitmap.p);
-        hipLaunchKernelGGL(k_st_stitch, dim3((npc + 63) / 64), dim3(64), 0, st, dpc, npc, dsg,
-                           (const uint16_t*)h->exitmap.p, (uint32_t*)h->entry.p);
+        // the walk from segment to segment: directly for short pieces, over groups of segments
+        // when some piece is long (kernels_stream.h)
+        uint32_t max_seg = 0;
+        for (const fl_piece& pc : t.pieces) max_seg = std::max(max_seg, pc.n_seg);
+        if (max_seg <= 4 * FL_STITCH_GROUP) {
+            hipLaunchKernelGGL(k_st_stitch, dim3((npc + 63) / 64), dim3(64), 0, st, dpc, npc, dsg,
+                               (const uint16_t*)h->exitmap.p, (uint32_t*)h->entry.p);
+        } else {
+            std::vector<fl_sgroup> groups;
+            std::vector<uint32_t> group0(npc);
+            for (uint32_t i = 0; i < npc; i++) {
+                group0[i] = (uint32_t)groups.size();
+                for (uint32_t g = 0; g * FL_STITCH_GROUP < t.pieces[i].n_seg; g++) groups.push_back(fl_sgroup{i, g});
+            }
+            const uint32_t ngr = (uint32_t)groups.size();
+            if ((rc = ensure(h, h->sgroups, sizeof(fl_sgroup) * (ngr + 1)))) return rc;
+            if ((rc = ensure(h, h->sgroup0, sizeof(uint32_t) * npc))) return rc;
+            if ((rc = ensure(h, h->gmap, ((size_t)ngr + 1) * FL_SEG_ENTRIES * sizeof(uint16_t)))) return rc;
+            if ((rc = ensure(h, h->gentry, sizeof(uint32_t) * (ngr + 1)))) return rc;
+            HIP_OK(h, hipMemcpyAsync(h->sgroups.p, groups.data(), sizeof(fl_sgroup) * ngr, hipMemcpyHostToDevice, st));
+            HIP_OK(h, hipMemcpyAsync(h->sgroup0.p, group0.data(), sizeof(uint32_t) * npc, hipMemcpyHostToDevice, st));
+            HIP_OK(h, hipStreamSynchronize(st));
+            if (ngr) {
+                hipLaunchKernelGGL(k_st_stitch_a, dim3(ngr), dim3(FL_SEG_ENTRIES), 0, st, dpc,
+                                   (const fl_sgroup*)h->sgroups.p, dsg, (const uint16_t*)h->exitmap.p,
+                                   (uint16_t*)h->gmap.p);
+                hipLaunchKernelGGL(k_st_stitch_b, dim3((npc + 63) / 64), dim3(64), 0, st, dpc, npc,
+                                   (const uint32_t*)h->sgroup0.p, dsg, (const uint16_t*)h->gmap.p,
+                                   (uint32_t*)h->gentry.p);
+                hipLaunchKernelGGL(k_st_stitch_c, dim3((ngr + 63) / 64), dim3(64), 0, st, dpc,
+                                   (const fl_sgroup*)h->sgroups.p, ngr, dsg, (const uint16_t*)h->exitmap.p,
+                                   (const uint32_t*)h->gentry.p, (uint32_t*)h->entry.p);
+            }
+        }
         hipLaunchKernelGGL(k_st_parse2, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg,
                            (const uint32_t*)h->desc.p, (const uint16_t*)h->jmp.p, (const uint32_t*)h->entry.p,
                            (uint32_t*)h->marks.p, (uint32_t*)h->segtok.p);
@@ -347,7 +380,8 @@ int flate_hip_destroy(flate_hip_handle h) {
     fold_profile(h);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
-                      &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
+                      &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
+                      &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);

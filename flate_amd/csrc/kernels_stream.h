@@ -120,6 +120,73 @@ __global__ __launch_bounds__(64) void k_st_stitch(const fl_piece* __restrict__ p
     }
 }
 
+// Pieces of many segments (a 1 GiB stream has 32768) would make that walk the longest thing in
+// the pass, so it is done in three short steps over groups of FL_STITCH_GROUP segments: every
+// group composes its segments' exit maps for all 512 possible entries (k_st_stitch_a), one thread
+// per piece walks the groups (k_st_stitch_b), one thread per group walks its segments from the
+// group's now known entry (k_st_stitch_c).
+#define FL_STITCH_GROUP 64u
+struct fl_sgroup {
+    uint32_t piece;
+    uint32_t g;  // group number inside the piece
+};
+// one step of the walk: anchor `a` (stream position) enters segment s of the piece
+__device__ __forceinline__ uint32_t fl_stitch_step(const fl_piece& pc, const fl_seg* __restrict__ segs,
+                                                   const uint16_t* __restrict__ exitmap, uint32_t s, uint32_t a) {
+    const uint32_t h0 = segs[pc.seg0 + s].h0;
+    const uint32_t slot = h0 >= pc.start ? a - h0 : 0u;  // an entry at or before the first position is slot 0
+    return h0 + (uint32_t)exitmap[(uint64_t)(pc.seg0 + s) * FL_SEG_ENTRIES + slot];
+}
+__global__ __launch_bounds__(FL_SEG_ENTRIES) void k_st_stitch_a(const fl_piece* __restrict__ pieces,
+                                                                const fl_sgroup* __restrict__ groups,
+                                                                const fl_seg* __restrict__ segs,
+                                                                const uint16_t* __restrict__ exitmap,
+                                                                uint16_t* __restrict__ gmap) {
+    const fl_sgroup gr = groups[blockIdx.x];
+    const fl_piece pc = pieces[gr.piece];
+    const uint32_t s0 = gr.g * FL_STITCH_GROUP, s1 = min(s0 + FL_STITCH_GROUP, pc.n_seg);
+    if (s1 >= pc.n_seg) return;  // the last group hands over to nobody
+    // entries of group 0 all mean "the piece start"; of later groups: h0 of the group's first segment + e
+    uint32_t a = gr.g == 0 ? pc.start : segs[pc.seg0 + s0].h0 + threadIdx.x;
+    for (uint32_t s = s0; s < s1; s++) a = fl_stitch_step(pc, segs, exitmap, s, a);
+    gmap[(uint64_t)blockIdx.x * FL_SEG_ENTRIES + threadIdx.x] = (uint16_t)(a - segs[pc.seg0 + s1].h0);
+}
+__global__ __launch_bounds__(64) void k_st_stitch_b(const fl_piece* __restrict__ pieces, uint32_t n_pieces,
+                                                    const uint32_t* __restrict__ piece_group0,
+                                                    const fl_seg* __restrict__ segs,
+                                                    const uint16_t* __restrict__ gmap,
+                                                    uint32_t* __restrict__ gentry) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_pieces) return;
+    const fl_piece pc = pieces[i];
+    const uint32_t ng = (pc.n_seg + FL_STITCH_GROUP - 1) / FL_STITCH_GROUP, g0 = piece_group0[i];
+    uint32_t a = pc.start;
+    for (uint32_t g = 0; g < ng; g++) {
+        gentry[g0 + g] = a;
+        if (g + 1 < ng) {
+            const uint32_t slot = g == 0 ? 0u : a - segs[pc.seg0 + g * FL_STITCH_GROUP].h0;
+            a = segs[pc.seg0 + (g + 1) * FL_STITCH_GROUP].h0 + (uint32_t)gmap[(uint64_t)(g0 + g) * FL_SEG_ENTRIES + slot];
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_st_stitch_c(const fl_piece* __restrict__ pieces,
+                                                    const fl_sgroup* __restrict__ groups, uint32_t n_groups,
+                                                    const fl_seg* __restrict__ segs,
+                                                    const uint16_t* __restrict__ exitmap,
+                                                    const uint32_t* __restrict__ gentry,
+                                                    uint32_t* __restrict__ entry) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_groups) return;
+    const fl_sgroup gr = groups[i];
+    const fl_piece pc = pieces[gr.piece];
+    const uint32_t s0 = gr.g * FL_STITCH_GROUP, s1 = min(s0 + FL_STITCH_GROUP, pc.n_seg);
+    uint32_t a = gentry[i];
+    for (uint32_t s = s0; s < s1; s++) {
+        entry[pc.seg0 + s] = a - segs[pc.seg0 + s].h0;
+        if (s + 1 < pc.n_seg) a = fl_stitch_step(pc, segs, exitmap, s, a);
+    }
+}
+
 // ------------------------------------------------------------------ k_st_parse2
 // One workgroup per segment: anchors of the segment (k_lz_parse phases c-e) from its entry
 // anchor, and the number of tokens they emit.  marks_all was cleared by the host: segments of

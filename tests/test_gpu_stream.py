@@ -210,3 +210,19 @@ def test_stream_passes_are_split_by_bytes():
     finally:
         del os.environ["FLATE_HIP_MAX_STREAM_PASS_MIB"]
     assert st == [0] * 5 and st2 == [0] * 5 and a == b
+
+
+def test_long_stream_takes_the_grouped_stitch():
+    # more than 256 segments in one piece: the segment walk goes over groups (k_st_stitch_a/b/c)
+    eng = engine()
+    from flate_amd import synth
+    data = synth.text(synth.SEED_TEXT + 21, 12 << 20).tobytes()
+    outs, st = eng.compress_many([data, data[: 9 << 20]], O.RAW, 6)
+    assert st == [0, 0]
+    assert outs[0] == O.compress(data, O.RAW, 6)
+    assert outs[1] == O.compress(data[: 9 << 20], O.RAW, 6)
+    got, st = eng.compress_flush(data, [5 << 20, (5 << 20) + 3, 11 << 20], True, O.RAW, 6)
+    d = O.Deflate(O.RAW, 6)
+    d.write(data[: 5 << 20]); d.flush(); d.write(data[5 << 20:(5 << 20) + 3]); d.flush()
+    d.write(data[(5 << 20) + 3:11 << 20]); d.flush(); d.write(data[11 << 20:]); d.finish()
+    assert st == 0 and got == d.output()
