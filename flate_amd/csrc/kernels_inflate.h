@@ -6,11 +6,13 @@
 // container parse (container.zig:111-166).  The status returned for a bad stream is
 // the error name the reference returns (pinned by its 40-case table, inflate.zig:487-527).
 //
-// The symbol decode of one stream is inherently serial: every lane of the wave runs
-// it in lock step (wave-uniform control flow), lane 0 owns the literal stores, and
-// the LZ77 copies and the checksum are spread over the 64 lanes.  Throughput comes
-// from many streams in flight (one per wave, several waves per CU).  Output goes
-// straight to the caller's buffer -- no 64 KiB ring as in the reference.
+// The symbol decode of one stream is serial, but a dynamic block is decoded in rounds: every
+// lane looks up the codes that would start at "current bit + lane", then the wave walks the
+// chain of real symbol starts with scalar reads of those results (fl_inf_fast_round); anything
+// unusual takes the symbol-at-a-time path, which keeps the reference's order of errors.
+// Output goes to an LDS ring and leaves in coalesced 8-byte stores; LZ77 copies and the
+// checksum are spread over the 64 lanes.  Throughput comes from many streams in flight
+// (16 per CU with the 2 KiB ring).
 #pragma once
 #include "kernels_common.h"
 

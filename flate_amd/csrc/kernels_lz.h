@@ -1,6 +1,7 @@
-// kernels_lz.h -- the LZ77 tokenizer of levels 4..9 on the GPU, for chunks of at
-// most 65535 bytes (no window slide inside a chunk: SlidingWindow.zig:36-44 is
-// never reached, deflate.zig:304-321 breaks out after the first short read).
+// kernels_lz.h -- the LZ77 tokenizer of levels 4..9 on the GPU.  The kernels of the chunk
+// path (inputs of at most 65535 bytes: SlidingWindow.zig:36-44 is never reached,
+// deflate.zig:304-321 breaks out after the first short read); k_lz_sort and k_lz_match also
+// serve, as <true> instances, the tiles of the whole-stream path (kernels_stream.h).
 //
 // Reference path: Deflate.tokenize / findMatch (deflate.zig:154-266),
 // SlidingWindow.match (SlidingWindow.zig:81-104), Lookup (Lookup.zig:12-84).
@@ -9,23 +10,21 @@
 // depend on the parse: every position is inserted exactly once, in ascending
 // order (deflate.zig:207-211,236; Lookup.zig:55-72), so chain[p] is simply the
 // nearest earlier position with the same 15-bit hash.  That makes the whole
-// tokenizer data-parallel:
+// tokenizer data-parallel (one workgroup per chunk in every kernel):
 //
-//   k_lz_sort   (1 wave / chunk)   stable LSD radix sort of the positions by hash:
-//                                  the candidates of a position are its predecessors
-//                                  in its bucket, nearest first.
-//   k_lz_match  (1 WG / chunk)     for EVERY position, the longest-match record the
-//                                  reference's findMatch would return, for the full
-//                                  chain budget and for chain >> 2 (deflate.zig:241-245),
-//                                  window staged in LDS.
-//   k_lz_parse  (1 WG / chunk)     the lazy-matching automaton (deflate.zig:154-205) as
-//                                  a function "anchor -> next anchor", resolved with
-//                                  pointer jumping instead of a serial walk; emits the
-//                                  token list, the per-block histograms and the block
-//                                  boundaries (32768 tokens, deflate.zig:227-230).
+//   k_lz_sort   stable LSD radix sort of the positions by hash: the candidates of a
+//               position are its predecessors in its bucket, nearest first.
+//   k_lz_match  for EVERY position, the longest-match record the reference's findMatch
+//               would return, for the full chain budget and for chain >> 2
+//               (deflate.zig:241-245); window staged in LDS.
+//   k_lz_parse  the lazy-matching automaton (deflate.zig:154-205) as a function
+//               "anchor -> next anchor", resolved with pointer jumping instead of a
+//               serial walk: descriptors per position + the set of anchors.
+//   k_lz_emit   token list, per-block histograms and the block boundaries
+//               (32768 tokens, deflate.zig:227-230) by prefix sums over the anchors.
 //
-// Bounds: all three are latency/issue bound integer kernels over HBM-resident
-// scratch (the window itself is read once into LDS); no MFMA.
+// Bounds: k_lz_match is bound by vector-ALU issue, the others by latency and by the traffic
+// of the per-position scratch arrays in HBM; no MFMA.
 #pragma once
 #include "kernels_common.h"
 
