@@ -17,8 +17,8 @@ Errors are FlateError subclasses named after the reference's error set
 Scope of this round: one-shot streams of any length.  At levels 4..9 an
 input longer than 65535 bytes is compressed as ONE stream by the whole-stream path
 (SURVEY.md 8f-2), byte-identical to the reference's sliding-window compressor.
-Compressor.flush (deflate.zig:335-337, levels 4..9) is a sync flush that keeps the LZ
-history: the object re-runs the stream so far with its flush points on the GPU and
+Compressor.flush (deflate.zig:335-337; 474-478 for the huffman-only / store-only
+compressors) is a sync flush that keeps the LZ history: the object re-runs the stream so far with its flush points on the GPU and
 hands the writer only the new bytes (the output of a prefix of the calls is a prefix
 of the output).
 """
@@ -111,9 +111,6 @@ class _Compressor:
         return self
 
     def _run(self, finish):
-        if self._mode < 4:
-            raise NotImplementedError("sync flush of the huffman-only / store-only compressors "
-                                      "(deflate.zig:474-478) is not on the GPU path")
         out, st = self._eng.compress_flush(bytes(self._buf), self._flushes, finish, self._container, self._mode)
         raise_for_status(st)
         # the stream so far is a prefix of the stream after more calls: hand over only what is new

@@ -59,7 +59,7 @@ struct flate_hip_ctx {
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
-    DevBuf sgroups, sgroup0, gmap, gentry;
+    DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
@@ -381,7 +381,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
-                      &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
+                      &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
@@ -531,6 +531,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         // block table of this pass
         std::vector<uint32_t> blk_chunk;
+        std::vector<fl_sblock> sblocks;  // huffman-only / store-only with flush points
         StreamTables tabs;
         uint32_t nb = 0;
         for (uint32_t i = 0; i < nc; i++) {
@@ -538,6 +539,23 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             c.first_block = nb;
             if (stream) {
                 add_stream_chunk(tabs, c, i, nb, fs);
+            } else if (fs) {
+                // SimpleCompressor (deflate.zig:449-529): the 65535-byte buffer goes out as soon as it is
+                // full; flush / finish write what it holds then, an empty block if nothing (474-484)
+                uint32_t prev = 0;
+                auto piece = [&](uint32_t start, uint32_t end, bool last) {
+                    uint32_t p = start;
+                    for (; end - p >= FL_BLOCK_BYTES; p += FL_BLOCK_BYTES) sblocks.push_back(fl_sblock{p, FL_BLOCK_BYTES, 0u});
+                    sblocks.push_back(fl_sblock{p, end - p, last ? 1u : 0u});
+                    if (!last) sblocks.push_back(fl_sblock{0u, 0u, 2u});
+                };
+                for (uint32_t k = 0; k < fs->n; k++) {
+                    piece(prev, (uint32_t)fs->pos[k], false);
+                    prev = (uint32_t)fs->pos[k];
+                }
+                if (fs->finish) piece(prev, c.in_len, true);
+                c.n_blocks = (uint32_t)sblocks.size();
+                c.pos_off = 0;
             } else {
                 c.n_blocks = mode >= 4 ? 2u : (uint32_t)(c.in_len / FL_BLOCK_BYTES + 1);  // deflate.zig:498-511, 480-484
                 c.pos_off = (uint64_t)i * FL_CHUNK_STRIDE;
@@ -555,6 +573,12 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
         HIP_OK(h, hipMemcpyAsync(h->chunks.p, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, st));
         HIP_OK(h, hipMemcpyAsync(h->blk_chunk.p, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));
+        const fl_sblock* dsb = nullptr;
+        if (!sblocks.empty()) {
+            if ((rc = ensure(h, h->sblocks, sizeof(fl_sblock) * sblocks.size()))) return rc;
+            HIP_OK(h, hipMemcpyAsync(h->sblocks.p, sblocks.data(), sizeof(fl_sblock) * sblocks.size(), hipMemcpyHostToDevice, st));
+            dsb = (const fl_sblock*)h->sblocks.p;
+        }
         // the host vectors must outlive the async copies
         HIP_OK(h, hipStreamSynchronize(st));
 
@@ -566,7 +590,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
 
         if (container != 0) {
             ProfScope ps(h, K_CHECKSUM);
-            hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, prm, h->crc, dcks);
+            hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, dcks);
         }
         if (stream) {
             if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, tabs))) return rc;
@@ -614,15 +638,15 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = (uint64_t)i * FL_CHUNK_STRIDE;
         } else if (mode == 1) {
             ProfScope ps(h, K_BYTE_HIST);
-            hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dhist);
+            hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dsb, dhist);
         }
         {
             ProfScope ps(h, K_PLAN);
             if (mode == 0)
-                hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, nb, dpl);
+                hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, dsb, nb, dpl);
             else
                 hipLaunchKernelGGL(k_plan, dim3((nb + FL_PLAN_WAVES - 1) / FL_PLAN_WAVES), dim3(64 * FL_PLAN_WAVES), 0, st,
-                                   dch, dbc, prm, (const uint32_t*)dhist, dpl);
+                                   dch, dbc, dsb, prm, (const uint32_t*)dhist, dpl);
         }
         {
             ProfScope ps(h, K_OFFSETS);
@@ -667,7 +691,7 @@ int flate_hip_compress_flush(flate_hip_handle h, const uint8_t* in, uint64_t n, 
                              uint32_t n_flush, int finish, int container, int mode, uint8_t* out, uint64_t out_cap,
                              uint64_t* out_len, int32_t* status, int memkind) {
     if (!h || !out_len || !status || (n_flush && !flush_pos)) return FLATE_HIP_E_INVALID_ARG;
-    if (mode < 4 || mode > 9) return FLATE_HIP_E_UNSUPPORTED;
+    if (!(mode == 0 || mode == 1 || (mode >= 4 && mode <= 9))) return FLATE_HIP_E_INVALID_ARG;
     if (memkind != FLATE_HIP_MEM_HOST) return FLATE_HIP_E_UNSUPPORTED;
     if (n > 0xfff00000ull) return FLATE_HIP_E_INVALID_ARG;
     uint64_t prev = 0;

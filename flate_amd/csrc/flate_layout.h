@@ -57,6 +57,14 @@ struct fl_seg {
     uint32_t h0;  // multiple of 32768
 };
 
+// huffman-only / store-only streams with sync-flush points (flate_hip_compress_flush): the block
+// table is built on the host, one entry per plan slot; ordinary batches compute the same from
+// the chunk length (block j = bytes [65535 j, ...), deflate.zig:498-511).
+struct fl_sblock {
+    uint32_t start, len;  // chunk-relative byte range
+    uint32_t flags;       // bit0: final block of the stream; bit1: the empty stored block after a flush
+};
+
 // call-wide constants
 struct fl_params {
     uint32_t n_chunks;

@@ -11,6 +11,44 @@
 #pragma once
 #include "kernels_common.h"
 
+// block b of a huffman-only / store-only pass: from the host table when there is one, else
+// block j = b - first_block of its chunk covers bytes [65535 j, 65535 (j+1)) (deflate.zig:498-511)
+struct fl_sb {
+    uint32_t start, len;
+    bool final_block, marker;
+};
+__device__ __forceinline__ fl_sb fl_simple_block(const fl_chunk& ck, const fl_sblock* __restrict__ sblocks, uint32_t b) {
+    fl_sb r;
+    if (sblocks) {
+        const fl_sblock e = sblocks[b];
+        r.start = e.start;
+        r.len = e.len;
+        r.final_block = (e.flags & 1) != 0;
+        r.marker = (e.flags & 2) != 0;
+    } else {
+        const uint32_t j = b - ck.first_block;
+        const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
+        r.start = (uint32_t)min(s, (uint64_t)ck.in_len);
+        r.len = min(FL_BLOCK_BYTES, ck.in_len - r.start);
+        r.final_block = j + 1 == ck.n_blocks;
+        r.marker = false;
+    }
+    return r;
+}
+// the empty stored block a sync flush appends (deflate.zig:474-478, 276-278)
+__device__ __forceinline__ void fl_plan_marker(fl_block_plan* plan) {
+    plan->valid = 2;
+    plan->type = FL_BLOCK_STORED;
+    plan->size_bits = 0;
+    plan->hdr_nbits = 0;
+    plan->final_block = 0;
+    plan->in_start = 0;
+    plan->in_len = 0;
+    plan->tok_start = 0;
+    plan->tok_count = 0;
+    plan->no_input = 0;
+}
+
 // ------------------------------------------------------------------ histograms
 // huffman-only mode: 256-bin byte histogram of each 65535-byte block
 // (block_writer.zig:575-585).  One workgroup (256 threads) per block; per-wave
@@ -18,6 +56,7 @@
 __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ in,
                                                    const fl_chunk* __restrict__ chunks,
                                                    const uint32_t* __restrict__ blk_chunk,
+                                                   const fl_sblock* __restrict__ sblocks,
                                                    uint32_t* __restrict__ hist /* [n_blocks][320] */) {
     __shared__ uint32_t sh[4][256];
     const uint32_t b = blockIdx.x;
@@ -26,10 +65,9 @@ __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ i
     for (uint32_t i = tid; i < 4 * 256; i += 256) (&sh[0][0])[i] = 0;
     __syncthreads();
     if (!ck.skip) {
-        const uint32_t j = b - ck.first_block;
-        const uint64_t start = (uint64_t)j * FL_BLOCK_BYTES;
-        const uint32_t len = (uint32_t)min((uint64_t)FL_BLOCK_BYTES, (uint64_t)ck.in_len - min((uint64_t)ck.in_len, start));
-        const uint8_t* src = in + ck.in_off + start;
+        const fl_sb sb = fl_simple_block(ck, sblocks, b);
+        const uint32_t len = sb.len;
+        const uint8_t* src = in + ck.in_off + sb.start;
         // head bytes up to 4-byte alignment, then dword loads
         const uint32_t mis = (uint32_t)((4 - ((uintptr_t)src & 3)) & 3);
         const uint32_t head = mis < len ? mis : len;
@@ -57,7 +95,8 @@ __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ i
 // crc(A||B) = crc(A) * x^(8|B|) + crc(B).
 __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
                                                  const fl_chunk* __restrict__ chunks,
-                                                 const uint32_t* __restrict__ blk_chunk, fl_params prm,
+                                                 const uint32_t* __restrict__ blk_chunk,
+                                                 const fl_sblock* __restrict__ sblocks, fl_params prm,
                                                  fl_crc_consts cc, uint32_t* __restrict__ part /* [n_blocks][2] */) {
     __shared__ uint32_t tab[4][256];
     const uint32_t b = blockIdx.x;
@@ -70,10 +109,9 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
         start = 0;
         len = ck.in_len;
     } else {
-        const uint32_t j = b - ck.first_block;
-        const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
-        start = (uint32_t)min(s, (uint64_t)ck.in_len);
-        len = min(FL_BLOCK_BYTES, ck.in_len - start);
+        const fl_sb sb = fl_simple_block(ck, prm.mode < 4 ? sblocks : nullptr, b);
+        start = sb.start;
+        len = sb.len;
     }
     const uint8_t* src = in + ck.in_off + start;
     const uint32_t lo = min(len, lane * 1024u), hi = min(len, lane * 1024u + 1024u);
@@ -139,7 +177,8 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
 // scratch in LDS.  mode 1: huffmanBlock; mode >= 4: BlockWriter.write.
 #define FL_PLAN_WAVES 4
 __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __restrict__ chunks,
-                                                             const uint32_t* __restrict__ blk_chunk, fl_params prm,
+                                                             const uint32_t* __restrict__ blk_chunk,
+                                                             const fl_sblock* __restrict__ sblocks, fl_params prm,
                                                              const uint32_t* __restrict__ hist,
                                                              fl_block_plan* __restrict__ plans) {
     __shared__ fl_plan_ws wss[FL_PLAN_WAVES];
@@ -160,18 +199,19 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
             if (lane == 0) plan->valid = 0;
             return;
         }
-        const uint32_t j = b - ck.first_block;
-        const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
-        const uint32_t start = (uint32_t)min(s, (uint64_t)ck.in_len);
-        const uint32_t len = min(FL_BLOCK_BYTES, ck.in_len - start);
+        const fl_sb sb = fl_simple_block(ck, sblocks, b);
+        if (sb.marker) {
+            if (lane == 0) fl_plan_marker(plan);
+            return;
+        }
         for (uint32_t i = lane; i < 256; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         fl_wave_lds_sync();
         if (lane == 0) {
             plan->valid = 1;
-            plan->in_start = start;
-            plan->tok_start = start;
-            plan->tok_count = len;
-            fl_plan_huffman_block(&ws, plan, len, j + 1 == ck.n_blocks);
+            plan->in_start = sb.start;
+            plan->tok_start = sb.start;
+            plan->tok_count = sb.len;
+            fl_plan_huffman_block(&ws, plan, sb.len, sb.final_block);
         }
     } else {
         // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel,
@@ -188,25 +228,24 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
 
 // store-only mode: every block is a stored block (deflate.zig:486-493)
 __global__ __launch_bounds__(256) void k_plan_store(const fl_chunk* __restrict__ chunks,
-                                                    const uint32_t* __restrict__ blk_chunk, uint32_t n_blocks,
+                                                    const uint32_t* __restrict__ blk_chunk,
+                                                    const fl_sblock* __restrict__ sblocks, uint32_t n_blocks,
                                                     fl_block_plan* __restrict__ plans) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
     const fl_chunk ck = chunks[blk_chunk[b]];
     fl_block_plan* plan = &plans[b];
-    const uint32_t j = b - ck.first_block;
-    const uint64_t s = (uint64_t)j * FL_BLOCK_BYTES;
-    const uint32_t start = (uint32_t)min(s, (uint64_t)ck.in_len);
-    const uint32_t len = min(FL_BLOCK_BYTES, ck.in_len - start);
+    const fl_sb sb = fl_simple_block(ck, sblocks, b);
     plan->valid = ck.skip ? 0 : 1;
     plan->type = FL_BLOCK_STORED;
     plan->size_bits = 0;
     plan->hdr_nbits = 0;
-    plan->final_block = (j + 1 == ck.n_blocks);
-    plan->in_start = start;
-    plan->in_len = len;
-    plan->tok_start = start;
-    plan->tok_count = len;
+    plan->final_block = sb.final_block ? 1 : 0;
+    plan->in_start = sb.start;
+    plan->in_len = sb.len;
+    plan->tok_start = sb.start;
+    plan->tok_count = sb.len;
+    plan->no_input = 0;
 }
 
 // ------------------------------------------------------------------ offsets

@@ -20,7 +20,7 @@
 // One-shot semantics run on the GPU, for inputs of any length: at levels 4..9 an input longer than
 // 65535 bytes is compressed as one stream by the whole-stream path (same bytes as the reference's
 // sliding-window compressor).  Compressor::flush (history-preserving sync flush,
-// deflate.zig:335-337, levels 4..9) runs on the GPU as well.  There is no CPU fallback.
+// deflate.zig:335-337, 474-478) runs on the GPU as well.  There is no CPU fallback.
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -152,7 +152,6 @@ class CompressorImpl {
     // The stream so far is re-run with its flush points; what a shorter prefix of the calls has
     // produced is a prefix of it, so only the new bytes go to the writer.
     void flush() {
-        if (mode_ < 4) throw Error(FLATE_HIP_E_UNSUPPORTED, "sync flush of the huffman-only / store-only compressors");
         flushes_.push_back(buf_.size());
         emit(Engine::instance().compress_flush(buf_, flushes_, false, container_, mode_));
     }

@@ -127,7 +127,8 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
                              int memkind);
 
 /*
- * One stream with sync-flush points (levels 4..9): what a Compressor of the reference has
+ * One stream with sync-flush points (levels 4..9, huffman-only, store-only): what a Compressor
+ * / SimpleCompressor of the reference (deflate.zig:335-337, 474-478) has
  * written after   write(in[0 .. p0]); flush(); write(in[p0 .. p1]); flush(); ...   and, when
  * `finish` is non-zero, write(rest); finish().  flush_pos: n_flush ascending stream positions
  * (<= n; equal neighbours = flush called twice).  Without `finish` the last flush point must be

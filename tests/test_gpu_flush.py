@@ -153,3 +153,22 @@ def test_flush_fuzz_against_oracle():
             assert st == 0
             want = _oracle_stream(data, flushes, finish, O.RAW, level)[0]
             assert got == want, (i, level, n, flushes, finish, len(got), len(want))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_simple_compressors_flush(mode):
+    # SimpleCompressor.flush (deflate.zig:474-478): what the buffer holds as a block of its own,
+    # then the empty stored block; blocks of 65535 bytes restart after every flush
+    eng = engine()
+    base = CASES[15][0]
+    seqs = [(b"", [0], True), (b"abc", [0, 1, 1, 3], True), (base[:1000], [1000], False),
+            (base[:200000], [65535, 131070, 131071], True), (base[:200000], [70000, 70000 + 65535], True),
+            (base[:140000], [65534, 65536], False)]
+    for container in (0, 1, 2):
+        for data, flushes, finish in seqs:
+            fl = flushes if finish or flushes[-1] == len(data) else flushes + [len(data)]
+            got, st = eng.compress_flush(data, fl, finish, container, mode)
+            assert st == 0
+            assert got == _oracle_stream(data, fl, finish, container, mode)[0], (mode, container, len(data), fl, finish)
+            if finish:
+                assert pyzlib.decompress(got, WBITS[container]) == data
