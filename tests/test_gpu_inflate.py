@@ -1,5 +1,7 @@
 """GPU parity tests of the inflate path: outputs and per-stream status (the reference's
 error names, inflate.zig:487-527) identical to the oracle's, through the C ABI."""
+import zlib as pyzlib
+
 import numpy as np
 import pytest
 
@@ -100,3 +102,62 @@ def test_gpu_compress_then_gpu_inflate():
         assert st == [0] * len(chunks)
         outs, st, _ = eng.decompress_many(comp, container, caps=[65536] * len(chunks))
         assert st == [0] * len(chunks) and b"".join(outs) == data
+
+
+def _mutants(seed, n_per_base=120):
+    """Differential fuzzing in the spirit of the reference's bin/fuzz_puff.zig: valid streams of
+    every block type, then truncated, bit-flipped, byte-smashed and spliced."""
+    from flate_amd import synth
+    rng = np.random.default_rng(seed)
+    text = synth.text(synth.SEED_TEXT + 33, 6000).tobytes()
+    rnd = rng.integers(0, 256, 700, dtype=np.uint8).tobytes()
+    bases = []
+    for data in (text, text[:300], rnd, bytes(900), b"abc" * 200, b"", text[:2000] + rnd[:300] + bytes(500)):
+        for container in (0, 1, 2):
+            for mode in (0, 1, 4, 9):
+                bases.append((container, O.compress(data, container, mode)))
+        bases.append((0, pyzlib.compress(data, 1)[2:-4]))     # zlib's encoder: fixed blocks, other tree shapes
+        bases.append((0, pyzlib.compress(data, 9)[2:-4]))
+    out = []
+    for container, b in bases:
+        out.append((container, b))
+        for _ in range(n_per_base // 10):
+            m = bytearray(b)
+            kind = int(rng.integers(0, 5))
+            if kind == 0 and len(m) > 1:
+                m = m[: int(rng.integers(0, len(m)))]
+            elif kind == 1 and len(m):
+                for _ in range(int(rng.integers(1, 4))):
+                    i = int(rng.integers(0, len(m)))
+                    m[i] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2 and len(m):
+                i = int(rng.integers(0, len(m)))
+                m[i] = int(rng.integers(0, 256))
+            elif kind == 3 and len(m) > 4:
+                i = int(rng.integers(0, len(m) - 2))
+                m[i:i + 2] = rng.integers(0, 256, 2, dtype=np.uint8).tobytes()
+            else:
+                other = bases[int(rng.integers(0, len(bases)))][1]
+                cut = int(rng.integers(0, len(m) + 1))
+                m = m[:cut] + other[int(rng.integers(0, len(other) + 1)):]
+            out.append((container, bytes(m)))
+    return out
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_differential_fuzz_against_oracle(flags):
+    # same status name as the oracle (= the reference's error for that input) on every mutant,
+    # same bytes and same consumed count whenever the stream decodes
+    eng = engine()
+    muts = _mutants(4242)
+    cap = 1 << 16
+    for container in (0, 1, 2):
+        streams = [m for c, m in muts if c == container]
+        outs, st, used = eng.decompress_many(streams, container, flags, caps=[cap] * len(streams))
+        bad = []
+        for i, s in enumerate(streams):
+            name, want, wused = O.decompress(s, container, flags, cap=cap)
+            got_name = O.STATUS[st[i]]
+            if got_name != name or (name == "Ok" and (outs[i] != want or used[i] != wused)):
+                bad.append((i, len(s), got_name, name, len(outs[i]), len(want), used[i], wused))
+        assert not bad, (container, flags, len(bad), bad[:5])
