@@ -197,3 +197,27 @@ def test_api_mirror_roundtrip():
         cmp.finish()
         d = pkg.decompressor(io.BytesIO(c.getvalue()))
         assert d.reader().read() == plain
+
+
+def test_chunk_passes_are_split_and_mixed_with_streams():
+    # FLATE_HIP_MAX_PASS_CHUNKS bounds one chunk-path pass; short and long inputs alternate, so the
+    # call becomes many passes of both kinds: same bytes as in one go
+    import os
+    eng = engine()
+    from flate_amd import synth
+    text = synth.text(synth.SEED_TEXT + 3, 1 << 20).tobytes()
+    rng = np.random.default_rng(8)
+    datas = []
+    for i in range(40):
+        n = int(rng.integers(0, 65536)) if i % 5 else int(rng.integers(65536, 200000))
+        o = int(rng.integers(0, len(text) - n))
+        datas.append(text[o:o + n])
+    a, st = eng.compress_many(datas, 1, 6)
+    os.environ["FLATE_HIP_MAX_PASS_CHUNKS"] = "3"
+    try:
+        b, st2 = eng.compress_many(datas, 1, 6)
+    finally:
+        del os.environ["FLATE_HIP_MAX_PASS_CHUNKS"]
+    assert st == [0] * 40 and st2 == [0] * 40 and a == b
+    for d, got in zip(datas[:12], a):
+        assert got == O.compress(d, 1, 6)
