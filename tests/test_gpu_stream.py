@@ -226,3 +226,20 @@ def test_long_stream_takes_the_grouped_stitch():
     d.write(data[: 5 << 20]); d.flush(); d.write(data[5 << 20:(5 << 20) + 3]); d.flush()
     d.write(data[(5 << 20) + 3:11 << 20]); d.flush(); d.write(data[11 << 20:]); d.finish()
     assert st == 0 and got == d.output()
+
+
+def test_adversarial_long_streams_match_oracle():
+    # long runs of the extreme token shapes: one match per 258 bytes, stored blocks only,
+    # every match at the maximum distance, one literal per byte with tiny alphabets
+    eng = engine()
+    rng = np.random.default_rng(123)
+    blk = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    datas = [bytes(24 << 20),
+             rng.integers(0, 256, 12 << 20, dtype=np.uint8).tobytes(),
+             blk * 384,
+             rng.integers(0, 2, 6 << 20, dtype=np.uint8).tobytes()]
+    for level in (4, 6):
+        outs, st = eng.compress_many(datas, O.GZIP, level)
+        assert st == [0] * len(datas)
+        for d, got in zip(datas, outs):
+            assert got == O.compress(d, O.GZIP, level), (level, len(d))
