@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""One-off wide parity sweep (not part of the test suite: it takes minutes of CPU oracle time):
+random structured inputs through the chunk path, the whole-stream path, sync flushes and inflate,
+all levels / containers, against the oracle.  Usage: parity_sweep.py [seed] [rounds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import _oracle as O
+from flate_amd import Engine
+from test_gpu_stream import _fuzz_input
+from test_gpu_flush import _oracle_stream
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+eng = Engine(0)
+rng = np.random.default_rng(seed)
+bad = 0
+for rd in range(rounds):
+    # chunk path: many short inputs
+    datas = []
+    for i in range(60):
+        d = _fuzz_input(int(rng.integers(1, 1 << 30)))
+        n = int(rng.integers(0, 65536))
+        o = int(rng.integers(0, max(1, len(d) - n)))
+        datas.append(d[o:o + n])
+    for mode in (0, 1, 4, 5, 6, 7, 8, 9):
+        container = int(rng.integers(0, 3))
+        outs, st = eng.compress_many(datas, container, mode)
+        for d, got, s in zip(datas, outs, st):
+            if s != 0 or got != O.compress(d, container, mode):
+                bad += 1
+                print("CHUNK MISMATCH", rd, mode, container, len(d), s)
+        back, st2, _ = eng.decompress_many(outs, container, 0, [len(d) + 8 for d in datas])
+        if st2 != [0] * len(datas) or back != datas:
+            bad += 1
+            print("INFLATE MISMATCH", rd, mode, container)
+    # whole-stream path
+    datas = [_fuzz_input(int(rng.integers(1, 1 << 30))) for _ in range(10)]
+    for mode in (4, 5, 6, 7, 8, 9):
+        container = int(rng.integers(0, 3))
+        outs, st = eng.compress_many(datas, container, mode)
+        for d, got, s in zip(datas, outs, st):
+            if s != 0 or got != O.compress(d, container, mode):
+                bad += 1
+                print("STREAM MISMATCH", rd, mode, container, len(d), s)
+    # sync flushes
+    for d in datas[:6]:
+        n = len(d)
+        k = int(rng.integers(1, 8))
+        fl = sorted(int(x) for x in rng.integers(0, n + 1, k))
+        finish = bool(rng.random() < 0.7)
+        if not finish:
+            fl = [f for f in fl if f < n] + [n]
+        mode = int(rng.choice([0, 1, 4, 6, 9]))
+        container = int(rng.integers(0, 3))
+        got, s = eng.compress_flush(d, fl, finish, container, mode)
+        if s != 0 or got != _oracle_stream(d, fl, finish, container, mode)[0]:
+            bad += 1
+            print("FLUSH MISMATCH", rd, mode, container, n, fl, finish, s)
+    print("round", rd, "done, mismatches so far:", bad, flush=True)
+print("SWEEP", "FAILED" if bad else "OK", bad)
