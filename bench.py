@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL reassembly of the output")
     ap.add_argument("--force-gather", action="store_true", help="run the reassembly path even with one rank (test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=4096)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=8192)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-decompress", action="store_true",
                     help="skip the inflate leg (one wave per stream: a single huge stream would take minutes)")
