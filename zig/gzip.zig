@@ -1,0 +1,2 @@
+//! Drop-in for ianic/flate's src/gzip.zig on the MI355X engine.
+pub usingnamespace @import("flate_hip.zig").Module(1);
