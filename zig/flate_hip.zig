@@ -63,7 +63,7 @@ fn statusToError(st: i32) Error!void {
 }
 
 /// deflate.zig:23-32
-pub const Level = enum(u4) {
+pub const DeflateLevel = enum(u4) {
     fast = 0xb,
     level_4 = 4,
     level_5 = 5,
@@ -75,9 +75,9 @@ pub const Level = enum(u4) {
     level_9 = 9,
 };
 /// deflate.zig:15-17
-pub const Options = struct { level: Level = .default };
+pub const DeflateOptions = struct { level: DeflateLevel = .default };
 
-fn modeOf(l: Level) c_int {
+fn modeOf(l: DeflateLevel) c_int {
     return switch (l) {
         .fast, .level_4 => 4,
         .level_5 => 5,
@@ -313,8 +313,8 @@ fn DecompressorImpl(comptime container: c_int, comptime ReaderType: type) type {
 /// 1 = src/gzip.zig, 2 = src/zlib.zig.
 pub fn Module(comptime container: c_int) type {
     return struct {
-        pub const Options = @import("flate_hip.zig").Options;
-        pub const Level = @import("flate_hip.zig").Level;
+        pub const Options = DeflateOptions;
+        pub const Level = DeflateLevel;
 
         /// flate.zig:10-12
         pub fn decompress(reader: anytype, writer: anytype) !void {
