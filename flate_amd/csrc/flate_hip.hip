@@ -767,7 +767,7 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
         // many streams: the small ring keeps 13 per CU in flight
         const char* e = getenv("FLATE_HIP_INFLATE_RING");
-        const bool large = e ? atoi(e) >= (int)FL_INF_RING_LARGE : n_chunks <= 3u * 256u;
+        const bool large = e ? atoi(e) >= (int)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // measured crossover
         if (large)
             hipLaunchKernelGGL(k_inflate<FL_INF_RING_LARGE>, dim3(n_chunks), dim3(64), 0, st, d_in,
                                (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
