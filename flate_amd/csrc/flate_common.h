@@ -34,6 +34,34 @@
 #define FL_TOK_DIST0(t) ((t)&0x7fffu)
 
 // consts.zig
+// On the GPU the planner is executed by all 64 lanes of a wave in lock step, redundantly (same
+// data, same control flow, same stores); only the two sorts of the Huffman code construction use
+// the lanes for what they are.  On the CPU (tests/cpu_shim) it is plain serial code.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FL_PLAN_PARALLEL 1
+#define FL_PLAN_LANE() (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#define FL_PLAN_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+// loops whose iterations are independent: strided over the lanes on the GPU; sums are
+// completed with FL_PLAN_REDUCE
+#define FL_PLAN_FOR(i, a, b) for (uint32_t i = (a) + FL_PLAN_LANE(); i < (b); i += 64)
+static __device__ __forceinline__ uint32_t fl_plan_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+#define FL_PLAN_REDUCE(v) (v) = fl_plan_wave_sum(v)
+#else
+#define FL_PLAN_PARALLEL 0
+#define FL_PLAN_FOR(i, a, b) for (uint32_t i = (a); i < (b); i++)
+#define FL_PLAN_REDUCE(v)
+#define FL_PLAN_SYNC()
+#endif
+
 #define FL_MAX_TOKENS 32768u     // consts.zig:7  tokens per block
 #define FL_MIN_MATCH 4u          // consts.zig:12
 #define FL_MAX_MATCH 258u        // consts.zig:13
@@ -164,12 +192,24 @@ FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
     const uint16_t* freq = ws->list_freq;
     fl_level_info* levels = ws->levels;
     if (max_bits > n - 1) max_bits = n - 1;
+#if FL_PLAN_PARALLEL
+    {
+        const uint32_t lane = FL_PLAN_LANE();
+        if (lane < 18) {
+            levels[lane].level = 0; levels[lane].last_freq = 0; levels[lane].next_char_freq = 0;
+            levels[lane].next_pair_freq = 0; levels[lane].needed = 0;
+        }
+        for (uint32_t i = lane; i < 17 * 16; i += 64) (&ws->leaf_counts[0][0])[i] = 0;
+        FL_PLAN_SYNC();
+    }
+#else
     for (uint32_t i = 0; i < 18; i++) {
         levels[i].level = 0; levels[i].last_freq = 0; levels[i].next_char_freq = 0;
         levels[i].next_pair_freq = 0; levels[i].needed = 0;
     }
     for (uint32_t i = 0; i < 17; i++)
         for (uint32_t j = 0; j < 16; j++) ws->leaf_counts[i][j] = 0;
+#endif
     for (uint32_t level = 1; level <= max_bits; level++) {
         levels[level].level = level;
         levels[level].last_freq = freq[1];
@@ -197,7 +237,15 @@ FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
             l->next_char_freq = (next >= n) ? 65535u : (uint32_t)freq[next];
         } else {
             l->last_freq = l->next_pair_freq;
+#if FL_PLAN_PARALLEL
+            {
+                const uint32_t lane = FL_PLAN_LANE();
+                if (lane < level) ws->leaf_counts[level][lane] = ws->leaf_counts[level - 1][lane];
+                FL_PLAN_SYNC();
+            }
+#else
             for (uint32_t j = 0; j < level; j++) ws->leaf_counts[level][j] = ws->leaf_counts[level - 1][j];
+#endif
             levels[l->level - 1].needed = 2;
         }
         l->needed -= 1;
@@ -220,13 +268,33 @@ FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
     }
 }
 
-// huffman_encoder.zig:62-95 + 251-278.  Serial (one lane); insertion sorts stand
-// in for std.mem.sort -- both orders are total, so the result is identical.
+// huffman_encoder.zig:62-95 + 251-278.
 FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq,
                             uint32_t max_bits, fl_hcode* codes) {
     uint16_t* lsym = ws->list_sym;
     uint16_t* lfrq = ws->list_freq;
     uint32_t count = 0;
+#if FL_PLAN_PARALLEL
+    {
+        const uint32_t lane = FL_PLAN_LANE();
+        const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        for (uint32_t base = 0; base < nfreq; base += 64) {  // stream compaction, 64 symbols per step
+            const uint32_t i = base + lane;
+            const uint32_t f = i < nfreq ? freq[i] : 0u;
+            const uint64_t used = __ballot(f != 0);
+            if (f != 0) {
+                const uint32_t at = count + (uint32_t)__popcll(used & below);
+                lsym[at] = (uint16_t)i;
+                lfrq[at] = (uint16_t)f;
+            } else if (i < nfreq) {
+                codes[i].len = 0;
+                codes[i].code = 0;
+            }
+            count += (uint32_t)__popcll(used);
+        }
+        FL_PLAN_SYNC();
+    }
+#else
     for (uint32_t i = 0; i < nfreq; i++) {
         if (freq[i] != 0) {
             lsym[count] = (uint16_t)i;
@@ -237,6 +305,7 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
             codes[i].code = 0;
         }
     }
+#endif
     if (count <= 2) {
         for (uint32_t i = 0; i < count; i++) {
             codes[lsym[i]].code = (uint16_t)i;
@@ -244,9 +313,39 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
         }
         return;
     }
-    // sort by (freq, symbol): the list is already in symbol order, so a stable
-    // insertion sort on freq alone gives the (freq, symbol) order (:355-361)
-    for (uint32_t i = 1; i < count; i++) {
+    // sort by (freq, symbol) (:355-361); the list is in symbol order, so the sort has to be
+    // stable on freq alone
+#if FL_PLAN_PARALLEL
+    {
+        // rank sort: every lane places its own (at most 5) elements: rank = how many elements
+        // come before it.  All reads happen before the first write.
+        const uint32_t lane = FL_PLAN_LANE();
+        uint16_t ms[5], mf[5];
+        uint32_t rk[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const uint32_t e = lane + 64 * k;
+            ms[k] = e < count ? lsym[e] : (uint16_t)0;
+            mf[k] = e < count ? lfrq[e] : (uint16_t)0;
+            rk[k] = 0;
+        }
+        for (uint32_t j = 0; j < count; j++) {
+            const uint32_t fj = lfrq[j];
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) rk[k] += (fj < mf[k] || (fj == mf[k] && j < lane + 64 * k)) ? 1u : 0u;
+        }
+        FL_PLAN_SYNC();
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            if (lane + 64 * k < count) {
+                lsym[rk[k]] = ms[k];
+                lfrq[rk[k]] = mf[k];
+            }
+        }
+        FL_PLAN_SYNC();
+    }
+#else
+    for (uint32_t i = 1; i < count; i++) {  // insertion sort stands in for std.mem.sort: the order is total
         uint16_t s = lsym[i], f = lfrq[i];
         uint32_t j = i;
         while (j > 0 && lfrq[j - 1] > f) {
@@ -257,6 +356,7 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
         lsym[j] = s;
         lfrq[j] = f;
     }
+#endif
     fl_huff_bit_counts(ws, count, max_bits);
     uint32_t used_bits = max_bits > count - 1 ? count - 1 : max_bits;
     uint32_t code = 0;
@@ -267,6 +367,22 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
         if (n == 0 || bits == 0) continue;
         // the `bits` most frequent remaining symbols get length n, codes in symbol order
         uint32_t lo = list_len - bits;
+#if FL_PLAN_PARALLEL
+        {
+            // no need to sort: a symbol's code is the first code of the length plus the number
+            // of smaller symbols in the chunk
+            const uint32_t lane = FL_PLAN_LANE();
+            for (uint32_t e = lo + lane; e < list_len; e += 64) {
+                const uint32_t sy = lsym[e];
+                uint32_t r = 0;
+                for (uint32_t j = lo; j < list_len; j++) r += lsym[j] < sy ? 1u : 0u;
+                codes[sy].code = fl_bit_reverse((uint16_t)((code + r) & 0xffffu), n);
+                codes[sy].len = (uint16_t)n;
+            }
+            code = (code + bits) & 0xffffu;
+            FL_PLAN_SYNC();
+        }
+#else
         for (uint32_t i = lo + 1; i < list_len; i++) {  // sort chunk by symbol
             uint16_t s = lsym[i];
             uint32_t j = i;
@@ -281,14 +397,16 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
             codes[lsym[k]].len = (uint16_t)n;
             code = (code + 1) & 0xffffu;
         }
+#endif
         list_len -= bits;
     }
 }
 
 FL_HD uint32_t fl_huff_bit_length(const fl_hcode* codes, const uint16_t* freq, uint32_t n) {
     uint32_t total = 0;  // huffman_encoder.zig:97-105
-    for (uint32_t i = 0; i < n; i++)
+    FL_PLAN_FOR(i, 0, n)
         if (freq[i] != 0) total += (uint32_t)freq[i] * codes[i].len;
+    FL_PLAN_REDUCE(total);
     return total;
 }
 
@@ -431,18 +549,21 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
     const bool storable = in_len != FL_NO_INPUT && in_len <= FL_MAX_STORE;
     const uint32_t stored_size = storable ? (in_len + 5) * 8 : 0;
     uint32_t real_extra_bits = 0;
-    for (uint32_t lc = 257 + 8; lc < num_literals; lc++)
+    FL_PLAN_FOR(lc, 257 + 8, num_literals)
         real_extra_bits += (uint32_t)ws->lit_freq[lc] * fl_len_extra_bits(lc - 257);
-    for (uint32_t dc = 4; dc < num_distances; dc++)
+    FL_PLAN_FOR(dc, 4, num_distances)
         real_extra_bits += (uint32_t)ws->dist_freq[dc] * fl_dist_extra_bits(dc);
+    FL_PLAN_REDUCE(real_extra_bits);
     // the estimates only include the extra bits when a stored block is possible (:317-334)
     const uint32_t extra_bits = storable ? real_extra_bits : 0;
     // fixedSize (:206-211)
-    uint32_t fixed_bits = 3 + extra_bits;
-    for (uint32_t i = 0; i < FL_NUM_LIT; i++)
-        if (ws->lit_freq[i]) fixed_bits += (uint32_t)ws->lit_freq[i] * fl_fixed_lit_code(i).len;
-    for (uint32_t i = 0; i < FL_NUM_DIST; i++)
-        if (ws->dist_freq[i]) fixed_bits += (uint32_t)ws->dist_freq[i] * 5u;
+    uint32_t fixed_sum = 0;
+    FL_PLAN_FOR(i, 0, FL_NUM_LIT)
+        if (ws->lit_freq[i]) fixed_sum += (uint32_t)ws->lit_freq[i] * fl_fixed_lit_code(i).len;
+    FL_PLAN_FOR(i, 0, FL_NUM_DIST)
+        if (ws->dist_freq[i]) fixed_sum += (uint32_t)ws->dist_freq[i] * 5u;
+    FL_PLAN_REDUCE(fixed_sum);
+    const uint32_t fixed_bits = 3 + extra_bits + fixed_sum;
     uint32_t size = fixed_bits;
     uint32_t type = FL_BLOCK_FIXED;
 
@@ -472,12 +593,12 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
     w.nbits = 0;
     if (type == FL_BLOCK_DYNAMIC) {
         fl_emit_dynamic_header(ws, &w, num_literals, num_distances, num_codegens, eof);
-        for (uint32_t i = 0; i < FL_NUM_LIT; i++) plan->lit[i] = ws->lit_codes[i];
-        for (uint32_t i = 0; i < FL_NUM_DIST; i++) plan->dist[i] = ws->dist_codes[i];
+        FL_PLAN_FOR(i, 0, FL_NUM_LIT) plan->lit[i] = ws->lit_codes[i];
+        FL_PLAN_FOR(i, 0, FL_NUM_DIST) plan->dist[i] = ws->dist_codes[i];
     } else if (type == FL_BLOCK_FIXED) {
         fl_hdr_put(&w, eof ? 3u : 2u, 3);  // fixedHeader :293-300
-        for (uint32_t i = 0; i < FL_NUM_LIT; i++) plan->lit[i] = fl_fixed_lit_code(i);
-        for (uint32_t i = 0; i < FL_NUM_DIST; i++) plan->dist[i] = fl_fixed_dist_code(i);
+        FL_PLAN_FOR(i, 0, FL_NUM_LIT) plan->lit[i] = fl_fixed_lit_code(i);
+        FL_PLAN_FOR(i, 0, FL_NUM_DIST) plan->dist[i] = fl_fixed_dist_code(i);
     }
     fl_hdr_finish(&w);
     plan->hdr_nbits = w.nbits;
@@ -486,16 +607,18 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
 // ---- planner for a huffman-only block: huffmanBlock, block_writer.zig:524-572 ----
 // ws->lit_freq[0..255] holds the byte histogram of the block's input.
 FL_HD void fl_plan_huffman_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_len, uint32_t eof) {
-    for (uint32_t i = 256; i < FL_NUM_LIT; i++) ws->lit_freq[i] = 0;
+    FL_PLAN_FOR(i, 256, FL_NUM_LIT) ws->lit_freq[i] = 0;
+    FL_PLAN_SYNC();
     ws->lit_freq[FL_EOB] = 1;
     const uint32_t num_literals = FL_EOB + 1;
     const uint32_t num_distances = 1;
     // huff_distance (huffman_encoder.zig:340-348): symbol 0 with a 1-bit code
-    for (uint32_t i = 0; i < FL_NUM_DIST; i++) {
+    FL_PLAN_FOR(i, 0, FL_NUM_DIST) {
         ws->dist_freq[i] = 0;
         ws->dist_codes[i].code = 0;
         ws->dist_codes[i].len = 0;
     }
+    FL_PLAN_SYNC();
     ws->dist_freq[0] = 1;
     ws->dist_codes[0].len = 1;
     fl_huff_generate(ws, ws->lit_freq, FL_NUM_LIT, 15, ws->lit_codes);
@@ -523,7 +646,7 @@ FL_HD void fl_plan_huffman_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t i
     w.nbits = 0;
     if (type == FL_BLOCK_DYNAMIC) {
         fl_emit_dynamic_header(ws, &w, num_literals, num_distances, num_codegens, eof);
-        for (uint32_t i = 0; i < FL_NUM_LIT; i++) plan->lit[i] = ws->lit_codes[i];
+        FL_PLAN_FOR(i, 0, FL_NUM_LIT) plan->lit[i] = ws->lit_codes[i];
     }
     fl_hdr_finish(&w);
     plan->hdr_nbits = w.nbits;

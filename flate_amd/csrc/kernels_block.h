@@ -206,13 +206,12 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         }
         for (uint32_t i = lane; i < 256; i += 64) ws.lit_freq[i] = (uint16_t)hist[(uint64_t)b * 320 + i];
         fl_wave_lds_sync();
-        if (lane == 0) {
-            plan->valid = 1;
-            plan->in_start = sb.start;
-            plan->tok_start = sb.start;
-            plan->tok_count = sb.len;
-            fl_plan_huffman_block(&ws, plan, sb.len, sb.final_block);
-        }
+        // all lanes run the planner in lock step (flate_common.h: only its sorts are lane-parallel)
+        plan->valid = 1;
+        plan->in_start = sb.start;
+        plan->tok_start = sb.start;
+        plan->tok_count = sb.len;
+        fl_plan_huffman_block(&ws, plan, sb.len, sb.final_block);
     } else {
         // token block: metadata (valid, tok_*, in_*, final_block) was written by the emit kernel,
         // valid = 0 for the slots of skipped chunks
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         fl_wave_lds_sync();
         // in_len == FL_NO_INPUT: a window slide since the previous flush took the raw bytes away
         // (SlidingWindow.zig:119-123); only whole-stream passes ever set it
-        if (lane == 0) fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);
+        fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);  // all lanes, in lock step
     }
 }
 
