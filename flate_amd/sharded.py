@@ -70,7 +70,10 @@ class OutputGather:
         self.local_cap = (int(local_cap) + 15) & ~15
         self.packed = torch.empty(self.local_cap + 16, dtype=torch.uint8, device=device)
         self.sizes = torch.zeros(world, dtype=torch.int64, device=device)
-        self.gathered = torch.empty((world, self.local_cap), dtype=torch.uint8, device=device)
+        # one flat buffer: a step uses its first world * width bytes as `world` equal slices, which
+        # is what all_gather_into_tensor wants (no per-rank tensor list, no staging copy)
+        self.gathered = torch.empty(world * self.local_cap, dtype=torch.uint8, device=device)
+        self.width = 0
         self.dst_off = None
 
     def run(self, out, out_off, out_len):
@@ -81,14 +84,11 @@ class OutputGather:
         if self.dst_off is None or self.dst_off.numel() != n + 1:
             self.dst_off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
         pack_streams(self.engine, out, out_off, out_len, self.packed, self.dst_off)
-        mine = self.dst_off[n:n + 1].clone()
-        parts = [self.sizes[r:r + 1] for r in range(self.world)]
-        dist.all_gather(parts, mine)
+        dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
         sizes = [int(x) for x in self.sizes.cpu().tolist()]
-        width = (max(sizes) + 15) & ~15  # same slice width on every rank
-        views = [self.gathered[r, :width] for r in range(self.world)]
-        dist.all_gather(views, self.packed[:width])
+        self.width = (max(sizes) + 15) & ~15  # same slice width on every rank
+        dist.all_gather_into_tensor(self.gathered[: self.world * self.width], self.packed[: self.width])
         return sizes
 
     def shard(self, r, sizes):
-        return self.gathered[r, :sizes[r]]
+        return self.gathered[r * self.width: r * self.width + sizes[r]]
