@@ -618,6 +618,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                         if (x == 0 && maxlen > 8) dmask |= 1u << (kk0 + u - 1);
                     }
                 }
+                // When most lanes are waiting for the window anyway (runs, long repeats), one round
+                // serves them all: do it now; a match of `nice` bytes then ends the walk early.
+                if (__popcll(__ballot(dmask != 0)) >= 40) flush_deep();
             }
             flush_deep();
         }
