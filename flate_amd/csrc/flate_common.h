@@ -529,8 +529,13 @@ FL_HD uint64_t fl_stored_end(uint64_t off, uint32_t len) {
 // slice; FL_NO_INPUT stands for the Zig `null` (a window slide happened since the
 // last flush, SlidingWindow.zig:119-123 -- never the case for chunks <= 65535
 // bytes, but the reference's golden "-noinput" vectors exercise it).
+// `dynamic_only` selects the reference's other token-block writer, BlockWriter.dynamicBlock
+// (block_writer.zig:395-432: no fixed-code candidate, extra bits left out of the estimate, stored
+// when the input does not shrink by 1/16).  The reference's compressor never calls it; its golden
+// ".dyn" vectors do (block_writer.zig:645), and so does the debug seam flate_hip_debug_write_block.
 #define FL_NO_INPUT 0xffffffffu
-FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_len, uint32_t eof) {
+FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_len, uint32_t eof,
+                               bool dynamic_only = false) {
     ws->lit_freq[FL_EOB] += 1;
     uint32_t num_literals = FL_NUM_LIT;
     while (ws->lit_freq[num_literals - 1] == 0) num_literals--;
@@ -555,7 +560,7 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
         real_extra_bits += (uint32_t)ws->dist_freq[dc] * fl_dist_extra_bits(dc);
     FL_PLAN_REDUCE(real_extra_bits);
     // the estimates only include the extra bits when a stored block is possible (:317-334)
-    const uint32_t extra_bits = storable ? real_extra_bits : 0;
+    const uint32_t extra_bits = (storable && !dynamic_only) ? real_extra_bits : 0;
     // fixedSize (:206-211)
     uint32_t fixed_sum = 0;
     FL_PLAN_FOR(i, 0, FL_NUM_LIT)
@@ -573,11 +578,15 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
     uint32_t dyn_size = fl_dynamic_header_size(ws, &num_codegens) +
                         fl_huff_bit_length(ws->lit_codes, ws->lit_freq, FL_NUM_LIT) +
                         fl_huff_bit_length(ws->dist_codes, ws->dist_freq, FL_NUM_DIST) + extra_bits;
-    if (dyn_size < size) {  // ties go to fixed (:362)
+    if (dyn_size < size || dynamic_only) {  // ties go to fixed (:362)
         size = dyn_size;
         type = FL_BLOCK_DYNAMIC;
     }
-    if (storable && stored_size < size) type = FL_BLOCK_STORED;  // ties go to Huffman (:369)
+    if (dynamic_only) {
+        if (storable && stored_size < size + (size >> 4)) type = FL_BLOCK_STORED;  // :424
+    } else if (storable && stored_size < size) {
+        type = FL_BLOCK_STORED;  // ties go to Huffman (:369)
+    }
 
     plan->type = type;
     // The reference's estimate counts the phantom distance symbol of a block

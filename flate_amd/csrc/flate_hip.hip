@@ -852,4 +852,74 @@ int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tok
     return (int64_t)n;
 }
 
+int flate_hip_debug_write_block(flate_hip_handle h, const uint32_t* tokens, uint32_t n_tokens, const uint8_t* input,
+                                uint32_t input_len, int eof, int dynamic_only, uint8_t* out, uint64_t out_cap,
+                                uint64_t* out_len) {
+    if (!h || !out || !out_len || (n_tokens && !tokens) || n_tokens > FL_MAX_TOKENS) return FLATE_HIP_E_INVALID_ARG;
+    const bool has_input = input != nullptr;
+    if (has_input && input_len > 0xfffffff0u) return FLATE_HIP_E_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    hipStream_t st = h->stream;
+    int rc;
+    const uint32_t in_len = has_input ? input_len : 0u;
+    const uint64_t cap4 = (out_cap + 3) & ~3ull;
+    if ((rc = ensure(h, h->chunks, sizeof(fl_chunk)))) return rc;
+    if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->plans, sizeof(fl_block_plan)))) return rc;
+    if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320))) return rc;
+    if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2))) return rc;
+    if ((rc = ensure(h, h->tokens, sizeof(uint32_t) * ((size_t)n_tokens + 1)))) return rc;
+    if ((rc = ensure(h, h->st_in, (size_t)in_len + 16))) return rc;
+    if ((rc = ensure(h, h->st_out, cap4 + 16))) return rc;
+    if ((rc = ensure(h, h->st_outlen, sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(h, h->st_status, sizeof(int32_t)))) return rc;
+    fl_chunk ck{};
+    ck.in_off = 0;
+    ck.out_off = 0;
+    ck.out_cap = out_cap;
+    ck.in_len = in_len;
+    ck.n_blocks = 1;
+    fl_block_plan plan{};
+    plan.valid = 1;
+    plan.tok_count = n_tokens;
+    plan.in_len = has_input ? in_len : FL_NO_INPUT;  // Zig null: the block cannot be stored
+    plan.final_block = eof ? 1u : 0u;
+    const uint32_t zero = 0;
+    fl_params prm{};
+    level_args(6, prm);
+    prm.n_chunks = 1;
+    prm.n_blocks = 1;
+    prm.container = 0;
+    prm.mode = 6;
+    prm.stream = 1;  // plain block numbering in k_plan
+    prm.plan_dynamic_only = dynamic_only ? 1u : 0u;
+    HIP_OK(h, hipMemcpyAsync(h->chunks.p, &ck, sizeof ck, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(h->blk_chunk.p, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(h->plans.p, &plan, sizeof plan, hipMemcpyHostToDevice, st));
+    if (n_tokens)
+        HIP_OK(h, hipMemcpyAsync(h->tokens.p, tokens, sizeof(uint32_t) * n_tokens, hipMemcpyHostToDevice, st));
+    if (in_len) HIP_OK(h, hipMemcpyAsync(h->st_in.p, input, in_len, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemsetAsync(h->st_out.p, 0, cap4 + 16, st));
+    HIP_OK(h, hipStreamSynchronize(st));  // the host structs must outlive the async copies
+    hipLaunchKernelGGL(k_dbg_token_hist, dim3(1), dim3(256), 0, st, (const uint32_t*)h->tokens.p, n_tokens,
+                       (uint32_t*)h->hist.p);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(64 * FL_PLAN_WAVES), 0, st, (const fl_chunk*)h->chunks.p,
+                       (const uint32_t*)h->blk_chunk.p, (const fl_sblock*)nullptr, prm, (const uint32_t*)h->hist.p,
+                       (fl_block_plan*)h->plans.p);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, st, (const fl_chunk*)h->chunks.p, prm, h->crc,
+                       (fl_block_plan*)h->plans.p, (const uint32_t*)h->cks.p, (uint8_t*)h->st_out.p,
+                       (uint64_t*)h->st_outlen.p, (int32_t*)h->st_status.p);
+    hipLaunchKernelGGL(k_encode<true>, dim3(1), dim3(64 * FL_ENC_WAVES), 0, st, (const uint8_t*)h->st_in.p,
+                       (const fl_chunk*)h->chunks.p, (const uint32_t*)h->blk_chunk.p,
+                       (const fl_block_plan*)h->plans.p, (const uint32_t*)h->tokens.p, (uint32_t*)h->st_out.p);
+    HIP_OK(h, hipGetLastError());
+    int32_t status = 0;
+    HIP_OK(h, hipMemcpyAsync(out_len, h->st_outlen.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(h, hipMemcpyAsync(&status, h->st_status.p, sizeof status, hipMemcpyDeviceToHost, st));
+    HIP_OK(h, hipStreamSynchronize(st));
+    if (status != 0) return FLATE_HIP_E_INVALID_ARG;  // out_cap too small
+    if (*out_len) HIP_OK(h, hipMemcpy(out, h->st_out.p, *out_len, hipMemcpyDeviceToHost));
+    return FLATE_HIP_OK;
+}
+
 }  // extern "C"

@@ -75,6 +75,7 @@ struct fl_params {
     uint32_t good, lazy, nice, chain;
     uint32_t dbg;     // tuning experiments only (FLATE_HIP_DBG), 0 in production
     uint32_t stream;  // non-zero: whole-stream pass (kernels_stream.h)
+    uint32_t plan_dynamic_only;  // debug seam only: plan token blocks as BlockWriter.dynamicBlock does
 };
 
 // CRC-32 helper constants computed on the host once (reflected representation,

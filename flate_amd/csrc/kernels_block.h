@@ -88,6 +88,26 @@ __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ i
     hist[(uint64_t)b * 320 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
 }
 
+// debug seam (flate_hip_debug_write_block): histogram of a caller-supplied token list, as the
+// tokenizer's emit kernels build it (block_writer.zig:444-462)
+__global__ __launch_bounds__(256) void k_dbg_token_hist(const uint32_t* __restrict__ tokens, uint32_t n,
+                                                        uint32_t* __restrict__ hist /* [320] */) {
+    __shared__ uint32_t sh[320];
+    for (uint32_t i = threadIdx.x; i < 320; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t t = tokens[i];
+        if (FL_TOK_IS_MATCH(t)) {
+            atomicAdd(&sh[257 + fl_len_index(FL_TOK_LENLIT(t))], 1u);
+            atomicAdd(&sh[286 + fl_dist_code(FL_TOK_DIST0(t))], 1u);
+        } else {
+            atomicAdd(&sh[FL_TOK_LENLIT(t)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 320; i += 256) hist[i] = sh[i];
+}
+
 // ------------------------------------------------------------------ checksums
 // Per-block CRC-32 (gzip) or Adler-32 partial sums (zlib) of the raw input
 // (deflate.zig:314,507 -> container.zig:168-206).  One wave per 65535-byte block,
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(64 * FL_PLAN_WAVES) void k_plan(const fl_chunk* __r
         fl_wave_lds_sync();
         // in_len == FL_NO_INPUT: a window slide since the previous flush took the raw bytes away
         // (SlidingWindow.zig:119-123); only whole-stream passes ever set it
-        fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block);  // all lanes, in lock step
+        fl_plan_token_block(&ws, plan, plan->in_len, plan->final_block, prm.plan_dynamic_only != 0);  // all lanes, in lock step
     }
 }
 

@@ -157,6 +157,23 @@ class Engine:
         self._L.flate_hip_debug_phase_cycles(self._h, buf.ctypes.data, 64)
         return buf
 
+    def debug_write_block(self, tokens, input_bytes, eof, dynamic_only=False):
+        """One block from a token list through the device planner / offset scan / bit packer
+        (input_bytes None = the Zig null).  Returns the block's bytes."""
+        tok = np.ascontiguousarray(tokens, dtype=np.uint32)
+        inp = None if input_bytes is None else np.frombuffer(bytes(input_bytes), dtype=np.uint8)
+        cap = 8 * tok.size + (0 if inp is None else inp.size) + 1024
+        out = np.zeros(cap + 8, dtype=np.uint8)
+        out_len = np.zeros(1, dtype=np.uint64)
+        keep = np.zeros(1, dtype=np.uint8)  # a non-NULL pointer for an empty input
+        rc = self._L.flate_hip_debug_write_block(
+            self._h, tok.ctypes.data if tok.size else None, tok.size,
+            None if inp is None else (inp.ctypes.data if inp.size else keep.ctypes.data),
+            0 if inp is None else inp.size, int(bool(eof)), int(bool(dynamic_only)), out.ctypes.data, cap,
+            out_len.ctypes.data)
+        self._check(rc, "flate_hip_debug_write_block")
+        return out[: int(out_len[0])].tobytes()
+
     def debug_tokens(self, chunk):
         """Token list the tokenizer kernels produced for `chunk` of the last level 4..9 call."""
         buf = np.zeros(65536, dtype=np.uint32)

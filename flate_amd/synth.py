@@ -5,6 +5,7 @@
   text(seed, n)        T: "enwik-like" -- Zipf draws from a 4096-word vocabulary with
                        punctuation and wiki/XML-ish markup tokens
   silesia_like(seed,n) S: mixed segments (text, binary records, tag-heavy XML, random, sparse zeros)
+  tar_like(seed, n)    TAR: ustar headers + text bodies + zero padding (stand-in for ziglang.tar)
 """
 import numpy as np
 
@@ -151,6 +152,22 @@ def silesia_like(seed, n):
         pos += size
         seg += 1
     return out
+
+
+TAR_BYTES = 177_244_160  # ziglang.tar of the reference's benchmarks (inflate_bench.zig:14)
+
+
+def tar_like(seed=SEED_TAR, n=TAR_BYTES):
+    """TAR(seed): stand-in for ziglang.tar (not obtainable offline): text bodies, every 24 KiB a
+    512-byte ustar header, each entry closed by 4 KiB of zero padding."""
+    body = text(seed, n)
+    hdr = np.zeros(512, dtype=np.uint8)
+    hdr[:100] = np.frombuffer(b"src/flate/deflate.zig".ljust(100, b"\0"), dtype=np.uint8)
+    hdr[257:263] = np.frombuffer(b"ustar\0", dtype=np.uint8)
+    for off in range(0, n - 8192, 24576):
+        body[off:off + 512] = hdr
+        body[off + 20480:off + 24576] = 0
+    return body
 
 
 def split_offsets(n, chunk):

@@ -185,6 +185,16 @@ int flate_hip_profile_reset(flate_hip_handle h);
  * dist-1) into host memory.  Returns the token count or a negative error. */
 int64_t flate_hip_debug_tokens(flate_hip_handle h, uint32_t chunk, uint32_t* tokens, uint64_t cap);
 
+/* ---- test seam for the block writer alone (the reference tests it the same way: token lists
+ * straight into BlockWriter.write / dynamicBlock, block_writer.zig:599-706).  Runs the DEVICE
+ * planner, offset scan and bit packer on a caller-supplied token list (<= 32768 tokens, encoding as
+ * above) and optional raw input (`input` NULL = the Zig `null`: the block cannot be stored) and
+ * writes the block, padded to a byte as BlockWriter.flush does, to host memory.  dynamic_only = 1
+ * plans the block as BlockWriter.dynamicBlock does (block_writer.zig:395-432). */
+int flate_hip_debug_write_block(flate_hip_handle h, const uint32_t* tokens, uint32_t n_tokens,
+                                const uint8_t* input, uint32_t input_len, int eof, int dynamic_only,
+                                uint8_t* out, uint64_t out_cap, uint64_t* out_len);
+
 /* Tuning aid: shader-clock timestamps that workgroup 0 of the tokenizer kernels took at its
  * phase boundaries during the last call (slots: sort 0-7, match 8-10, parse 16-23). */
 int flate_hip_debug_phase_cycles(flate_hip_handle h, uint64_t* out, int n);

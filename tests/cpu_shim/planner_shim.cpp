@@ -10,7 +10,8 @@ extern "C" {
 
 int shim_plan_sizeof() { return (int)sizeof(fl_block_plan); }
 
-// mode 0: token block (BlockWriter.write); mode 1: huffman-only block.
+// mode 0: token block (BlockWriter.write); mode 1: huffman-only block; mode 2: token block as
+// BlockWriter.dynamicBlock plans it.
 void shim_plan_block(int mode, const uint16_t* lit_freq, const uint16_t* dist_freq, uint32_t in_len,
                      uint32_t eof, fl_block_plan* plan) {
     static fl_plan_ws ws;
@@ -18,8 +19,8 @@ void shim_plan_block(int mode, const uint16_t* lit_freq, const uint16_t* dist_fr
     memcpy(ws.lit_freq, lit_freq, sizeof ws.lit_freq);
     memcpy(ws.dist_freq, dist_freq, sizeof ws.dist_freq);
     memset(plan, 0, sizeof *plan);
-    if (mode == 0)
-        fl_plan_token_block(&ws, plan, in_len, eof);
+    if (mode == 0 || mode == 2)
+        fl_plan_token_block(&ws, plan, in_len, eof, mode == 2);
     else
         fl_plan_huffman_block(&ws, plan, in_len, eof);
 }

@@ -221,3 +221,82 @@ def test_chunk_passes_are_split_and_mixed_with_streams():
     assert st == [0] * 40 and st2 == [0] * 40 and a == b
     for d, got in zip(datas[:12], a):
         assert got == O.compress(d, 1, 6)
+
+
+# ---- BASELINE.json configs[2]: gzip level 9 on the TAR-like workload ----
+def test_config3_gzip_l9_tar_like_chunks():
+    """Every 65535-byte chunk of 4 MiB of the TAR-like buffer, gzip level 9 == oracle."""
+    from flate_amd import synth
+    eng = engine()
+    data = synth.tar_like(synth.SEED_TAR, 4 << 20).tobytes()
+    chunks = [data[i:i + 65535] for i in range(0, len(data), 65535)]
+    outs, st = eng.compress_many(chunks, O.GZIP, 9)
+    assert st == [0] * len(chunks)
+    for i, (c, got) in enumerate(zip(chunks, outs)):
+        assert got == O.compress(c, O.GZIP, 9), "chunk %d" % i
+        assert pyzlib.decompress(got, 31) == c
+
+
+def test_config3_gzip_l9_tar_like_one_stream():
+    """The same 4 MiB + a ragged tail as ONE gzip level 9 stream (whole-stream path) == oracle, every byte."""
+    from flate_amd import synth
+    eng = engine()
+    data = synth.tar_like(synth.SEED_TAR, (4 << 20) + 12345).tobytes()
+    outs, st = eng.compress_many([data], O.GZIP, 9)
+    assert st == [0]
+    assert outs[0] == O.compress(data, O.GZIP, 9)
+    assert pyzlib.decompress(outs[0], 31) == data
+
+
+# ---- the reference's block-writer goldens through the DEVICE planner / bit packer ----
+def _bw_cases():
+    with open(os.path.join(GOLDEN, "block_writer_tokens.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        c["tok"] = np.array([O.tok_lit(t[0]) if len(t) == 1 else O.tok_match(t[0], t[1])
+                             for t in c["tokens"]], dtype=np.uint32)
+    return cases
+
+
+@pytest.mark.parametrize("fn", ["wb", "dyn"])
+def test_block_writer_goldens_through_the_device_planner(fn):
+    """block_writer.zig:599-706: token lists straight into BlockWriter.write (wb) / dynamicBlock (dyn),
+    with and without the raw input, eof 0/1 -- 17 golden files each, run by k_plan / k_offsets / k_encode."""
+    eng = engine()
+    checked = 0
+    for c in _bw_cases():
+        variants = []
+        if c["input"] and c["want"]:
+            variants.append((golden("block_writer", c["input"]), c["want"]))
+        variants.append((None, c["want_no_input"]))
+        for inp, name in variants:
+            want = golden("block_writer", name.replace("{s}", fn))
+            got = eng.debug_write_block(c["tok"], inp, False, fn == "dyn")
+            assert got == want, name
+            got = bytearray(eng.debug_write_block(c["tok"], inp, True, fn == "dyn"))
+            assert got[0] & 1 == 1
+            got[0] &= 0xFE
+            assert bytes(got) == want, name + " (eof)"
+            checked += 1
+    assert checked == 17
+
+
+def test_device_planner_matches_oracle_on_random_token_blocks():
+    eng = engine()
+    rng = np.random.default_rng(12)
+    for trial in range(24):
+        n = int(rng.integers(0, 5000))
+        kind = trial % 4
+        if kind == 0:
+            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            data = rng.integers(97, 101, n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            data = (b"the quick brown fox jumps over the lazy dog " * (n // 40 + 1))[:n]
+        else:
+            data = bytes(n)
+        toks = O.tokenize(data, 6)
+        for eof in (False, True):
+            for fn in ("wb", "dyn"):
+                for inp in (data, None):
+                    assert eng.debug_write_block(toks, inp, eof, fn == "dyn") == O.block_write(fn, toks, eof, inp)

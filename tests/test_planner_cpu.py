@@ -65,7 +65,7 @@ def tables(lib):
     return li, le, lb, dc, de, db
 
 
-def encode_block(lib, mode, tokens, input_bytes, eof):
+def encode_block(lib, mode, tokens, input_bytes, eof, dyn=False):
     """Assemble the block bytes the way the encode kernel does: planner output + codes."""
     li, le, lb, dc, de, db = tables(lib)
     lit = np.zeros(286, np.uint16)
@@ -83,7 +83,7 @@ def encode_block(lib, mode, tokens, input_bytes, eof):
         lit[:256] = h
     in_len = NO_INPUT if input_bytes is None else len(input_bytes)
     plan = Plan()
-    lib.shim_plan_block(mode, lit.ctypes.data, dist.ctypes.data, in_len, int(eof), C.addressof(plan))
+    lib.shim_plan_block(2 if dyn else mode, lit.ctypes.data, dist.ctypes.data, in_len, int(eof), C.addressof(plan))
     s = BitSink()
     if plan.type == 0:  # stored
         s.put(1 if eof else 0, 3)
@@ -187,18 +187,19 @@ def _cases():
     return cases
 
 
-def test_planner_reproduces_block_writer_goldens(shim):
+@pytest.mark.parametrize("fn", ["wb", "dyn"])
+def test_planner_reproduces_block_writer_goldens(shim, fn):
     n = 0
     for c in _cases():
         for with_input in (True, False):
             if with_input and not (c["input"] and c["want"]):
                 continue
             inp = golden("block_writer", c["input"]) if with_input else None
-            name = (c["want"] if with_input else c["want_no_input"]).replace("{s}", "wb")
+            name = (c["want"] if with_input else c["want_no_input"]).replace("{s}", fn)
             want = golden("block_writer", name)
-            got, plan = encode_block(shim, 0, c["tok"], inp, False)
+            got, plan = encode_block(shim, 0, c["tok"], inp, False, fn == "dyn")
             assert got == want, name
-            got, plan = encode_block(shim, 0, c["tok"], inp, True)
+            got, plan = encode_block(shim, 0, c["tok"], inp, True, fn == "dyn")
             assert got[0] & 1 and bytes([got[0] & 0xFE]) + got[1:] == want
             n += 1
     assert n == 17

@@ -47,13 +47,7 @@ def dev_arrays(eng, data_np, in_off_np, container, mode):
 def config3(eng):
     n = 177_244_160
     # TAR-like: 512-byte headers + text bodies + zero padding
-    body = synth.text(synth.SEED_TAR, n)
-    hdr = np.zeros(512, dtype=np.uint8)
-    hdr[:100] = np.frombuffer(b"src/flate/deflate.zig".ljust(100, b"\0"), dtype=np.uint8)
-    hdr[257:263] = np.frombuffer(b"ustar\0", dtype=np.uint8)
-    for off in range(0, n - 8192, 24576):
-        body[off:off + 512] = hdr
-        body[off + 20480:off + 24576] = 0
+    body = synth.tar_like(synth.SEED_TAR, n)
     in_off = synth.split_offsets(n, 65535)
     t, out_off = dev_arrays(eng, body, in_off, 1, 9)
     k = len(in_off) - 1
@@ -78,13 +72,7 @@ def config3_stream(eng):
     """#3 as ONE gzip stream (whole-stream path): the config's "deep hash-chain match search" over
     a single 177 MB input.  Parity: the first 3 MiB of it as a stream of its own == oracle."""
     n = 177_244_160
-    body = synth.text(synth.SEED_TAR, n)
-    hdr = np.zeros(512, dtype=np.uint8)
-    hdr[:100] = np.frombuffer(b"src/flate/deflate.zig".ljust(100, b"\0"), dtype=np.uint8)
-    hdr[257:263] = np.frombuffer(b"ustar\0", dtype=np.uint8)
-    for off in range(0, n - 8192, 24576):
-        body[off:off + 512] = hdr
-        body[off + 20480:off + 24576] = 0
+    body = synth.tar_like(synth.SEED_TAR, n)
     in_off = np.array([0, n], dtype=np.uint64)
     t, out_off = dev_arrays(eng, body, in_off, 1, 9)
 
