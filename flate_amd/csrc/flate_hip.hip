@@ -16,6 +16,7 @@
 #include "kernels_common.h"
 #include "kernels_inflate.h"
 #include "kernels_lz.h"
+#include "kernels_match.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -246,9 +247,16 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
-                               (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                               (uint32_t*)h->rec.p);
+            if (!(prm.dbg & 2))
+                hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
+                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p);
+            else if (prm.mode == 4)
+                hipLaunchKernelGGL((k_lz_match2<true, 4>), dim3(nt), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp,
+                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+            else
+                hipLaunchKernelGGL((k_lz_match2<true, 8>), dim3(nt), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp,
+                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
         }
     }
     if (nseg) {
@@ -616,9 +624,18 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                if (!(prm.dbg & 2))  // first-generation match finder (FLATE_HIP_DBG=2 selects the second generation while it is tuned)
+                    hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                else if (mode == 4)
+                    hipLaunchKernelGGL((k_lz_match2<false, 4>), dim3(nc), dim3(FL_M2_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+                else
+                    hipLaunchKernelGGL((k_lz_match2<false, 8>), dim3(nc), dim3(FL_M2_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);
