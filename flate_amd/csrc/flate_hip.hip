@@ -191,6 +191,22 @@ uint64_t stream_pass_byte_limit() {
     return 4096ull << 20;
 }
 
+// second-generation match finder: units of 4 candidates at level 4 (chain >> 2 = 4), else 8; levels
+// 7..9 (chains longer than one tile) keep the lanes' state in LDS between epochs
+template <bool STREAM>
+void launch_match2(hipStream_t st, uint32_t n, int mode, const uint8_t* d_in, const fl_chunk* dch, const fl_tile* dti,
+                   const uint32_t* dfp, const uint32_t* nsorted, const fl_params& prm, const uint16_t* S, uint32_t* rec) {
+    if (mode == 4)
+        hipLaunchKernelGGL((k_lz_match2<STREAM, 4, false>), dim3(n), dim3(64 * FL_M2_WAVES_SHALLOW), 0, st, d_in, dch,
+                           dti, dfp, nsorted, prm, S, rec);
+    else if (mode <= 6)
+        hipLaunchKernelGGL((k_lz_match2<STREAM, 8, false>), dim3(n), dim3(64 * FL_M2_WAVES_SHALLOW), 0, st, d_in, dch,
+                           dti, dfp, nsorted, prm, S, rec);
+    else
+        hipLaunchKernelGGL((k_lz_match2<STREAM, 8, true>), dim3(n), dim3(64 * FL_M2_WAVES_DEEP), 0, st, d_in, dch, dti,
+                           dfp, nsorted, prm, S, rec);
+}
+
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
 // histograms and the block table for the shared back end.
 int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
@@ -247,16 +263,13 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            if (!(prm.dbg & 2))
+            if (prm.dbg & 2)
                 hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
                                    (uint32_t*)h->rec.p);
-            else if (prm.mode == 4)
-                hipLaunchKernelGGL((k_lz_match2<true, 4>), dim3(nt), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp,
-                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
             else
-                hipLaunchKernelGGL((k_lz_match2<true, 8>), dim3(nt), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp,
-                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+                launch_match2<true>(st, nt, prm.mode, d_in, dch, dti, dfp, (const uint32_t*)h->nsorted.p, prm,
+                                    (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
         }
     }
     if (nseg) {
@@ -624,18 +637,13 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                if (!(prm.dbg & 2))  // first-generation match finder (FLATE_HIP_DBG=2 selects the second generation while it is tuned)
+                if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
                     hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
                                        (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
-                else if (mode == 4)
-                    hipLaunchKernelGGL((k_lz_match2<false, 4>), dim3(nc), dim3(FL_M2_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
                 else
-                    hipLaunchKernelGGL((k_lz_match2<false, 8>), dim3(nc), dim3(FL_M2_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+                    launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
+                                         (uint32_t*)h->rec.p);
             }
             {
                 ProfScope ps(h, K_LZ_PARSE);

@@ -18,14 +18,17 @@
 //    generation lacked: there a lane was tied to its entry for the whole walk and idled once its
 //    (short) chain was done -- lane efficiency 57 % on text, 75-85 % here.
 //  * a unit is evaluated branch-free on registers: per candidate two XORs, the trailing-equal-bytes
-//    mask, a packed score (equal bytes, then nearest) and a max.  Only the winner of a unit
-//    touches the key of its entry.  Units whose winner agrees in all 8 prefix bytes go to a
-//    per-round queue; the queue is served by full waves that walk the window (SlidingWindow.match's
-//    reject-on-one-compare, then the extension), nearest candidate first, so `nice` ends a walk
-//    exactly where the reference ends it (deflate.zig:256-258).
-//  * rounds are processed in order, so the state of an entry after round t is the state of the
-//    reference's walk after G (t + 1) candidates: the chain >> 2 record is a snapshot.
-//  * chains longer than 128 (levels 7..9) run in epochs of 128 candidates, each with its own tile.
+//    mask, a packed score (equal bytes, then nearest), a max, and one bit "agrees in all 8 prefix
+//    bytes" shifted into a per-lane mask.  Only the winner of a unit touches the lane's key.
+//  * every 32 candidates (and where the chain >> 2 budget ends) the lanes serve their masks:
+//    SlidingWindow.match against the window (reject on one compare, then the extension), nearest
+//    candidate first, so `nice` ends a walk exactly where the reference ends it
+//    (deflate.zig:256-258).  Between two such points the order of evaluation does not matter: the
+//    key is a maximum, and an 8-byte candidate can never beat one that reached `nice` (>= 16).
+//  * units are processed in order, so the state of a lane after candidate k is the state of the
+//    reference's walk after k candidates: the chain >> 2 record is a snapshot.
+//  * chains longer than 128 (levels 7..9) run in epochs of 128 candidates, each with its own tile;
+//    the lanes' state waits in LDS between epochs.
 //
 // Bound: vector-ALU issue (about 8 instructions per candidate); the LDS carries one 8-byte read
 // per candidate.  No MFMA: byte compares and maxima.
@@ -51,18 +54,19 @@
 #define M2_ACC(slot)
 #define M2_CNT(slot, v)
 #endif
-#define FL_M2_WAVES 12
-#define FL_M2_THREADS (64 * FL_M2_WAVES)
 #define FL_M2_SLICE 256u   // sorted entries per wave step
 #define FL_M2_BACK 128u    // candidates per epoch = tile entries before the slice
 #define FL_M2_TILE (FL_M2_BACK + FL_M2_SLICE)
+// waves per workgroup: what fits next to the 64 KiB window (levels 7..9 keep 2 KiB more per wave)
+#define FL_M2_WAVES_SHALLOW 16
+#define FL_M2_WAVES_DEEP 12
 
+template <bool DEEP>
 struct fl_m2_wave {
     uint2 tW[FL_M2_TILE];       // first 8 window bytes of the tile's entries
-    uint2 est[FL_M2_SLICE];     // per entry of the slice: x = position | candidates it may look at << 16
-                                // (0 = the walk has ended), y = best match so far: len << 16 | 65535 - dist
+    uint2 est[DEEP ? FL_M2_SLICE : 1];  // between epochs: x = position | candidates allowed << 16 (0: walk ended), y = key
     uint16_t tS[FL_M2_TILE];    // positions of the tile's entries
-    uint16_t dq[FL_M2_SLICE];   // entries of this round whose unit has a candidate equal in 8 bytes
+    uint16_t nE[DEEP ? 1 : FL_M2_SLICE];  // candidates each entry of the slice may look at (levels 4..6)
     uint8_t perm[FL_M2_SLICE];  // the slice's entries ordered by units left, most first
     uint32_t cnt[40];           // bins of the counting sort; afterwards cnt[b] = entries with >= b units
 };
@@ -98,166 +102,53 @@ __device__ __forceinline__ uint32_t fl_extend_from(const uint32_t* win32, uint32
     return min(len, maxlen);
 }
 
-struct fl_m2_ctx {
-    const uint32_t* win32;
-    const uint32_t* fp;
-    uint32_t N, w0, in_len, n_flush, zone, nice;
-    bool has_fl;
+// inclusive prefix sum over lanes 0 .. 47 (what the bins of the counting sort need) without LDS:
+// row_shr DPP adds inside the rows of 16 lanes, then the row totals
+__device__ __forceinline__ uint32_t fl_m2_scan48(uint32_t v, uint32_t lane) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    if (lane >= 16) v += t0;
+    if (lane >= 32) v += t1;
+    return v;
+}
+
+// the walk of one lane (= one sorted entry)
+struct fl_m2_lane {
+    uint32_t e;       // entry of the slice
+    uint32_t p;       // its position
+    uint32_t p0, p1;  // window bytes p .. p+7
+    uint32_t n;       // candidates it may look at in total; 0: the walk has ended
+    uint32_t key;     // best match so far: len << 16 | 65535 - (number of the candidate along the chain)
+    uint32_t maxlen, lov, lenmask;
+    uint32_t dm;      // bit b: candidate kdone - b agrees in 8 bytes and waits for the window
 };
 
-template <bool STREAM>
-__device__ __forceinline__ uint32_t fl_m2_maxlen(const fl_m2_ctx& cx, uint32_t p) {
-    uint32_t maxlen = min(cx.N - p, FL_MAX_MATCH);
-    if (STREAM && cx.has_fl) maxlen = min(maxlen, fl_next_flush(cx.fp, cx.n_flush, cx.w0 + p, cx.in_len) - (cx.w0 + p));
-    return maxlen;
-}
-// valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248), p - q <= 32768
-// (deflate.zig:250-251), beyond the slide zone only the upper half of the window
-template <bool STREAM>
-__device__ __forceinline__ uint32_t fl_m2_lov(const fl_m2_ctx& cx, uint32_t p) {
-    uint32_t lov = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
-    if (STREAM && p >= cx.zone) lov = max(lov, FL_MAX_DIST + 1u);
-    return lov;
-}
-
-// One round for NB x 64 entries of the slice (perm[b0 ..]): candidates kbase + k0 + 1 .. + G.
-// The NB batches are independent chains of LDS reads; written side by side so that the loads of
-// one overlap the arithmetic of the other.  Returns the new length of the deep queue.
-template <bool STREAM, int G, int NB>
-__device__ __forceinline__ uint32_t fl_m2_units(fl_m2_wave& W, const fl_m2_ctx& cx, uint32_t lane, uint32_t a,
-                                                uint32_t A, uint32_t b0, uint32_t kbase, uint32_t k0, uint32_t dqn) {
-    bool on[NB];
-    uint32_t e[NB], slot0[NB];
-    uint2 st[NB], cw[NB][G];
-#pragma unroll
-    for (int h = 0; h < NB; h++) {
-        const uint32_t j = b0 + 64 * h + lane;
-        on[h] = j < A;
-        e[h] = on[h] ? W.perm[j] : 0u;
-    }
-#pragma unroll
-    for (int h = 0; h < NB; h++) {
-        st[h] = W.est[e[h]];
-        slot0[h] = e[h] + FL_M2_BACK - k0 - G;  // slot of candidate k0 + G
-#pragma unroll
-        for (int u = 0; u < G; u++) cw[h][u] = W.tW[slot0[h] + G - 1 - u];
-    }
-    uint32_t p[NB], nrel[NB], maxlen[NB], lov[NB], p0[NB], p1[NB], qc[NB];
-    bool live[NB];
-#pragma unroll
-    for (int h = 0; h < NB; h++) {
-        p[h] = st[h].x & 0xffffu;
-        const uint32_t n = on[h] ? st[h].x >> 16 : 0u;  // 0: the walk of this entry has ended
-        nrel[h] = n > kbase ? n - kbase : 0u;            // epoch-relative candidates allowed
-        live[h] = nrel[h] > k0;
-        fl_lds_load8(cx.win32, p[h], p0[h], p1[h]);
-        // the farthest candidate of this unit that the count allows decides whether every
-        // candidate of the unit passes the position bound
-        const uint32_t kc = live[h] ? min(nrel[h], k0 + G) : 1u;
-        qc[h] = W.tS[e[h] + FL_M2_BACK - kc];
-        maxlen[h] = fl_m2_maxlen<STREAM>(cx, p[h]);
-        lov[h] = fl_m2_lov<STREAM>(cx, p[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < NB; h++) {
-        // (slots below sorted index 0 hold position 0, which fails every bound)
-        const bool trunc = live[h] && (qc[h] < lov[h] || a + e[h] < kbase + k0 + G);
-        const uint32_t lenmask = maxlen[h] >= 8 ? 0x80808080u : (0x00808080u >> (8 * (7 - maxlen[h])));
-        uint32_t best = 0;
-        if (__any(trunc)) {
-            // some lane's unit reaches below its position bound: check every candidate's position
-            const uint16_t* cs = &W.tS[slot0[h]];
-#pragma unroll
-            for (int u = 0; u < G; u++) {
-                const uint32_t q = cs[G - 1 - u];
-                uint32_t s = fl_m2_score(cw[h][u], p0[h], p1[h], lenmask, 0x20u | (uint32_t)(G - 1 - u));
-                if (q < lov[h] || k0 + 1 + u > nrel[h]) s = 0;
-                best = max(best, s);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < G; u++)
-                best = max(best, fl_m2_score(cw[h][u], p0[h], p1[h], lenmask, 0x20u | (uint32_t)(G - 1 - u)));
-        }
-        if (!live[h]) best = 0;
-        if (best) {
-            const uint32_t uw = (G - 1) - (best & 7u);
-            const uint32_t le = min(4u + (uint32_t)__popc(best & 0x80808080u), maxlen[h]);
-            const uint32_t q = W.tS[slot0[h] + (G - 1) - uw];
-            const uint32_t kcand = (le << 16) | (q + 0xffffu - p[h]);  // low half = 65535 - (p - q)
-            if (kcand > st[h].y) {  // deflate.zig:254-261
-                // nothing longer possible (le <= 8 < nice): the walk ends
-                W.est[e[h]] = make_uint2(le >= maxlen[h] ? p[h] : st[h].x, kcand);
-            }
-        }
-        // a candidate equal in all 8 prefix bytes that may run on: the window decides
-        const bool deep = best >= 0x80808080u && maxlen[h] > 8;
-        const uint64_t dm = __ballot(deep);
-        if (deep)
-            W.dq[dqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] =
-                (uint16_t)e[h];
-        dqn += (uint32_t)__popcll(dm);
-    }
-    return dqn;
-}
-
-// Serve 64 entries of the deep queue: SlidingWindow.match against the window for the candidates of
-// the unit that agree in 8 bytes, nearest first.
-template <bool STREAM, int G>
-__device__ __forceinline__ void fl_m2_deep(fl_m2_wave& W, const fl_m2_ctx& cx, uint32_t lane, uint32_t dqn,
-                                           uint32_t b0, uint32_t kbase, uint32_t k0) {
-    const uint32_t* win32 = cx.win32;
-    const uint32_t j = b0 + lane;
-    const bool on = j < dqn;
-    const uint32_t e = on ? W.dq[j] : 0u;
-    const uint2 st = W.est[e];
-    const uint32_t slot0 = e + FL_M2_BACK - k0 - G;
-    const uint2* cw = &W.tW[slot0];
-    const uint16_t* cs = &W.tS[slot0];
-    uint2 w[G];
-    uint32_t qs[G];
-#pragma unroll
-    for (int u = 0; u < G; u++) {
-        w[u] = cw[G - 1 - u];
-        qs[u] = cs[G - 1 - u];
-    }
-    const uint32_t p = st.x & 0xffffu;
-    const uint32_t n = on ? st.x >> 16 : 0u;
-    const uint32_t nrel = n > kbase ? n - kbase : 0u;
-    // window bytes p .. p+15
-    uint32_t p0, p1, pA, pB;
-    {
-        const uint32_t i = p >> 2, sh = p & 3;
-        const uint32_t d0 = win32[i], d1 = win32[i + 1], d2 = win32[i + 2], d3 = win32[i + 3], d4 = win32[i + 4];
-        p0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-        p1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        pA = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        pB = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    }
-    const uint32_t maxlen = fl_m2_maxlen<STREAM>(cx, p);
-    const uint32_t lov = fl_m2_lov<STREAM>(cx, p);
-    uint32_t dmask = 0;  // bit u: candidate k0 + 1 + u is valid and agrees in 8 bytes
-#pragma unroll
-    for (int u = 0; u < G; u++)
-        if (((w[u].x ^ p0) | (w[u].y ^ p1)) == 0 && qs[u] >= lov && k0 + 1 + u <= nrel) dmask |= 1u << u;
-    if (nrel <= k0) dmask = 0;
-    uint32_t key = st.y;
-    const uint32_t cp = 0xffffu - p;
+// Serve the lanes' masks of 8-byte candidates: SlidingWindow.match against the window, nearest
+// first.  kdone = epoch-relative number of the last candidate shifted into the masks.
+__device__ __forceinline__ void fl_m2_deep(fl_m2_lane& L, const uint32_t* win32, const uint16_t* tS, uint32_t kbase,
+                                           uint32_t kdone, uint32_t nice, uint32_t dbg = 0) {
+    if (!__any(L.dm != 0)) return;
+    if (dbg & 4) { L.dm = 0; return; }  // timing experiment: no window walks (wrong output)
+    // window bytes p+8 .. p+15
+    uint32_t pA, pB;
+    fl_lds_load8(win32, L.p + 8, pA, pB);
     uint32_t pb = 0;  // window bytes p+best-3 .. p+best (valid when best >= 16)
-    if ((key >> 16) >= 16) pb = fl_lds_load4(win32, p + (key >> 16) - 3);
-    bool stop = false;
-    while (__any(dmask != 0)) {
+    if ((L.key >> 16) >= 16) pb = fl_lds_load4(win32, L.p + (L.key >> 16) - 3);
+    while (__any(L.dm != 0)) {
         M2_CNT(43, 1);
-        if (dmask) {
-            const uint32_t u = (uint32_t)__builtin_ctz(dmask);  // nearest first
-            dmask &= dmask - 1;
-            const uint32_t q = cs[G - 1 - u];
-            const uint32_t bestl = key >> 16;
+        if (L.dm) {
+            const uint32_t b = 31u - (uint32_t)__builtin_clz(L.dm);  // nearest first
+            L.dm &= ~(1u << b);
+            const uint32_t q = tS[L.e + FL_M2_BACK - (kdone - b)];
+            const uint32_t bestl = L.key >> 16;
             // bytes 8 .. 15 of the candidate, and the reference's reject-on-one-compare
             // (SlidingWindow.zig:91-98) once the best match is longer than that
             uint32_t qA, qB;
             fl_lds_load8(win32, q + 8, qA, qB);
-            bool take = maxlen > bestl;
+            bool take = L.maxlen > bestl;
             if (take && bestl >= 16) take = fl_lds_load4(win32, q + bestl - 3) == pb;
             if (take) {
                 const uint32_t yA = qA ^ pA, yB = qB ^ pB;
@@ -267,77 +158,78 @@ __device__ __forceinline__ void fl_m2_deep(fl_m2_wave& W, const fl_m2_ctx& cx, u
                 else if (yB)
                     le += 4 + ((uint32_t)__builtin_ctz(yB) >> 3);
                 else
-                    le = fl_extend_from(win32, p, q, 16, maxlen);
-                le = min(le, maxlen);
-                const uint32_t kcand = (le << 16) | (q + cp);
-                if (kcand > key) {  // deflate.zig:254-261
-                    key = kcand;
-                    if (le >= 16) pb = fl_lds_load4(win32, p + le - 3);
-                    if (le >= maxlen || le >= cx.nice) {  // nothing longer possible / stop looking
-                        stop = true;
-                        dmask = 0;
+                    le = fl_extend_from(win32, L.p, q, 16, L.maxlen);
+                le = min(le, L.maxlen);
+                const uint32_t kcand = (le << 16) | (0xffffu - (kbase + kdone - b));
+                if (kcand > L.key) {  // deflate.zig:254-261
+                    L.key = kcand;
+                    if (le >= 16) pb = fl_lds_load4(win32, L.p + le - 3);
+                    if (le >= L.maxlen || le >= nice) {  // nothing longer possible / stop looking
+                        L.n = 0;
+                        L.dm = 0;
                     }
                 }
             }
         }
     }
-    if (on) W.est[e] = make_uint2(stop ? p : st.x, key);
 }
 
-template <bool STREAM, int G>
-__global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __restrict__ in,
-                                                             const fl_chunk* __restrict__ chunks,
-                                                             const fl_tile* __restrict__ tiles,
-                                                             const uint32_t* __restrict__ fpts,
-                                                             const uint32_t* __restrict__ n_sorted, fl_params prm,
-                                                             const uint16_t* __restrict__ S,
-                                                             uint32_t* __restrict__ rec_all) {
+// key -> record (len << 16 | dist - 1).  A key whose low half is 65535 was not beaten in this
+// epoch: the record it came with stays.
+__device__ __forceinline__ uint32_t fl_m2_record(const fl_m2_lane& L, const uint16_t* tS, uint32_t kbase,
+                                                 uint32_t oldrec) {
+    const uint32_t le = L.key >> 16, low = L.key & 0xffffu;
+    if (le == 0 || low == 0xffffu) return oldrec;
+    const uint32_t q = tS[L.e + FL_M2_BACK - ((0xffffu - low) - kbase)];
+    return (le << 16) | (L.p - q - 1u);
+}
+
+template <bool STREAM, int G, bool DEEP>
+__global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW)) void k_lz_match2(
+    const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks, const fl_tile* __restrict__ tiles,
+    const uint32_t* __restrict__ fpts, const uint32_t* __restrict__ n_sorted, fl_params prm,
+    const uint16_t* __restrict__ S, uint32_t* __restrict__ rec_all) {
+    constexpr uint32_t NW = DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW;
+    constexpr uint32_t NT = 64 * NW;
     constexpr uint32_t WIN_DW = STREAM ? FL_WIN_DW_STREAM : FL_WIN_DW_CHUNK;
-    constexpr uint32_t RPE = FL_M2_BACK / G;  // rounds per epoch
+    constexpr uint32_t RPE = FL_M2_BACK / G;  // units per epoch
     __shared__ uint32_t win32[WIN_DW];
     __shared__ uint32_t bmask[2048 + 2];  // bit i: sorted entry i starts a bucket
-    __shared__ fl_m2_wave wv[FL_M2_WAVES];
+    __shared__ uint16_t gcarry[1024 + 2];  // last bucket start before group g of 64 sorted entries
+    __shared__ fl_m2_wave<DEEP> wv[NW];
     const uint32_t c = blockIdx.x;
     const uint32_t w0 = STREAM ? tiles[c].w0 : 0u;
     const uint32_t tgt0 = STREAM ? tiles[c].tgt0 : 0u;
     const fl_chunk ck = chunks[STREAM ? tiles[c].chunk : c];
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t zone = STREAM ? tiles[c].zone : 65536u;
     const uint32_t N = ck.in_len - w0;
     const uint32_t Mpos = min(N >= 4 ? N - 3 : 0u, 65536u);  // positions with 4 bytes left in the stream
     const uint32_t M = STREAM ? n_sorted[c] : Mpos;            // entries of the sorted array
-    fl_m2_ctx cx;
-    cx.win32 = win32;
-    cx.fp = STREAM ? fpts + ck.flush_off : nullptr;
-    cx.N = N;
-    cx.w0 = w0;
-    cx.in_len = ck.in_len;
-    cx.n_flush = ck.n_flush;
-    cx.zone = STREAM ? tiles[c].zone : 65536u;
-    cx.nice = prm.nice;
+    const uint32_t* fp = STREAM ? fpts + ck.flush_off : nullptr;
     // a flush point up to 258 bytes past the last position still shortens matches in this window
-    cx.has_fl =
-        STREAM && ck.n_flush && fl_next_flush(cx.fp, ck.n_flush, w0, ck.in_len) <= w0 + Mpos + 2 + FL_MAX_MATCH;
+    const bool has_fl =
+        STREAM && ck.n_flush && fl_next_flush(fp, ck.n_flush, w0, ck.in_len) <= w0 + Mpos + 2 + FL_MAX_MATCH;
     const uint8_t* src = in + ck.in_off + w0;
     const uint16_t* Sc = S + (uint64_t)c * FL_CHUNK_STRIDE;
     uint2* rec2 = (uint2*)rec_all + ck.pos_off + w0;
-    const uint32_t chain = prm.chain, quarter = prm.chain >> 2;
+    const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
 
     fl_prof_mark(8);
     // stage the window in LDS (zero padded)
     const uint32_t ndw = (min(N, WIN_DW * 4u) + 3) >> 2;
-    for (uint32_t i = tid; i < WIN_DW; i += FL_M2_THREADS)
-        win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
+    for (uint32_t i = tid; i < WIN_DW; i += NT) win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
     // positions without a hash entry never match (Lookup.zig:24)
     // (with flush points in the stream the host has cleared all records beforehand)
-    for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += FL_M2_THREADS) rec2[p] = make_uint2(0u, 0u);
+    for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += NT) rec2[p] = make_uint2(0u, 0u);
     __syncthreads();
     fl_prof_mark(9);
 
     // ---- bucket starts: bit i set iff entry i is the first of its hash bucket ----
     {
         const uint32_t ngrp = (M + 63) >> 6;
-        for (uint32_t g0 = wave * 4; g0 < ngrp; g0 += FL_M2_WAVES * 4) {
+        for (uint32_t g0 = wave * 4; g0 < ngrp; g0 += NW * 4) {
             uint32_t q[4], qp[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -359,9 +251,35 @@ __global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __re
         }
     }
     __syncthreads();
+    // the last bucket start before every group of 64 entries: a running maximum over the groups
+    if (wave == 0) {
+        const uint32_t ngrp = (M + 63) >> 6;
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < ngrp; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            uint32_t last = 0;
+            if (g < ngrp) {
+                const uint32_t lo = bmask[2 * g], hi = bmask[2 * g + 1];
+                if (hi)
+                    last = (g << 6) + 63 - (uint32_t)__builtin_clz(hi);
+                else if (lo)
+                    last = (g << 6) + 31 - (uint32_t)__builtin_clz(lo);
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(last, d, 64);
+                if (lane >= (uint32_t)d) last = max(last, t);
+            }
+            last = max(last, run);
+            if (g < ngrp) gcarry[g + 1] = (uint16_t)last;
+            run = __shfl(last, 63, 64);
+        }
+        if (lane == 0) gcarry[0] = 0;
+    }
+    __syncthreads();
     fl_prof_mark(10);
 
-    fl_m2_wave& W = wv[wave];
+    fl_m2_wave<DEEP>& W = wv[wave];
 #ifdef FL_M2_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int k = 32; k < 48; k++) g_fl_prof[k] = 0;
@@ -378,13 +296,13 @@ __global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __re
             nxq[r] = (wave < nslices && i >= 0 && i < (int32_t)M) ? Sc[i] : 0u;
         }
     }
-    for (uint32_t slice = wave; slice < nslices; slice += FL_M2_WAVES) {
+    for (uint32_t slice = wave; slice < nslices; slice += NW) {
         const uint32_t a = slice * FL_M2_SLICE;
         uint32_t tq[6];
 #pragma unroll
         for (int r = 0; r < 6; r++) tq[r] = nxq[r];
         {
-            const uint32_t sn = slice + FL_M2_WAVES;
+            const uint32_t sn = slice + NW;
             const int32_t base = (int32_t)(sn * FL_M2_SLICE) - (int32_t)FL_M2_BACK;
 #pragma unroll
             for (int r = 0; r < 6; r++) {
@@ -392,8 +310,7 @@ __global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __re
                 nxq[r] = (sn < nslices && i < (int32_t)M) ? Sc[i] : 0u;
             }
         }
-        uint32_t qk[4] = {0, 0, 0, 0};
-        bool qsnap = false;
+        uint32_t nown[4];  // candidates each of the slice's entries may look at (epoch 0: lane = entry)
         uint32_t nepoch = 1;
         for (uint32_t ep = 0; ep < nepoch; ep++) {
             const uint32_t kbase = ep * FL_M2_BACK;  // candidates kbase + 1 .. kbase + 128
@@ -416,33 +333,34 @@ __global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __re
             }
             M2_ACC(33);
             if (ep == 0) {
-                // ---- the slice's own entries: position, candidates they may look at ----
+                // ---- the slice's own entries: candidates they may look at ----
                 uint32_t maxu = 0;
 #pragma unroll
                 for (uint32_t g = 0; g < 4; g++) {
-                    const uint32_t e = (g << 6) + lane, i = a + e;
+                    const uint32_t i = a + (g << 6) + lane;
                     const uint32_t p = tq[2 + g];
                     uint32_t n = 0;
                     if (i < M && (!STREAM || p >= tgt0)) {
                         // bucket offset = distance to the nearest bucket start at or before i, capped at chain
-                        uint32_t wd = i >> 5;
-                        uint32_t bits = bmask[wd] & (0xffffffffu >> (31 - (i & 31)));
-                        uint32_t o;
-                        for (;;) {
-                            if (bits) {
-                                o = i - ((wd << 5) + 31 - (uint32_t)__builtin_clz(bits));
-                                break;
-                            }
-                            if (wd == 0 || i - (wd << 5) >= chain) {
-                                o = chain;
-                                break;
-                            }
-                            wd--;
-                            bits = bmask[wd];
-                        }
-                        n = min(o, chain);
+                        const uint32_t gi = i >> 6;
+                        const uint32_t blo = bmask[2 * gi], bhi = bmask[2 * gi + 1];
+                        const uint32_t mlo = blo & (lane < 32 ? (0xffffffffu >> (31 - lane)) : 0xffffffffu);
+                        const uint32_t mhi = lane < 32 ? 0u : (bhi & (0xffffffffu >> (63 - lane)));
+                        uint32_t st;
+                        if (mhi)
+                            st = (gi << 6) + 63 - (uint32_t)__builtin_clz(mhi);
+                        else if (mlo)
+                            st = (gi << 6) + 31 - (uint32_t)__builtin_clz(mlo);
+                        else
+                            st = gcarry[gi];
+                        n = min(i - st, chain);
+                        if (n == 0) rec2[p] = make_uint2(0u, 0u);  // first of its bucket: no candidates, no match
                     }
-                    W.est[e] = make_uint2(p | (n << 16), 0u);
+                    nown[g] = n;
+                    if (DEEP)
+                        W.est[(g << 6) + lane] = make_uint2(p | (n << 16), 0u);
+                    else
+                        W.nE[(g << 6) + lane] = (uint16_t)n;
                     maxu = max(maxu, (n + G - 1) / G);
                 }
                 maxu = fl_wave_max(maxu);
@@ -450,83 +368,197 @@ __global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(const uint8_t* __re
                 M2_ACC(32);
             }
             // ---- order the entries by the units they have left in this epoch (most first) ----
+            // (bins in reverse: bin r holds the entries with RPE - r units, so that a prefix sum gives
+            // the slots)
             if (lane < 40) W.cnt[lane] = 0;
             fl_lds_order();
             uint32_t ub[4];
 #pragma unroll
             for (uint32_t g = 0; g < 4; g++) {
-                const uint32_t n = W.est[(g << 6) + lane].x >> 16;
+                const uint32_t n = DEEP ? (W.est[(g << 6) + lane].x >> 16) : nown[g];
                 const uint32_t left = n > kbase ? n - kbase : 0u;
                 ub[g] = min((left + G - 1) / G, RPE);
-                if (ub[g]) atomicAdd(&W.cnt[ub[g]], 1u);
+                if (ub[g]) atomicAdd(&W.cnt[RPE - ub[g]], 1u);
             }
             fl_lds_order();
             {
-                // suffix sums over the bins: lane b gets the number of entries with more units than b
-                const uint32_t cb = lane <= RPE ? W.cnt[lane] : 0u;
-                uint32_t suf = cb;  // sum over lanes >= this one
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_down(suf, d, 64);
-                    if (lane + d < 64) suf += t;
-                }
+                const uint32_t cb = lane < RPE ? W.cnt[lane] : 0u;
+                const uint32_t incl = fl_m2_scan48(cb, lane);
                 fl_lds_order();
-                // cnt[b] = first slot of bin b (entries with more units come first)
-                if (lane <= RPE) W.cnt[lane] = suf - cb;
+                if (lane < RPE) W.cnt[lane] = incl - cb;  // first slot of the bin
+                if (lane == RPE - 1) W.cnt[RPE] = incl;   // entries with work in this epoch
             }
             fl_lds_order();
 #pragma unroll
             for (uint32_t g = 0; g < 4; g++)
-                if (ub[g]) W.perm[atomicAdd(&W.cnt[ub[g]], 1u)] = (uint8_t)((g << 6) + lane);
+                if (ub[g]) W.perm[atomicAdd(&W.cnt[RPE - ub[g]], 1u)] = (uint8_t)((g << 6) + lane);
             fl_lds_order();
-            // now cnt[b] = end of bin b = number of entries with at least b units
+            uint32_t A = __builtin_amdgcn_readfirstlane(W.cnt[RPE]);  // entries with work in this epoch
+            const bool nosort = (prm.dbg & 8) != 0;  // experiment: entries in their natural order
+            if (nosort) A = A ? FL_M2_SLICE : 0u;
             M2_ACC(34);
 
-            // ---- rounds ----
+            // ---- the walks, 64 entries with about the same number of units at a time ----
 #pragma unroll 1
-            for (uint32_t t = 0; t < RPE; t++) {
-                const uint32_t A = __builtin_amdgcn_readfirstlane(W.cnt[t + 1]);  // entries with more than t units
-                if (A == 0) break;
-                const uint32_t k0 = G * t;  // this round: epoch-relative candidates k0 + 1 .. k0 + G
-                uint32_t dqn = 0;
-                uint32_t b0 = 0;
-#pragma unroll 1
-                for (; b0 + 64 < A; b0 += 128) dqn = fl_m2_units<STREAM, G, 2>(W, cx, lane, a, A, b0, kbase, k0, dqn);
-                if (b0 < A) dqn = fl_m2_units<STREAM, G, 1>(W, cx, lane, a, A, b0, kbase, k0, dqn);
-                fl_lds_order();
-                M2_ACC(35);
-                M2_CNT(40, (A + 63) / 64);
-                M2_CNT(41, (dqn + 63) / 64);
-                M2_CNT(42, dqn);
-#pragma unroll 1
-                for (uint32_t d0 = 0; d0 < dqn; d0 += 64) fl_m2_deep<STREAM, G>(W, cx, lane, dqn, d0, kbase, k0);
-                fl_lds_order();
+            for (uint32_t b0 = 0; b0 < A; b0 += 64) {
+                fl_m2_lane L;
+                const bool on = b0 + lane < A;
+                L.e = on ? (nosort ? b0 + lane : (uint32_t)W.perm[b0 + lane]) : 0u;
+                L.key = 0;
+                uint32_t oldrec = 0;  // the record the earlier epochs left
+                if (DEEP) {
+                    const uint2 st = W.est[L.e];
+                    L.p = st.x & 0xffffu;
+                    L.n = on ? st.x >> 16 : 0u;
+                    oldrec = st.y;
+                    L.key = (oldrec & 0xffff0000u) | 0xffffu;  // wins every tie: it is nearer
+                    fl_lds_load8(win32, L.p, L.p0, L.p1);
+                } else {
+                    // epoch 0: the entry's own slot of the tile, its chain length from its first lane
+                    L.p = W.tS[FL_M2_BACK + L.e];
+                    const uint2 w = W.tW[FL_M2_BACK + L.e];
+                    L.p0 = w.x;
+                    L.p1 = w.y;
+                    const uint32_t n = W.nE[L.e];
+                    L.n = on ? n : 0u;
+                }
+                L.maxlen = min(N - L.p, FL_MAX_MATCH);
+                if (STREAM && has_fl) L.maxlen = min(L.maxlen, fl_next_flush(fp, ck.n_flush, w0 + L.p, ck.in_len) - (w0 + L.p));
+                // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248), p - q <= 32768
+                // (deflate.zig:250-251), beyond the slide zone only the upper half of the window
+                L.lov = L.p > FL_MAX_DIST ? L.p - FL_MAX_DIST : 1u;
+                if (STREAM && L.p >= zone) L.lov = max(L.lov, FL_MAX_DIST + 1u);
+                L.lenmask = L.maxlen >= 8 ? 0x80808080u : (0x00808080u >> (8 * (7 - L.maxlen)));
+                L.dm = 0;
+                uint32_t qrec = 0;
+                bool qsnap = false;
+                // Candidates get farther along the chain, so those the position bound allows are a
+                // prefix: the walk ends at the first one below the bound (deflate.zig:248-251).  Cut
+                // the lane's count there (binary search over this epoch's candidates, rarely needed).
+                bool cut = false;
                 M2_ACC(36);
-                // the chain >> 2 budget (deflate.zig:241-245) ends with this round?
-                if (kbase + k0 + G == quarter) {
+                {
+                    const uint32_t nr = L.n > kbase ? min(L.n - kbase, FL_M2_BACK) : 0u;
+                    uint32_t lo = 0, hi = nr;  // candidates 1 .. lo pass, candidate hi (if > lo) does not
+                    if (nr && W.tS[L.e + FL_M2_BACK - nr] >= L.lov) lo = nr;
+                    cut = lo < hi;
+                    if (__any(cut)) {
 #pragma unroll
-                    for (uint32_t g = 0; g < 4; g++) qk[g] = W.est[(g << 6) + lane].y;
-                    qsnap = true;
+                        for (int it = 0; it < 7; it++) {  // hi - lo <= 128 halves to <= 1
+                            const uint32_t mid = (lo + hi) >> 1;
+                            const bool ok = W.tS[L.e + FL_M2_BACK - max(mid, 1u)] >= L.lov;
+                            const bool go = hi - lo > 1;
+                            lo = (go && ok) ? mid : lo;
+                            hi = (go && !ok) ? mid : hi;
+                        }
+                    }
+                    if (cut) L.n = lo ? kbase + lo : 0u;
+                }
+                M2_ACC(37);
+                uint32_t nrel = L.n > kbase ? L.n - kbase : 0u;  // candidates of this epoch the lane may look at
+                const uint32_t kmax = (prm.dbg & 16) ? 0u : min(fl_wave_max(nrel), FL_M2_BACK);  // (16: timing experiment, no walks)
+                uint32_t kdone = 0;
+                uint32_t bb = 0;  // best score of the current block of 32 candidates
+                // what a block (or the chain >> 2 budget) ends with: the block's winner meets the key,
+                // then the 8-byte candidates meet the window
+                auto block_end = [&](uint32_t kb) {
+                    if (__any(bb != 0)) {
+                        if (bb) {
+                            const uint32_t le = min(4u + (uint32_t)__popc(bb & 0x80808080u), L.maxlen);
+                            const uint32_t kcand = (le << 16) | (0xffffu - (kbase + kb + 32u - (bb & 31u)));
+                            if (kcand > L.key) {  // deflate.zig:254-261
+                                L.key = kcand;
+                                if (le >= L.maxlen) {  // nothing longer possible (le <= 8 < nice): the walk ends
+                                    L.n = 0;
+                                    L.dm = 0;
+                                }
+                            }
+                        }
+                        bb = 0;
+                    }
+                    if (L.maxlen <= 8) L.dm = 0;
+                    fl_m2_deep(L, win32, W.tS, kbase, kdone, nice, prm.dbg);
+                    if (L.n == 0) nrel = 0;
+                    if (kbase + kdone == quarter) {  // the chain >> 2 budget (deflate.zig:241-245) ends here
+                        qrec = fl_m2_record(L, W.tS, kbase, oldrec);
+                        qsnap = true;
+                        if (DEEP && on) rec2[L.p].y = qrec;
+                    }
+                };
+                // tile words of the first unit; each unit fetches the next one's before it computes
+                uint2 cwn[G];
+                {
+                    const uint2* cwp = &W.tW[L.e + FL_M2_BACK - G];
+#pragma unroll
+                    for (int u = 0; u < G; u++) cwn[u] = cwp[G - 1 - u];
+                }
+#pragma unroll 1
+                for (uint32_t kb = 0; kb < kmax; kb += 32) {  // a block: candidates kbase + kb + 1 .. + 32
+#pragma unroll
+                    for (uint32_t t = 0; t < 32 / G; t++) {
+                        const uint32_t k0 = kb + G * t;  // this unit: candidates kbase + k0 + 1 .. + G
+                        if (k0 < kmax) {
+                            const bool live = nrel > k0;
+                            uint2 cw[G];
+#pragma unroll
+                            for (int u = 0; u < G; u++) cw[u] = cwn[u];
+                            {
+                                const uint32_t kn = min(k0 + G, FL_M2_BACK - G);
+                                const uint2* cwp = &W.tW[L.e + FL_M2_BACK - kn - G];
+#pragma unroll
+                                for (int u = 0; u < G; u++) cwn[u] = cwp[G - 1 - u];
+                            }
+                            // A unit the count ends in: what follows in the tile are entries of other
+                            // buckets (they differ in their first four bytes: the hash is a function of
+                            // those), except where the count was cut by the position bound or the tile
+                            // reaches below sorted index 0 -- then the candidates beyond the count must
+                            // be masked.
+                            const bool partial = live && nrel < k0 + G && (cut || a + L.e < kbase + k0 + G);
+                            if (__any(partial)) {
+                                const uint32_t nv = nrel - min(nrel, k0);  // valid candidates of this unit (>= G: all)
+#pragma unroll
+                                for (int u = 0; u < G; u++) {
+                                    const uint32_t sc = fl_m2_score(cw[u], L.p0, L.p1, L.lenmask, 0x40u | (31u - (G * t + u)));
+                                    const uint32_t s = (uint32_t)u < nv ? sc : 0u;
+                                    bb = max(bb, s);
+                                    L.dm = __builtin_amdgcn_alignbit(L.dm, s, 31);
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < G; u++) {
+                                    const uint32_t sc = fl_m2_score(cw[u], L.p0, L.p1, L.lenmask, 0x40u | (31u - (G * t + u)));
+                                    const uint32_t s = live ? sc : 0u;
+                                    bb = max(bb, s);
+                                    L.dm = __builtin_amdgcn_alignbit(L.dm, s, 31);
+                                }
+                            }
+                            kdone = k0 + G;
+                            if (t + 1 < 32 / G && kbase + kdone == quarter) block_end(kb);
+                        }
+                    }
+                    block_end(kb);
+                    if (!__any(nrel > kdone)) break;  // every walk of the group has ended
+                }
+                M2_CNT(40, 1);
+                M2_ACC(38);
+                if (DEEP) {
+                    // the lane's state waits for the next epoch; the full-budget record goes out when
+                    // the walk is over (the chain >> 2 half went out at its snapshot, or equals it)
+                    const bool more = L.n > kbase + FL_M2_BACK;
+                    const uint32_t rf = fl_m2_record(L, W.tS, kbase, oldrec);
+                    if (on) W.est[L.e] = make_uint2(L.p | ((more ? L.n : 0u) << 16), rf);
+                    if (on && !more) {
+                        rec2[L.p].x = rf;
+                        // the walk ended before the chain >> 2 budget did: both records are the same
+                        if (!qsnap && kbase < quarter) rec2[L.p].y = rf;
+                    }
+                } else if (on) {
+                    const uint32_t rf = fl_m2_record(L, W.tS, kbase, 0u);
+                    rec2[L.p] = make_uint2(rf, qsnap ? qrec : rf);
                 }
             }
+            M2_ACC(39);
         }
-        fl_lds_order();
-        // ---- records of the slice's entries ----
-#pragma unroll
-        for (uint32_t g = 0; g < 4; g++) {
-            const uint32_t e = (g << 6) + lane, i = a + e;
-            const uint2 st = W.est[e];
-            const uint32_t p = st.x & 0xffffu;
-            if (i < M && (!STREAM || p >= tgt0)) {
-                const uint32_t key = st.y;
-                const uint32_t qkey = qsnap ? qk[g] : key;
-                // key -> record: len << 16 | dist - 1, dist = 65535 - low half
-                const uint32_t rf = (key >> 16) ? ((key & 0xffff0000u) | (0xfffeu - (key & 0xffffu))) : 0u;
-                const uint32_t rq = (qkey >> 16) ? ((qkey & 0xffff0000u) | (0xfffeu - (qkey & 0xffffu))) : 0u;
-                rec2[p] = make_uint2(rf, rq);
-            }
-        }
-        M2_ACC(37);
     }
     fl_prof_mark(11);
 }

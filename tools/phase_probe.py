@@ -22,8 +22,8 @@ seg("parse: (a) desc", 16, 17); seg("parse: (b) jump", 17, 18); seg("parse: (c) 
 seg("parse: (e) mark", 20, 21); seg("parse: total", 16, 21)
 seg("emit: stage", 24, 25); seg("emit: count", 25, 26); seg("emit: emit", 26, 27); seg("emit: total", 24, 27)
 if t[32:48].any():
-    names = {32: "m2: slice init", 33: "m2: tile build", 34: "m2: bin + perm", 35: "m2: unit batches", 36: "m2: deep queue",
-             37: "m2: records", 40: "m2: # unit batches", 41: "m2: # deep batches", 42: "m2: # deep entries",
+    names = {32: "m2: slice init", 33: "m2: tile build", 34: "m2: bin + perm", 35: "m2: (unused)", 36: "m2: group setup", 37: "m2: cut search", 38: "m2: unit loop + deep", 39: "m2: records",
+             40: "m2: # groups",
              43: "m2: # deep loop iterations"}
     for k in sorted(names):
         print("%-28s %10d" % (names[k], t[k]))
