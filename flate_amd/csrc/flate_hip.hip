@@ -191,20 +191,16 @@ uint64_t stream_pass_byte_limit() {
     return 4096ull << 20;
 }
 
-// second-generation match finder: units of 4 candidates at level 4 (chain >> 2 = 4), else 8; levels
-// 7..9 (chains longer than one tile) keep the lanes' state in LDS between epochs
+// second-generation match finder: units of 4 candidates at level 4 (chain >> 2 = 4), else 8
 template <bool STREAM>
 void launch_match2(hipStream_t st, uint32_t n, int mode, const uint8_t* d_in, const fl_chunk* dch, const fl_tile* dti,
                    const uint32_t* dfp, const uint32_t* nsorted, const fl_params& prm, const uint16_t* S, uint32_t* rec) {
     if (mode == 4)
-        hipLaunchKernelGGL((k_lz_match2<STREAM, 4, false>), dim3(n), dim3(64 * FL_M2_WAVES_SHALLOW), 0, st, d_in, dch,
-                           dti, dfp, nsorted, prm, S, rec);
-    else if (mode <= 6)
-        hipLaunchKernelGGL((k_lz_match2<STREAM, 8, false>), dim3(n), dim3(64 * FL_M2_WAVES_SHALLOW), 0, st, d_in, dch,
-                           dti, dfp, nsorted, prm, S, rec);
+        hipLaunchKernelGGL((k_lz_match2<STREAM, 4>), dim3(n), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp, nsorted,
+                           prm, S, rec);
     else
-        hipLaunchKernelGGL((k_lz_match2<STREAM, 8, true>), dim3(n), dim3(64 * FL_M2_WAVES_DEEP), 0, st, d_in, dch, dti,
-                           dfp, nsorted, prm, S, rec);
+        hipLaunchKernelGGL((k_lz_match2<STREAM, 8>), dim3(n), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp, nsorted,
+                           prm, S, rec);
 }
 
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,

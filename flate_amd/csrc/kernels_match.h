@@ -10,28 +10,24 @@
 // Work decomposition (one workgroup per chunk / stream tile, the window staged in LDS):
 //  * a wave takes a SLICE of 256 consecutive sorted entries at a time.  It loads a tile of the
 //    128 entries before the slice and the slice itself with the first 8 window bytes of each
-//    (one 8-byte LDS word per entry), so comparing an entry with a candidate is one ds_read_b64.
-//  * the walk is cut into UNITS of G (8; 4 at level 4) consecutive candidates.  Round t of an
-//    epoch handles candidates G t + 1 .. G t + G of every entry that still has that many: the
-//    entries of the slice are ordered by their number of units, so the active ones are a prefix,
-//    and 64 of them fill a wave whatever their position in the slice.  That is what the first
-//    generation lacked: there a lane was tied to its entry for the whole walk and idled once its
-//    (short) chain was done -- lane efficiency 57 % on text, 75-85 % here.
-//  * a unit is evaluated branch-free on registers: per candidate two XORs, the trailing-equal-bytes
-//    mask, a packed score (equal bytes, then nearest), a max, and one bit "agrees in all 8 prefix
-//    bytes" shifted into a per-lane mask.  Only the winner of a unit touches the lane's key.
-//  * every 32 candidates (and where the chain >> 2 budget ends) the lanes serve their masks:
-//    SlidingWindow.match against the window (reject on one compare, then the extension), nearest
-//    candidate first, so `nice` ends a walk exactly where the reference ends it
-//    (deflate.zig:256-258).  Between two such points the order of evaluation does not matter: the
-//    key is a maximum, and an 8-byte candidate can never beat one that reached `nice` (>= 16).
-//  * units are processed in order, so the state of a lane after candidate k is the state of the
-//    reference's walk after k candidates: the chain >> 2 record is a snapshot.
+//    (one 8-byte LDS word per entry), so comparing an entry with a candidate is one ds_read_b64,
+//    and consecutive lanes read consecutive words (no bank conflicts).
+//  * lane = entry, 64 entries at a time; the walk runs in BLOCKS of 32 candidates, branch-free on
+//    registers: per candidate two XORs, the trailing-equal-bytes mask, the position bound, a packed
+//    score (equal bytes, then nearest), a max, and one bit "agrees in all 8 prefix bytes" shifted
+//    into a per-lane mask.  The first generation spent 25-30 instructions per candidate on lane-mask
+//    algebra; this is 9.
+//  * at the end of a block (and where the chain >> 2 budget ends) the block's winner meets the
+//    lane's key, then the lanes serve their masks: SlidingWindow.match against the window (reject
+//    on one compare, then the extension), nearest candidate first, so `nice` ends a walk exactly
+//    where the reference ends it (deflate.zig:256-258).  Inside a block the order of evaluation does
+//    not matter: the key is a maximum, and an 8-byte candidate never beats one that reached `nice`
+//    (>= 16).  Blocks are processed in order, so the chain >> 2 record is a snapshot.
 //  * chains longer than 128 (levels 7..9) run in epochs of 128 candidates, each with its own tile;
-//    the lanes' state waits in LDS between epochs.
+//    the lanes' state stays in registers.
 //
-// Bound: vector-ALU issue (about 8 instructions per candidate); the LDS carries one 8-byte read
-// per candidate.  No MFMA: byte compares and maxima.
+// Bound: vector-ALU issue; the LDS carries one 8-byte and one 2-byte read per candidate.  No MFMA:
+// byte compares and maxima.
 #pragma once
 #include "kernels_common.h"
 #include "kernels_lz.h"
@@ -57,28 +53,13 @@
 #define FL_M2_SLICE 256u   // sorted entries per wave step
 #define FL_M2_BACK 128u    // candidates per epoch = tile entries before the slice
 #define FL_M2_TILE (FL_M2_BACK + FL_M2_SLICE)
-// waves per workgroup: what fits next to the 64 KiB window (levels 7..9 keep 2 KiB more per wave)
-#define FL_M2_WAVES_SHALLOW 16
-#define FL_M2_WAVES_DEEP 12
+#define FL_M2_WAVES 12
+#define FL_M2_THREADS (64 * FL_M2_WAVES)
 
-template <bool DEEP>
 struct fl_m2_wave {
-    uint2 tW[FL_M2_TILE];       // first 8 window bytes of the tile's entries
-    uint2 est[DEEP ? FL_M2_SLICE : 1];  // between epochs: x = position | candidates allowed << 16 (0: walk ended), y = key
-    uint16_t tS[FL_M2_TILE];    // positions of the tile's entries
-    uint16_t nE[DEEP ? 1 : FL_M2_SLICE];  // candidates each entry of the slice may look at (levels 4..6)
-    uint8_t perm[FL_M2_SLICE];  // the slice's entries ordered by units left, most first
-    uint32_t cnt[40];           // bins of the counting sort; afterwards cnt[b] = entries with >= b units
+    uint2 tW[FL_M2_TILE];     // first 8 window bytes of the tile's entries
+    uint16_t tS[FL_M2_TILE];  // positions of the tile's entries
 };
-
-// trailing-equal-bytes score of one candidate: 0 when the first four bytes differ, else
-// (0x80 per further equal byte, low byte first) | 0x20 | tie, cut to the bytes `lenmask` allows
-__device__ __forceinline__ uint32_t fl_m2_score(uint2 w, uint32_t p0, uint32_t p1, uint32_t lenmask, uint32_t tie) {
-    const uint32_t x0 = w.x ^ p0, x1 = w.y ^ p1;
-    const uint32_t m = ~x1 & (x1 - 1u);  // ones below the lowest differing bit
-    const uint32_t s = (m & lenmask) | tie;
-    return x0 == 0 ? s : 0u;
-}
 
 // exact common prefix of the window at p and q, known to be >= len0, capped at maxlen
 __device__ __forceinline__ uint32_t fl_extend_from(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t len0,
@@ -100,19 +81,6 @@ __device__ __forceinline__ uint32_t fl_extend_from(const uint32_t* win32, uint32
         len += 8;
     }
     return min(len, maxlen);
-}
-
-// inclusive prefix sum over lanes 0 .. 47 (what the bins of the counting sort need) without LDS:
-// row_shr DPP adds inside the rows of 16 lanes, then the row totals
-__device__ __forceinline__ uint32_t fl_m2_scan48(uint32_t v, uint32_t lane) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
-    if (lane >= 16) v += t0;
-    if (lane >= 32) v += t1;
-    return v;
 }
 
 // the walk of one lane (= one sorted entry)
@@ -184,19 +152,32 @@ __device__ __forceinline__ uint32_t fl_m2_record(const fl_m2_lane& L, const uint
     return (le << 16) | (L.p - q - 1u);
 }
 
-template <bool STREAM, int G, bool DEEP>
-__global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW)) void k_lz_match2(
+__device__ __forceinline__ uint32_t fl_sel4(const uint32_t (&v)[4], uint32_t g) {
+    uint32_t r = v[0];
+    r = g == 1 ? v[1] : r;
+    r = g == 2 ? v[2] : r;
+    r = g == 3 ? v[3] : r;
+    return r;
+}
+__device__ __forceinline__ void fl_put4(uint32_t (&v)[4], uint32_t g, uint32_t x) {
+    v[0] = g == 0 ? x : v[0];
+    v[1] = g == 1 ? x : v[1];
+    v[2] = g == 2 ? x : v[2];
+    v[3] = g == 3 ? x : v[3];
+}
+
+template <bool STREAM, int G>
+__global__ __launch_bounds__(FL_M2_THREADS) void k_lz_match2(
     const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks, const fl_tile* __restrict__ tiles,
     const uint32_t* __restrict__ fpts, const uint32_t* __restrict__ n_sorted, fl_params prm,
     const uint16_t* __restrict__ S, uint32_t* __restrict__ rec_all) {
-    constexpr uint32_t NW = DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW;
+    constexpr uint32_t NW = FL_M2_WAVES;
     constexpr uint32_t NT = 64 * NW;
     constexpr uint32_t WIN_DW = STREAM ? FL_WIN_DW_STREAM : FL_WIN_DW_CHUNK;
-    constexpr uint32_t RPE = FL_M2_BACK / G;  // units per epoch
     __shared__ uint32_t win32[WIN_DW];
     __shared__ uint32_t bmask[2048 + 2];  // bit i: sorted entry i starts a bucket
     __shared__ uint16_t gcarry[1024 + 2];  // last bucket start before group g of 64 sorted entries
-    __shared__ fl_m2_wave<DEEP> wv[NW];
+    __shared__ fl_m2_wave wv[NW];
     const uint32_t c = blockIdx.x;
     const uint32_t w0 = STREAM ? tiles[c].w0 : 0u;
     const uint32_t tgt0 = STREAM ? tiles[c].tgt0 : 0u;
@@ -279,12 +260,7 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
     __syncthreads();
     fl_prof_mark(10);
 
-    fl_m2_wave<DEEP>& W = wv[wave];
-#ifdef FL_M2_PROF
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int k = 32; k < 48; k++) g_fl_prof[k] = 0;
-#endif
-    M2_T0();
+    fl_m2_wave& W = wv[wave];
     const uint32_t nslices = (M + FL_M2_SLICE - 1) / FL_M2_SLICE;
     // positions of the first tile of this wave's next slice, fetched one slice ahead
     uint32_t nxq[6];
@@ -310,7 +286,11 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                 nxq[r] = (sn < nslices && i < (int32_t)M) ? Sc[i] : 0u;
             }
         }
-        uint32_t nown[4];  // candidates each of the slice's entries may look at (epoch 0: lane = entry)
+        // the state of the slice's entries: group g of 64, lane = entry
+        uint32_t sp[4], sp0[4], sp1[4];  // position, window bytes p .. p+7
+        uint32_t sn_[4];                 // candidates the entry may look at in total; 0: the walk has ended
+        uint32_t srec[4], sqrec[4];      // records so far: full budget, chain >> 2 budget
+        uint32_t sflag[4];               // bit 0: the entry gets a record; bit 1: chain >> 2 snapshot taken
         uint32_t nepoch = 1;
         for (uint32_t ep = 0; ep < nepoch; ep++) {
             const uint32_t kbase = ep * FL_M2_BACK;  // candidates kbase + 1 .. kbase + 128
@@ -330,17 +310,22 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                 fl_lds_load8(win32, tq[r], a0, a1);
                 W.tS[64 * r + lane] = (uint16_t)tq[r];
                 W.tW[64 * r + lane] = make_uint2(a0, a1);
+                if (ep == 0 && r >= 2) {
+                    sp[r - 2] = tq[r];
+                    sp0[r - 2] = a0;
+                    sp1[r - 2] = a1;
+                }
             }
-            M2_ACC(33);
             if (ep == 0) {
                 // ---- the slice's own entries: candidates they may look at ----
-                uint32_t maxu = 0;
+                uint32_t maxn = 0;
 #pragma unroll
                 for (uint32_t g = 0; g < 4; g++) {
                     const uint32_t i = a + (g << 6) + lane;
-                    const uint32_t p = tq[2 + g];
+                    const uint32_t p = sp[g];
                     uint32_t n = 0;
-                    if (i < M && (!STREAM || p >= tgt0)) {
+                    const bool has = i < M && (!STREAM || p >= tgt0);
+                    if (has) {
                         // bucket offset = distance to the nearest bucket start at or before i, capped at chain
                         const uint32_t gi = i >> 6;
                         const uint32_t blo = bmask[2 * gi], bhi = bmask[2 * gi + 1];
@@ -354,74 +339,33 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                         else
                             st = gcarry[gi];
                         n = min(i - st, chain);
-                        if (n == 0) rec2[p] = make_uint2(0u, 0u);  // first of its bucket: no candidates, no match
                     }
-                    nown[g] = n;
-                    if (DEEP)
-                        W.est[(g << 6) + lane] = make_uint2(p | (n << 16), 0u);
-                    else
-                        W.nE[(g << 6) + lane] = (uint16_t)n;
-                    maxu = max(maxu, (n + G - 1) / G);
+                    sn_[g] = n;
+                    srec[g] = 0;
+                    sqrec[g] = 0;
+                    sflag[g] = has ? 1u : 0u;
+                    maxn = max(maxn, n);
                 }
-                maxu = fl_wave_max(maxu);
-                nepoch = max(1u, (maxu + RPE - 1) / RPE);
-                M2_ACC(32);
-            }
-            // ---- order the entries by the units they have left in this epoch (most first) ----
-            // (bins in reverse: bin r holds the entries with RPE - r units, so that a prefix sum gives
-            // the slots)
-            if (lane < 40) W.cnt[lane] = 0;
-            fl_lds_order();
-            uint32_t ub[4];
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++) {
-                const uint32_t n = DEEP ? (W.est[(g << 6) + lane].x >> 16) : nown[g];
-                const uint32_t left = n > kbase ? n - kbase : 0u;
-                ub[g] = min((left + G - 1) / G, RPE);
-                if (ub[g]) atomicAdd(&W.cnt[RPE - ub[g]], 1u);
+                maxn = fl_wave_max(maxn);
+                nepoch = max(1u, (maxn + FL_M2_BACK - 1) / FL_M2_BACK);
             }
             fl_lds_order();
-            {
-                const uint32_t cb = lane < RPE ? W.cnt[lane] : 0u;
-                const uint32_t incl = fl_m2_scan48(cb, lane);
-                fl_lds_order();
-                if (lane < RPE) W.cnt[lane] = incl - cb;  // first slot of the bin
-                if (lane == RPE - 1) W.cnt[RPE] = incl;   // entries with work in this epoch
-            }
-            fl_lds_order();
-#pragma unroll
-            for (uint32_t g = 0; g < 4; g++)
-                if (ub[g]) W.perm[atomicAdd(&W.cnt[RPE - ub[g]], 1u)] = (uint8_t)((g << 6) + lane);
-            fl_lds_order();
-            uint32_t A = __builtin_amdgcn_readfirstlane(W.cnt[RPE]);  // entries with work in this epoch
-            const bool nosort = (prm.dbg & 8) != 0;  // experiment: entries in their natural order
-            if (nosort) A = A ? FL_M2_SLICE : 0u;
-            M2_ACC(34);
 
-            // ---- the walks, 64 entries with about the same number of units at a time ----
+            // ---- the walks: lane = entry, 64 entries at a time ----
 #pragma unroll 1
-            for (uint32_t b0 = 0; b0 < A; b0 += 64) {
+            for (uint32_t g = 0; g < 4; g++) {
                 fl_m2_lane L;
-                const bool on = b0 + lane < A;
-                L.e = on ? (nosort ? b0 + lane : (uint32_t)W.perm[b0 + lane]) : 0u;
-                L.key = 0;
-                uint32_t oldrec = 0;  // the record the earlier epochs left
-                if (DEEP) {
-                    const uint2 st = W.est[L.e];
-                    L.p = st.x & 0xffffu;
-                    L.n = on ? st.x >> 16 : 0u;
-                    oldrec = st.y;
-                    L.key = (oldrec & 0xffff0000u) | 0xffffu;  // wins every tie: it is nearer
-                    fl_lds_load8(win32, L.p, L.p0, L.p1);
-                } else {
-                    // epoch 0: the entry's own slot of the tile, its chain length from its first lane
-                    L.p = W.tS[FL_M2_BACK + L.e];
-                    const uint2 w = W.tW[FL_M2_BACK + L.e];
-                    L.p0 = w.x;
-                    L.p1 = w.y;
-                    const uint32_t n = W.nE[L.e];
-                    L.n = on ? n : 0u;
-                }
+                L.e = (g << 6) + lane;
+                L.n = fl_sel4(sn_, g);
+                uint32_t nrel = L.n > kbase ? L.n - kbase : 0u;  // candidates of this epoch the lane may look at
+                const uint32_t kmax = min(fl_wave_max(nrel), FL_M2_BACK);
+                if (kmax == 0) continue;
+                L.p = fl_sel4(sp, g);
+                L.p0 = fl_sel4(sp0, g);
+                L.p1 = fl_sel4(sp1, g);
+                const uint32_t oldrec = fl_sel4(srec, g);  // the record the earlier epochs left
+                L.key = ep ? ((oldrec & 0xffff0000u) | 0xffffu) : 0u;  // (wins every tie: it is nearer)
+                uint32_t qrec = fl_sel4(sqrec, g), flag = fl_sel4(sflag, g);
                 L.maxlen = min(N - L.p, FL_MAX_MATCH);
                 if (STREAM && has_fl) L.maxlen = min(L.maxlen, fl_next_flush(fp, ck.n_flush, w0 + L.p, ck.in_len) - (w0 + L.p));
                 // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248), p - q <= 32768
@@ -430,33 +374,6 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                 if (STREAM && L.p >= zone) L.lov = max(L.lov, FL_MAX_DIST + 1u);
                 L.lenmask = L.maxlen >= 8 ? 0x80808080u : (0x00808080u >> (8 * (7 - L.maxlen)));
                 L.dm = 0;
-                uint32_t qrec = 0;
-                bool qsnap = false;
-                // Candidates get farther along the chain, so those the position bound allows are a
-                // prefix: the walk ends at the first one below the bound (deflate.zig:248-251).  Cut
-                // the lane's count there (binary search over this epoch's candidates, rarely needed).
-                bool cut = false;
-                M2_ACC(36);
-                {
-                    const uint32_t nr = L.n > kbase ? min(L.n - kbase, FL_M2_BACK) : 0u;
-                    uint32_t lo = 0, hi = nr;  // candidates 1 .. lo pass, candidate hi (if > lo) does not
-                    if (nr && W.tS[L.e + FL_M2_BACK - nr] >= L.lov) lo = nr;
-                    cut = lo < hi;
-                    if (__any(cut)) {
-#pragma unroll
-                        for (int it = 0; it < 7; it++) {  // hi - lo <= 128 halves to <= 1
-                            const uint32_t mid = (lo + hi) >> 1;
-                            const bool ok = W.tS[L.e + FL_M2_BACK - max(mid, 1u)] >= L.lov;
-                            const bool go = hi - lo > 1;
-                            lo = (go && ok) ? mid : lo;
-                            hi = (go && !ok) ? mid : hi;
-                        }
-                    }
-                    if (cut) L.n = lo ? kbase + lo : 0u;
-                }
-                M2_ACC(37);
-                uint32_t nrel = L.n > kbase ? L.n - kbase : 0u;  // candidates of this epoch the lane may look at
-                const uint32_t kmax = (prm.dbg & 16) ? 0u : min(fl_wave_max(nrel), FL_M2_BACK);  // (16: timing experiment, no walks)
                 uint32_t kdone = 0;
                 uint32_t bb = 0;  // best score of the current block of 32 candidates
                 // what a block (or the chain >> 2 budget) ends with: the block's winner meets the key,
@@ -481,16 +398,20 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                     if (L.n == 0) nrel = 0;
                     if (kbase + kdone == quarter) {  // the chain >> 2 budget (deflate.zig:241-245) ends here
                         qrec = fl_m2_record(L, W.tS, kbase, oldrec);
-                        qsnap = true;
-                        if (DEEP && on) rec2[L.p].y = qrec;
+                        flag |= 2u;
                     }
                 };
-                // tile words of the first unit; each unit fetches the next one's before it computes
+                // tile words and positions of the first unit; each unit fetches the next one's before it computes
                 uint2 cwn[G];
+                uint32_t cqn[G];
                 {
                     const uint2* cwp = &W.tW[L.e + FL_M2_BACK - G];
+                    const uint16_t* cqp = &W.tS[L.e + FL_M2_BACK - G];
 #pragma unroll
-                    for (int u = 0; u < G; u++) cwn[u] = cwp[G - 1 - u];
+                    for (int u = 0; u < G; u++) {
+                        cwn[u] = cwp[G - 1 - u];
+                        cqn[u] = cqp[G - 1 - u];
+                    }
                 }
 #pragma unroll 1
                 for (uint32_t kb = 0; kb < kmax; kb += 32) {  // a block: candidates kbase + kb + 1 .. + 32
@@ -498,39 +419,39 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                     for (uint32_t t = 0; t < 32 / G; t++) {
                         const uint32_t k0 = kb + G * t;  // this unit: candidates kbase + k0 + 1 .. + G
                         if (k0 < kmax) {
-                            const bool live = nrel > k0;
+                            // a lane whose count ends inside the unit needs no mask: what follows in the
+                            // tile are entries of other buckets, which differ in their first four bytes
+                            // (the hash is a function of those), or slots below sorted index 0, which
+                            // hold position 0 and fail the bound; a chain budget ends on a unit boundary
+                            const uint32_t lovu = nrel > k0 ? L.lov : 0xffffffffu;
                             uint2 cw[G];
+                            uint32_t cq[G];
 #pragma unroll
-                            for (int u = 0; u < G; u++) cw[u] = cwn[u];
+                            for (int u = 0; u < G; u++) {
+                                cw[u] = cwn[u];
+                                cq[u] = cqn[u];
+                            }
                             {
                                 const uint32_t kn = min(k0 + G, FL_M2_BACK - G);
                                 const uint2* cwp = &W.tW[L.e + FL_M2_BACK - kn - G];
+                                const uint16_t* cqp = &W.tS[L.e + FL_M2_BACK - kn - G];
 #pragma unroll
-                                for (int u = 0; u < G; u++) cwn[u] = cwp[G - 1 - u];
+                                for (int u = 0; u < G; u++) {
+                                    cwn[u] = cwp[G - 1 - u];
+                                    cqn[u] = cqp[G - 1 - u];
+                                }
                             }
-                            // A unit the count ends in: what follows in the tile are entries of other
-                            // buckets (they differ in their first four bytes: the hash is a function of
-                            // those), except where the count was cut by the position bound or the tile
-                            // reaches below sorted index 0 -- then the candidates beyond the count must
-                            // be masked.
-                            const bool partial = live && nrel < k0 + G && (cut || a + L.e < kbase + k0 + G);
-                            if (__any(partial)) {
-                                const uint32_t nv = nrel - min(nrel, k0);  // valid candidates of this unit (>= G: all)
 #pragma unroll
-                                for (int u = 0; u < G; u++) {
-                                    const uint32_t sc = fl_m2_score(cw[u], L.p0, L.p1, L.lenmask, 0x40u | (31u - (G * t + u)));
-                                    const uint32_t s = (uint32_t)u < nv ? sc : 0u;
-                                    bb = max(bb, s);
-                                    L.dm = __builtin_amdgcn_alignbit(L.dm, s, 31);
-                                }
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < G; u++) {
-                                    const uint32_t sc = fl_m2_score(cw[u], L.p0, L.p1, L.lenmask, 0x40u | (31u - (G * t + u)));
-                                    const uint32_t s = live ? sc : 0u;
-                                    bb = max(bb, s);
-                                    L.dm = __builtin_amdgcn_alignbit(L.dm, s, 31);
-                                }
+                            for (int u = 0; u < G; u++) {
+                                // trailing-equal-bytes score: 0 when the first four bytes differ or the
+                                // position is out of bounds, else (0x80 per further equal byte, low byte
+                                // first) | 0x40 | 31 - number in the block (nearest wins a tie)
+                                const uint32_t x0 = cw[u].x ^ L.p0, x1 = cw[u].y ^ L.p1;
+                                const uint32_t m = ~x1 & (x1 - 1u);  // ones below the lowest differing bit
+                                const uint32_t sc = (m & L.lenmask) | (0x40u | (31u - (G * t + u)));
+                                const uint32_t s = (x0 == 0 && cq[u] >= lovu) ? sc : 0u;
+                                bb = max(bb, s);
+                                L.dm = __builtin_amdgcn_alignbit(L.dm, s, 31);
                             }
                             kdone = k0 + G;
                             if (t + 1 < 32 / G && kbase + kdone == quarter) block_end(kb);
@@ -539,26 +460,19 @@ __global__ __launch_bounds__(64 * (DEEP ? FL_M2_WAVES_DEEP : FL_M2_WAVES_SHALLOW
                     block_end(kb);
                     if (!__any(nrel > kdone)) break;  // every walk of the group has ended
                 }
-                M2_CNT(40, 1);
-                M2_ACC(38);
-                if (DEEP) {
-                    // the lane's state waits for the next epoch; the full-budget record goes out when
-                    // the walk is over (the chain >> 2 half went out at its snapshot, or equals it)
-                    const bool more = L.n > kbase + FL_M2_BACK;
-                    const uint32_t rf = fl_m2_record(L, W.tS, kbase, oldrec);
-                    if (on) W.est[L.e] = make_uint2(L.p | ((more ? L.n : 0u) << 16), rf);
-                    if (on && !more) {
-                        rec2[L.p].x = rf;
-                        // the walk ended before the chain >> 2 budget did: both records are the same
-                        if (!qsnap && kbase < quarter) rec2[L.p].y = rf;
-                    }
-                } else if (on) {
-                    const uint32_t rf = fl_m2_record(L, W.tS, kbase, 0u);
-                    rec2[L.p] = make_uint2(rf, qsnap ? qrec : rf);
-                }
+                // the lane's state waits for the next epoch
+                const bool more = L.n > kbase + FL_M2_BACK;
+                fl_put4(srec, g, fl_m2_record(L, W.tS, kbase, oldrec));
+                fl_put4(sn_, g, more ? L.n : 0u);
+                fl_put4(sqrec, g, qrec);
+                fl_put4(sflag, g, flag);
             }
-            M2_ACC(39);
         }
+        // ---- records of the slice's entries (a walk that ended before the chain >> 2 budget did has
+        // the same record twice) ----
+#pragma unroll
+        for (uint32_t g = 0; g < 4; g++)
+            if (sflag[g] & 1u) rec2[sp[g]] = make_uint2(srec[g], (sflag[g] & 2u) ? sqrec[g] : srec[g]);
     }
     fl_prof_mark(11);
 }
