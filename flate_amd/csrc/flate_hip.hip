@@ -259,8 +259,12 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            if (prm.dbg & 2)
-                hipLaunchKernelGGL(k_lz_match<true>, dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
+            if (!(prm.dbg & (2 | 64)))
+                hipLaunchKernelGGL((k_lz_match<true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
+                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p);
+            else if (prm.dbg & 2)
+                hipLaunchKernelGGL((k_lz_match<true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
                                    (uint32_t*)h->rec.p);
             else
@@ -633,8 +637,12 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
-                    hipLaunchKernelGGL(k_lz_match<false>, dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
+                    hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
+                    hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
                                        (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
                 else

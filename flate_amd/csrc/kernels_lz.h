@@ -358,7 +358,11 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 #define FL_WIN_DW_CHUNK (16384 + 8)
 #define FL_WIN_DW_STREAM (16384 + 72)
 #define FL_ZONE_START (65536u - (FL_MAX_MATCH + 4u))  // deflate.zig:159-163 min_lookahead = 262
-template <bool STREAM>
+// BF: the candidates of a tile are scored branch-free (two XORs, the trailing-equal-bytes mask, the
+// position bound, a packed score "equal bytes, then nearest", a max, and one bit "agrees in all 8
+// prefix bytes"); only the tile's winner meets the lane's key, at the end of the tile.  Same
+// result: the key is a maximum.
+template <bool STREAM, bool BF>
 __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks,
                                                                   const fl_tile* __restrict__ tiles,
@@ -555,8 +559,62 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 }
             }
         };
+        // ---- BF ----
+        const uint32_t lenmask = maxlen >= 8 ? 0x80808080u : (0x00808080u >> (8 * (7 - maxlen)));
+        uint32_t bb = 0;     // best score of the current tile: equal-byte flags | 0x40 | 32 - candidate number
+        uint32_t kdone = 0;  // candidates of the current tile scored so far; dmask bit b = candidate kdone - b
+        auto flush_deep_bf = [&]() {
+            if (maxlen <= 8 || (prm.dbg & 4)) dmask = 0;  // (4: timing experiment, wrong output)
+            while (__any(dmask != 0)) {
+                if (dmask) {
+                    const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
+                    dmask &= ~(1u << b);
+                    const uint32_t q = ts[FL_KB + lane - (kdone - b)];
+                    const uint32_t best = key >> 16;
+                    // SlidingWindow.zig:91-98: a candidate that does not extend the best match is
+                    // dropped on one compare
+                    bool take = maxlen > best;
+                    if (take && best >= 8) take = fl_lds_load4(win32, q + best - 3) == pb;
+                    if (take) {
+                        const uint32_t le = fl_extend_match(win32, p, q, maxlen);
+                        const uint32_t kc = (le << 16) | (q + cp);
+                        if (kc > key) {  // deflate.zig:254-261
+                            key = kc;
+                            pb = fl_lds_load4(win32, p + le - 3);
+                            if (le >= maxlen || le >= nice) {  // nothing longer possible / stop looking
+                                n = 0;
+                                lov = 0x7fffffffu;
+                                dmask = 0;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // the tile's winner meets the key, then the 8-byte candidates meet the window
+        auto tile_end_bf = [&]() {
+            if (__any(bb != 0)) {
+                if (bb) {
+                    const uint32_t q = ts[FL_KB + lane - (32u - (bb & 31u))];
+                    const uint32_t le = min(4u + (uint32_t)__popc(bb & 0x80808080u), maxlen);
+                    const uint32_t kc = (le << 16) | (q + cp);
+                    if (kc > key) {  // deflate.zig:254-261
+                        key = kc;
+                        if (le >= 8) pb = fl_lds_load4(win32, p + le - 3);
+                        if (le >= maxlen) {  // nothing longer possible (le <= 8 < nice here)
+                            n = 0;
+                            lov = 0x7fffffffu;
+                            dmask = 0;
+                        }
+                    }
+                }
+                bb = 0;
+            }
+            flush_deep_bf();
+        };
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
+            kdone = 0;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64) with their first 8 bytes
             fl_lds_order();
             {
@@ -583,13 +641,34 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 // the chain >> 2 budget (deflate.zig:241-245) ends after candidate `quarter`
                 // (a multiple of 4 at every level, deflate.zig:44-49)
                 if (kb + kk0 - 1 == quarter) {
-                    flush_deep();
+                    if (BF)
+                        tile_end_bf();
+                    else
+                        flush_deep();
                     qkey = key;
                     qsnap = true;
                 }
                 if (!__any(n >= kb + kk0)) break;
                 tsp -= 4;
                 twp -= 4;
+                if (BF) {
+                    // (the compiler turns the conditions into branches that skip the remaining loads of a
+                    // candidate whose first four bytes differ; measured faster than forcing them straight)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t q = tsp[3 - u];
+                        const uint2 w = twp[3 - u];
+                        const uint32_t x0 = w.x ^ p0, x1 = w.y ^ p1;
+                        const uint32_t m = ~x1 & (x1 - 1u);  // ones below the lowest differing bit
+                        const uint32_t sc = (m & lenmask) | (0x40u | (32u - (kk0 + u)));
+                        // (a lane whose walk has ended has lov = 0x7fffffff)
+                        const uint32_t s = (x0 == 0 && q >= lov) ? sc : 0u;
+                        bb = max(bb, s);
+                        dmask = __builtin_amdgcn_alignbit(dmask, s, 31);
+                    }
+                    kdone = kk0 + 3;
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t q = tsp[3 - u];
@@ -622,7 +701,10 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 // serves them all: do it now; a match of `nice` bytes then ends the walk early.
                 if (__popcll(__ballot(dmask != 0)) >= 40) flush_deep();
             }
-            flush_deep();
+            if (BF)
+                tile_end_bf();
+            else
+                flush_deep();
         }
         if (!qsnap) qkey = key;
         if (active) {
