@@ -637,6 +637,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
             // candidate kk of this tile sits in slot FL_KB + lane - kk; walk the slots downwards
             const uint16_t* tsp = ts + FL_KB + lane;
             const uint2* twp = tw + FL_KB + lane;
+#pragma unroll
             for (uint32_t kk0 = 1; kk0 <= FL_KB; kk0 += 4) {
                 // the chain >> 2 budget (deflate.zig:241-245) ends after candidate `quarter`
                 // (a multiple of 4 at every level, deflate.zig:44-49)
