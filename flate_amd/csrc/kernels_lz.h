@@ -465,7 +465,10 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 const uint32_t st = below ? base1 + 63u - (uint32_t)__builtin_clzll(below) : carry;
                 if (valid) {
                     const uint32_t n = min(i + 1 - st, chain);
-                    const uint32_t qn = n ? Sc[i - n] : 0xffffu;
+                    // (BF needs no position of candidate n: what follows candidate n in the tile is another
+                    // bucket -- other first four bytes --, the end of the chain budget, or a slot below
+                    // sorted index 0, which holds position 0 and fails the position bound)
+                    const uint32_t qn = BF ? 0u : (n ? Sc[i - n] : 0xffffu);
                     NQc[i] = n | (qn << 16);
                 }
                 if (starts) carry = base1 + 63u - (uint32_t)__builtin_clzll(starts);
