@@ -671,6 +671,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                         dmask = __builtin_amdgcn_alignbit(dmask, s, 31);
                     }
                     kdone = kk0 + 3;
+                    // When most lanes are waiting for the window anyway (runs, long repeats), one round
+                    // serves them all: do it now; a match of `nice` bytes then ends the walk early.
+                    if ((kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) tile_end_bf();  // (every 8 candidates)
                     continue;
                 }
 #pragma unroll
