@@ -1,18 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X DEFLATE engine.
 
-Workload (BASELINE.json configs[1]): raw deflate, level 6, 1 GiB of synthetic
+Default workload (BASELINE.json configs[1]): raw deflate, level 6, 1 GiB of synthetic
 enwik-like text per GPU, cut into independent 65535-byte chunks (one stream each,
 bit-exact with the reference's output for that chunk), inputs resident in HBM when
 the timed region starts.  One "step" = one pass of the whole compress path over the
-batch.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every
-rank compresses its own 1 GiB (weak scaling) and the compressed shards are
-reassembled on every rank with an RCCL all-gather, as BASELINE.json's north_star asks.
+batch.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N`
+without a launcher re-executes itself under `python -m torch.distributed.run` with N
+ranks on 127.0.0.1; under a launcher (WORLD_SIZE set) it checks that the world size is N.
+Every rank compresses its own shard (weak scaling, no data-path collective) and the
+compressed shards are reassembled on every rank over RCCL, as BASELINE.json's
+north_star asks.
+
+Other configurations of BASELINE.json (parity-test cases, not the headline):
+  --config 3   gzip level 9, TAR-like 177,244,160 bytes per rank, 65535-byte chunks
+  --config 4   huffman-only gzip, ONE 128 MiB Silesia-like stream per rank, RCCL reassembly
+  --config 5   batched gunzip of 128 x 1 MiB gzip-6 members per rank (the members of the whole
+               job are sharded over the ranks by ISIZE), outputs == inputs
+The flags of the reference's bin/deflate_bench.zig:101-114 are accepted too: -l LEVEL, -g (gzip),
+-z (zlib), -o FILE (write rank 0's first stream), -c (the same to stdout), plus an input file.
 
 Prints ONE JSON line (rank 0).  `value` = uncompressed MB/s (1e6 B/s) of the whole job.
-Extra keys: `roofline` (dominant kernel, HIP-event timed on the launch stream inside
-the timed region), `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1),
-`decompress` (GPU inflate of the produced streams, same batch).
+Extra keys: `roofline` (dominant kernel, HIP-event timed on the launch stream inside the
+timed region), `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1),
+`cpu_baseline_all_cores`, `e2e_host` (host buffers in and out over PCIe), `decompress`
+(GPU inflate of the produced streams, same batch), `other_workloads` (all-zero, Silesia-like,
+1 MiB streams; smaller buffers, same run).
 """
 import argparse
 import json
@@ -25,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 CHUNK = 65535
+MODE_NAMES = {0: "store", 1: "huffman-only"}
 
 
 def parse():
@@ -32,33 +48,183 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bytes", type=int, default=1 << 30, help="uncompressed bytes per GPU")
-    ap.add_argument("--workload", default="text", choices=["text", "zeros", "silesia"])
-    ap.add_argument("--mode", type=int, default=6, help="0 store, 1 huffman-only, 4..9 level")
-    ap.add_argument("--container", type=int, default=0, help="0 raw, 1 gzip, 2 zlib")
-    ap.add_argument("--chunk", type=int, default=CHUNK)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--bytes", type=int, default=None, help="uncompressed bytes per GPU (default: the configuration's)")
+    ap.add_argument("--workload", default=None, choices=["text", "zeros", "silesia", "tar"])
+    ap.add_argument("--mode", type=int, default=None, help="0 store, 1 huffman-only, 4..9 level")
+    ap.add_argument("-l", dest="level", type=int, default=None, help="compression level 4..9 (deflate_bench.zig -l)")
+    ap.add_argument("--container", type=int, default=None, help="0 raw, 1 gzip, 2 zlib")
+    ap.add_argument("-g", dest="gzip", action="store_true", help="gzip container (deflate_bench.zig -g)")
+    ap.add_argument("-z", dest="zlib", action="store_true", help="zlib container (deflate_bench.zig -z)")
+    ap.add_argument("-o", dest="out_file", default=None, help="write rank 0's first output stream to this file")
+    ap.add_argument("-c", dest="to_stdout", action="store_true", help="write rank 0's first output stream to stdout")
+    ap.add_argument("input_file", nargs="?", default=None, help="compress this file instead of synthetic data")
+    ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL reassembly of the output")
     ap.add_argument("--force-gather", action="store_true", help="run the reassembly path even with one rank (test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=8192)
+    ap.add_argument("--cpu-sample-chunks", type=int, default=4096)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-decompress", action="store_true",
                     help="skip the inflate leg (one wave per stream: a single huge stream would take minutes)")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip other_workloads / e2e_host / all-core baseline")
+    a = ap.parse_args()
+    # the configuration's defaults
+    d = {2: dict(workload="text", mode=6, container=0, chunk=CHUNK, bytes=1 << 30),
+         3: dict(workload="tar", mode=9, container=1, chunk=CHUNK, bytes=177_244_160),
+         4: dict(workload="silesia", mode=1, container=1, chunk=128 << 20, bytes=128 << 20),
+         5: dict(workload="silesia", mode=6, container=1, chunk=1 << 20, bytes=128 << 20)}[a.config]
+    if a.level is not None:
+        a.mode = a.level
+    if a.gzip:
+        a.container = 1
+    if a.zlib:
+        a.container = 2
+    for k, v in d.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    a.headline = a.config == 2 and a.workload == "text" and a.mode == 6 and a.container == 0 and a.chunk == CHUNK \
+        and a.input_file is None
+    return a
+
+
+def maybe_spawn(args):
+    """`--gpus N` (N > 1) outside a launcher: run N ranks of this script under torch.distributed.run."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def make_input(torch, args, rank, device):
+    import numpy as np
     from flate_amd import synth
     n = args.bytes
+    if args.input_file:
+        with open(args.input_file, "rb") as f:
+            buf = np.frombuffer(f.read(), dtype=np.uint8)
+        args.bytes = buf.size
+        return torch.from_numpy(buf.copy()).to(device)
     if args.workload == "zeros":
         return torch.zeros(n, dtype=torch.uint8, device=device)
     if args.workload == "silesia":
         return torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA + rank, n)).to(device)
+    if args.workload == "tar":
+        return torch.from_numpy(synth.tar_like(synth.SEED_TAR + rank, n)).to(device)
     return synth.text_torch(synth.SEED_TEXT + 7919 * rank, n, device=device)
+
+
+class CompressJob:
+    """Device-resident buffers of one compress batch + the step function."""
+
+    def __init__(self, torch, eng, data, chunk, container, mode):
+        import numpy as np
+        from flate_amd import synth
+        self.torch, self.eng, self.data = torch, eng, data
+        self.container, self.mode = container, mode
+        device = data.device
+        self.n_in = data.numel()
+        self.off_np = synth.split_offsets(self.n_in, chunk)
+        self.n_chunks = len(self.off_np) - 1
+        caps = np.array([(eng.compress_bound(int(self.off_np[i + 1] - self.off_np[i]), container, mode) + 7) & ~7
+                         for i in range(self.n_chunks)], dtype=np.uint64)
+        self.out_off_np = np.zeros(self.n_chunks + 1, dtype=np.uint64)
+        np.cumsum(caps, out=self.out_off_np[1:])
+        self.in_off = torch.from_numpy(self.off_np.astype(np.int64)).to(device)
+        self.out_off = torch.from_numpy(self.out_off_np.astype(np.int64)).to(device)
+        self.out = torch.empty(int(self.out_off_np[-1]) + 8, dtype=torch.uint8, device=device)
+        self.out_len = torch.zeros(self.n_chunks, dtype=torch.int64, device=device)
+        self.status = torch.zeros(self.n_chunks, dtype=torch.int32, device=device)
+
+    def step(self):
+        self.eng.compress_device(self.data.data_ptr(), self.in_off.data_ptr(), self.n_chunks, self.container, self.mode,
+                                 self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(),
+                                 self.status.data_ptr())
+
+    def results(self):
+        import numpy as np
+        st = self.status.cpu().numpy()
+        lens = self.out_len.cpu().numpy()
+        assert (st == 0).all(), "non-zero chunk status: %s" % np.unique(st)
+        return lens
+
+    def packed(self, lens):
+        """The produced streams back to back (device) + their offsets."""
+        import numpy as np
+        from flate_amd import sharded
+        torch = self.torch
+        n_out = int(lens.sum())
+        comp_off_np = np.zeros(self.n_chunks + 1, dtype=np.int64)
+        np.cumsum(lens, out=comp_off_np[1:])
+        comp = torch.empty(n_out + 8, dtype=torch.uint8, device=self.data.device)
+        idx_src = torch.from_numpy(self.out_off_np[:-1].astype(np.int64)).to(self.data.device)
+        comp_off = torch.from_numpy(comp_off_np).to(self.data.device)
+        sharded.compact(self.out, idx_src, self.out_len, comp, comp_off, engine=self.eng)
+        return comp, comp_off, n_out
+
+
+class InflateJob:
+    def __init__(self, torch, eng, comp, comp_off, n_streams, out_off, n_out, container):
+        self.eng, self.comp, self.comp_off, self.n, self.out_off, self.container = eng, comp, comp_off, n_streams, out_off, container
+        dev = comp.device
+        self.dec = torch.empty(n_out + 8, dtype=torch.uint8, device=dev)
+        self.dec_len = torch.zeros(n_streams, dtype=torch.int64, device=dev)
+        self.dec_st = torch.zeros(n_streams, dtype=torch.int32, device=dev)
+
+    def step(self):
+        self.eng.decompress_device(self.comp.data_ptr(), self.comp_off.data_ptr(), self.n, self.container, 0,
+                                   self.dec.data_ptr(), self.out_off.data_ptr(), self.dec_len.data_ptr(),
+                                   self.dec_st.data_ptr())
+
+
+def timed(torch, dist, eng, step, steps, warmup, world):
+    """warmup untimed steps, then `steps` steps bracketed by barrier + synchronize; max over ranks."""
+    def fence():
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, prof
+
+
+def roofline_of(prof, steps, algo_bytes, traffic=None):
+    dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 1))
+    dom_ms = dom[1][0] / max(dom[1][1], 1)
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic(dom[0]) if traffic else None,
+            "kernel_ms": round(dom_ms, 4),
+            "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items())}}
 
 
 def main():
     args = parse()
+    maybe_spawn(args)
+    # ONE JSON line on stdout: libraries that print banners from C (RCCL does) get stderr instead
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -68,179 +234,190 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if "WORLD_SIZE" in os.environ and args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1 or args.force_gather:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+        assert dist.get_world_size() == world, "RCCL world size %d != %d" % (dist.get_world_size(), world)
 
-    from flate_amd import Engine, synth
-    from flate_amd import sharded
+    from flate_amd import Engine, sharded
 
+    # Everything -- the engine's kernels, torch's copies, the RCCL collectives -- is ordered on ONE
+    # explicit (non-default) stream: the engine treats a NULL stream as "its own", which torch and
+    # RCCL would not be ordered against.
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
     eng = Engine(local)
-    stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     eng.set_sync(False)
 
-    data = make_input(torch, args, rank, device)
-    n_in = data.numel()
-    off_np = synth.split_offsets(n_in, args.chunk)
-    n_chunks = len(off_np) - 1
-    caps = np.array([(eng.compress_bound(int(off_np[i + 1] - off_np[i]), args.container, args.mode) + 7) & ~7
-                     for i in range(n_chunks)], dtype=np.uint64)
-    out_off_np = np.zeros(n_chunks + 1, dtype=np.uint64)
-    np.cumsum(caps, out=out_off_np[1:])
-    in_off = torch.from_numpy(off_np.astype(np.int64)).to(device)
-    out_off = torch.from_numpy(out_off_np.astype(np.int64)).to(device)
-    out = torch.empty(int(out_off_np[-1]) + 8, dtype=torch.uint8, device=device)
-    out_len = torch.zeros(n_chunks, dtype=torch.int64, device=device)
-    status = torch.zeros(n_chunks, dtype=torch.int32, device=device)
-    gather = None
-    if (world > 1 or args.force_gather) and not args.no_gather:
-        gather = sharded.OutputGather(world, rank, device, int(out_off_np[-1]))
-
-    def step():
-        eng.compress_device(data.data_ptr(), in_off.data_ptr(), n_chunks, args.container, args.mode, out.data_ptr(),
-                            out_off.data_ptr(), out_len.data_ptr(), status.data_ptr())
-        if gather is not None:
-            gather.run(out, out_off, out_len)
-
-    def fence():
-        if world > 1 or args.force_gather:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    st = status.cpu().numpy()
-    lens = out_len.cpu().numpy()
-    assert (st == 0).all(), "non-zero chunk status: %s" % np.unique(st)
-    n_out = int(lens.sum())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * n_in * args.steps / dt / 1e6
-
-    # ---- decompress leg: GPU inflate of the streams just produced (same batch) ----
-    comp_off_np = np.zeros(n_chunks + 1, dtype=np.int64)
-    np.cumsum(lens, out=comp_off_np[1:])
-    comp = torch.empty(n_out + 8, dtype=torch.uint8, device=device)
-    idx_src = torch.from_numpy(out_off_np[:-1].astype(np.int64)).to(device)
-    sharded.compact(out, idx_src, out_len, comp, torch.from_numpy(comp_off_np).to(device))
-    comp_off = torch.from_numpy(comp_off_np).to(device)
-    dec = torch.empty(n_in + 8, dtype=torch.uint8, device=device)
-    dec_len = torch.zeros(n_chunks, dtype=torch.int64, device=device)
-    dec_st = torch.zeros(n_chunks, dtype=torch.int32, device=device)
-
-    def dstep():
-        eng.decompress_device(comp.data_ptr(), comp_off.data_ptr(), n_chunks, args.container, 0, dec.data_ptr(),
-                              in_off.data_ptr(), dec_len.data_ptr(), dec_st.data_ptr())
-
-    dsteps = max(1, min(args.steps, 3))
-    ddt, dprof = float("nan"), {}
-    if not args.no_decompress:
-        dstep()
-        fence()
-        eng.profile_reset()
-        eng.profile_enable(True)
-        t0 = time.perf_counter()
-        for _ in range(dsteps):
-            dstep()
-        fence()
-        ddt = time.perf_counter() - t0
-        dprof = eng.profile_read()
-        eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([ddt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ddt = float(t.item())
-    roundtrip_ok = args.no_decompress or (int(dec_st.abs().sum().item()) == 0 and bool(torch.equal(dec[:n_in], data)))
-    assert roundtrip_ok or args.no_verify, "inflate(deflate(x)) != x"  # --no-verify: kernel tuning experiments only
-
-    result = None
+    if args.config == 5:
+        result = run_config5(args, torch, dist if use_dist else None, eng, world, rank, device)
+    else:
+        result = run_compress(args, torch, dist if use_dist else None, eng, world, rank, device)
     if rank == 0:
-        # dominant kernel of the compress path
-        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 1))
-        dom_ms = dom[1][0] / max(dom[1][1], 1)
-        algo_bytes = n_in + n_out  # SURVEY.md 8d: read every input byte once, write every output byte once
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": measured_traffic(args, n_in, dom[0]),
-                    "kernel_ms": round(dom_ms, 4),
-                    "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, data, off_np, out, out_off_np, lens)
-        elif not args.no_verify:
-            verify_sample(args, data, off_np, out, out_off_np, lens, 64)
-        dd = max(dprof.items(), key=lambda kv: kv[1][0]) if dprof else ("none", (0.0, 1))
-        result = {
-            "metric": "MB/s uncompressed, deflate level 6 compress" if args.mode == 6 else
-                      "MB/s uncompressed, deflate mode %d compress" % args.mode,
-            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "raw deflate level %d, %d MiB synthetic enwik-like text per GPU, %d-byte "
-                                   "independent chunks (%d chunks), one MI355X per rank" %
-                                   (args.mode, n_in >> 20, args.chunk, n_chunks)
-                       if args.workload == "text" else
-                       "%s, mode %d, %d MiB per GPU, %d-byte chunks" % (args.workload, args.mode, n_in >> 20, args.chunk),
-                       "container": ["raw", "gzip", "zlib"][args.container], "chunk_bytes": args.chunk,
-                       "bytes_per_gpu": n_in, "ratio": round(n_out / max(n_in, 1), 4),
-                       "gather": "rccl all_gather of compressed shards" if gather is not None else "none"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "decompress": None if args.no_decompress else {"value": round(world * n_in * dsteps / ddt / 1e6, 2), "unit": "MB/s",
-                           "ms_per_step": round(ddt / dsteps * 1e3, 3), "kernel": dd[0],
-                           "roundtrip_equal": roundtrip_ok,
-                           "roofline_frac": round((n_in + n_out) / (ddt / dsteps) / 1e9 / HBM_PEAK_GBS, 5)},
-        }
-        print(json.dumps(result))
-        sys.stdout.flush()
-    if gather is not None and rank == 0:
-        # the reassembled shard of this rank must be the packed streams themselves
-        sizes = gather.run(out, out_off, out_len)
-        torch.cuda.synchronize()
-        assert sizes[rank] == n_out and torch.equal(gather.shard(rank, sizes), comp[:n_out]), "gather mismatch"
-    elif gather is not None:
-        gather.run(out, out_off, out_len)
-    if world > 1 or args.force_gather:
+        if getattr(args, "stdout_stream", None) is not None:
+            sys.stderr.write(json.dumps(result) + "\n")
+            os.write(real_stdout, args.stdout_stream)
+        else:
+            os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return result
 
 
+def run_compress(args, torch, dist, eng, world, rank, device):
+    import numpy as np
+    from flate_amd import sharded
+    data = make_input(torch, args, rank, device)
+    job = CompressJob(torch, eng, data, args.chunk, args.container, args.mode)
+    n_in = job.n_in
+    gather = None
+    if dist is not None and not args.no_gather:
+        gather = sharded.OutputGather(world, rank, device, int(job.out_off_np[-1]), engine=eng)
+        job.step()
+        gather.calibrate(job.out, job.out_off, job.out_len)  # one host sync, outside the timed region
+
+    def step():
+        job.step()
+        if gather is not None:
+            gather.run(job.out, job.out_off, job.out_len)
+
+    dt, prof = timed(torch, dist, eng, step, args.steps, args.warmup, world)
+    lens = job.results()
+    n_out = int(lens.sum())
+    if gather is not None:
+        assert not gather.overflowed(), "a packed shard outgrew the calibrated gather width"
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n_in * args.steps / dt / 1e6
+
+    # ---- decompress leg: GPU inflate of the streams just produced (same batch) ----
+    comp, comp_off, _ = job.packed(lens)
+    dsteps = max(1, min(args.steps, 3))
+    ddt, dprof, roundtrip_ok = float("nan"), {}, True
+    if not args.no_decompress:
+        inf = InflateJob(torch, eng, comp, comp_off, job.n_chunks, job.in_off, n_in, args.container)
+        ddt, dprof = timed(torch, dist, eng, inf.step, dsteps, 1, world)
+        roundtrip_ok = int(inf.dec_st.abs().sum().item()) == 0 and bool(torch.equal(inf.dec[:n_in], data))
+        assert roundtrip_ok or args.no_verify, "inflate(deflate(x)) != x"  # --no-verify: kernel tuning experiments only
+
+    result = None
+    if rank == 0:
+        algo_bytes = n_in + n_out  # SURVEY.md 8d: read every input byte once, write every output byte once
+        roofline = roofline_of(prof, args.steps, algo_bytes, lambda k: measured_traffic(args, n_in, k))
+        cpu = cpu_all = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, data, job.off_np, job.out, job.out_off_np, lens)
+            if not args.no_extras:
+                cpu_all = cpu_baseline_all_cores(args, data, job.off_np)
+        elif not args.no_verify:
+            verify_sample(args, data, job.off_np, job.out, job.out_off_np, lens, 64)
+        dd = max(dprof.items(), key=lambda kv: kv[1][0]) if dprof else ("none", (0.0, 1))
+        mode_name = MODE_NAMES.get(args.mode, "level %d" % args.mode)
+        wl = {"text": "synthetic enwik-like text", "zeros": "all-zero bytes", "silesia": "synthetic Silesia-like mix",
+              "tar": "synthetic TAR-like buffer"}[args.workload] if not args.input_file else os.path.basename(args.input_file)
+        result = {
+            "metric": "MB/s uncompressed, deflate level 6 compress" if args.mode == 6 else
+                      "MB/s uncompressed, deflate %s compress" % mode_name,
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic" if not args.input_file else "file",
+            "config": {"workload": "%s deflate %s, %d MiB %s per GPU, %d-byte independent chunks (%d chunks), one "
+                                   "MI355X per rank (BASELINE.json configs[%d])" %
+                                   (["raw", "gzip", "zlib"][args.container], mode_name, n_in >> 20, wl, args.chunk,
+                                    job.n_chunks, args.config - 1),
+                       "container": ["raw", "gzip", "zlib"][args.container], "chunk_bytes": args.chunk,
+                       "bytes_per_gpu": n_in, "ratio": round(n_out / max(n_in, 1), 4),
+                       "gather": "rccl exchange of the compressed shards (%s)" % gather.algo if gather is not None else "none"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
+            "decompress": None if args.no_decompress else {
+                "value": round(world * n_in * dsteps / ddt / 1e6, 2), "unit": "MB/s",
+                "ms_per_step": round(ddt / dsteps * 1e3, 3), "kernel": dd[0], "roundtrip_equal": roundtrip_ok,
+                "roofline_frac": round((n_in + n_out) / (ddt / dsteps) / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if args.headline and world == 1 and not args.no_extras:
+            result["e2e_host"] = e2e_host(torch, eng, data, job)
+            result["other_workloads"] = other_workloads(args, torch, eng, device)
+        if args.out_file or args.to_stdout:
+            first = job.out[: int(lens[0])].cpu().numpy().tobytes()
+            if args.out_file:
+                with open(args.out_file, "wb") as f:
+                    f.write(first)
+            else:
+                args.stdout_stream = first  # -c: the stream owns stdout, the JSON line goes to stderr
+    if gather is not None:
+        # the reassembled shard of this rank must be the packed streams themselves
+        gather.run(job.out, job.out_off, job.out_len)
+        torch.cuda.synchronize()
+        if rank == 0:
+            sizes = gather.sizes_host()
+            assert sizes[rank] == n_out and torch.equal(gather.shard(rank, sizes), comp[:n_out]), "gather mismatch"
+    return result
+
+
+def run_config5(args, torch, dist, eng, world, rank, device):
+    """BASELINE.json configs[4]: batched gunzip of 1 MiB gzip members.  The job's members (128 per
+    rank) are sharded over the ranks by ISIZE; every rank builds and inflates its
+    own range, no collective in the data path."""
+    import numpy as np
+    from flate_amd import sharded, synth
+    per, sz = 128, args.chunk
+    total = per * world
+    lo, hi = sharded.shard_ranges([sz] * total, world)[rank]
+    m = hi - lo
+    raw = torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA + 1 + rank, m * sz)).to(device)
+    mk = CompressJob(torch, eng, raw, sz, 1, 6)  # the members: gzip level 6 of each slice (this engine, == oracle)
+    mk.step()
+    torch.cuda.synchronize()
+    lens = mk.results()
+    comp, comp_off, n_comp = mk.packed(lens)
+    inf = InflateJob(torch, eng, comp, comp_off, m, mk.in_off, m * sz, 1)
+    dt, prof = timed(torch, dist, eng, inf.step, args.steps, args.warmup, world)
+    ok = int(inf.dec_st.abs().sum().item()) == 0 and bool(torch.equal(inf.dec[: m * sz], raw))
+    assert ok, "gunzip output != input"
+    if rank != 0:
+        return None
+    if not args.no_verify:  # the members are what the reference would have written
+        O = _oracle()
+        for i in (0, m // 2, m - 1):
+            a = int(comp_off[i].item())
+            got = comp[a:a + int(lens[i])].cpu().numpy().tobytes()
+            assert got == O.compress(raw[i * sz:(i + 1) * sz].cpu().numpy().tobytes(), O.GZIP, 6)
+    n_out = m * sz
+    return {"metric": "MB/s uncompressed, batched gunzip (inflate)", "value": round(world * n_out * args.steps / dt / 1e6, 2),
+            "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batched gunzip of %d x %d-byte gzip level-6 members of a Silesia-like buffer per GPU, "
+                                   "sharded by ISIZE (BASELINE.json configs[4])" % (m, sz),
+                       "members_per_gpu": m, "ratio": round(n_comp / n_out, 4), "outputs_equal_inputs": ok},
+            "roofline": roofline_of(prof, args.steps, n_comp + n_out), "cpu_baseline": None}
+
+
 def measured_traffic(args, n_in, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (FETCH_SIZE + WRITE_SIZE, two separate
-    rocprofv3 --pmc runs of this very command; profiles/r01_hbm_traffic_1gib.json), when the workload matches;
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, two separate
+    rocprofv3 --pmc runs of this very command; profiles/r0N_hbm_traffic_1gib.json), when the workload matches;
     PMC counters cannot be read from inside an un-profiled run, so otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_1gib.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t["workload"] == args.workload and t["bytes_per_gpu"] == n_in and t["mode"] == args.mode and \
-                args.chunk == CHUNK and kernel in t["kernels"]:
-            k = t["kernels"][kernel]
-            return k["fetch_bytes"] + k["write_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r02_hbm_traffic_1gib.json", "r01_hbm_traffic_1gib.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t["workload"] == args.workload and t["bytes_per_gpu"] == n_in and t["mode"] == args.mode and \
+                    args.chunk == CHUNK and kernel in t["kernels"]:
+                k = t["kernels"][kernel]
+                return k["fetch_bytes"] + k["write_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
@@ -257,6 +434,8 @@ def verify_sample(args, data, off_np, out, out_off_np, lens, k):
     n_chunks = len(off_np) - 1
     pick = np.unique(np.linspace(0, n_chunks - 1, k).astype(np.int64))
     for i in pick:
+        if int(off_np[i + 1] - off_np[i]) > (8 << 20):
+            continue  # (a single huge stream: the -m gpu tests compare those with the oracle)
         src = data[int(off_np[i]):int(off_np[i + 1])].cpu().numpy().tobytes()
         got = out[int(out_off_np[i]):int(out_off_np[i]) + int(lens[i])].cpu().numpy().tobytes()
         assert got == O.compress(src, args.container, args.mode), "chunk %d differs from the oracle" % i
@@ -266,10 +445,12 @@ def cpu_baseline(args, data, off_np, out, out_off_np, lens):
     """The CPU oracle (a C port of the reference algorithm; the Zig reference itself cannot be
     built here) on a bounded sample of the same chunks, one host thread.  Doubles as the
     parity check of those chunks."""
-    import numpy as np
     O = _oracle()
     n_chunks = len(off_np) - 1
-    k = min(n_chunks, args.cpu_sample_chunks)
+    # ~10-20 s of CPU work: the slower the level, the fewer chunks
+    k = min(n_chunks, args.cpu_sample_chunks if args.mode <= 6 else max(args.cpu_sample_chunks // 4, 1))
+    while k > 1 and int(off_np[k]) > (512 << 20):
+        k //= 2
     hi = int(off_np[k])
     host = data[:hi].cpu().numpy().tobytes()
     outs_lo, outs_hi = int(out_off_np[0]), int(out_off_np[k])
@@ -281,8 +462,120 @@ def cpu_baseline(args, data, off_np, out, out_off_np, lens):
         a = int(out_off_np[i]) - outs_lo
         assert gpu_out[a:a + int(lens[i])].tobytes() == comp[i], "chunk %d differs from the oracle" % i
     return {"value": round(hi / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d chunks (%d MiB) of the same input, same level, oracle/flate_oracle.c -O3 "
+            "sample": "first %d chunks (%d MiB) of the same input, same mode, oracle/flate_oracle.c -O3 "
                       "-march=native; every sampled chunk byte-identical to the GPU output" % (k, hi >> 20)}
+
+
+def _cpu_worker(job):
+    blob, offs, container, mode = job
+    O = _oracle()
+    t0 = time.perf_counter()
+    n = 0
+    for i in range(len(offs) - 1):
+        n += len(O.compress(blob[offs[i]:offs[i + 1]], container, mode))
+    return time.perf_counter() - t0, n
+
+
+def cpu_baseline_all_cores(args, data, off_np):
+    """The same oracle over the same independent chunks with one worker process per host core
+    (SURVEY.md 8d (ii)): the aggregate a multi-threaded caller of the reference would see."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(cores, 64))
+    per = 256 if args.mode <= 6 else 64  # chunks per worker (~0.4 s each at level 6)
+    n_chunks = len(off_np) - 1
+    workers = min(workers, n_chunks)
+    per = max(1, min(per, n_chunks // workers))
+    k = per * workers
+    hi = int(off_np[k])
+    host = data[:hi].cpu().numpy().tobytes()
+    jobs = []
+    for w in range(workers):
+        a, b = int(off_np[w * per]), int(off_np[(w + 1) * per])
+        jobs.append((host[a:b], [int(off_np[w * per + i]) - a for i in range(per + 1)], args.container, args.mode))
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        pool.map(_cpu_worker, jobs)
+    dt = time.perf_counter() - t0
+    return {"value": round(hi / dt / 1e6, 2), "unit": "MB/s", "cores": workers, "host_cores_visible": cores, "kind": "port",
+            "sample": "%d chunks (%d MiB) of the same input over %d worker processes, wall time incl. process start"
+                      % (k, hi >> 20, workers)}
+
+
+def e2e_host(torch, eng, data, job):
+    """Host buffers in and out (FLATE_HIP_MEM_HOST): H2D + kernels + D2H over PCIe, 256 MiB of the same
+    input, straight through the C ABI.  Never `value`."""
+    import numpy as np
+    from flate_amd import _capi
+    L = _capi.lib()
+    n = min(data.numel(), 256 << 20)
+    k = int(np.searchsorted(job.off_np, n, side="right")) - 1
+    hi = int(job.off_np[k])
+    host = data[:hi].cpu().numpy()
+    in_off = job.off_np[:k + 1].astype(np.uint64)
+    out_off = job.out_off_np[:k + 1].astype(np.uint64)
+    out = np.zeros(int(out_off[-1]) + 8, dtype=np.uint8)
+    out_len = np.zeros(k, dtype=np.uint64)
+    status = np.zeros(k, dtype=np.int32)
+
+    def comp():
+        rc = L.flate_hip_compress_batch(eng._h, host.ctypes.data, in_off.ctypes.data, k, job.container, job.mode,
+                                        out.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data,
+                                        _capi.MEM_HOST)
+        assert rc == 0 and not status.any()
+
+    comp()  # staging buffers
+    t0 = time.perf_counter()
+    comp()
+    dt = time.perf_counter() - t0
+    # inflate: the streams packed back to back, outputs into the original layout
+    lens = out_len.astype(np.int64)
+    c_off = np.zeros(k + 1, dtype=np.uint64)
+    np.cumsum(lens, out=c_off[1:].view(np.int64))
+    packed = np.concatenate([out[int(out_off[i]):int(out_off[i]) + int(lens[i])] for i in range(k)])
+    dec = np.zeros(hi + 8, dtype=np.uint8)
+    dlen = np.zeros(k, dtype=np.uint64)
+
+    def decomp():
+        rc = L.flate_hip_decompress_batch(eng._h, packed.ctypes.data, c_off.ctypes.data, k, job.container, 0,
+                                          dec.ctypes.data, in_off.ctypes.data, dlen.ctypes.data, status.ctypes.data,
+                                          None, _capi.MEM_HOST)
+        assert rc == 0 and not status.any()
+
+    decomp()
+    t1 = time.perf_counter()
+    decomp()
+    dt2 = time.perf_counter() - t1
+    assert np.array_equal(dec[:hi], host)
+    return {"compress_MBps": round(hi / dt / 1e6, 1), "decompress_MBps": round(hi / dt2 / 1e6, 1), "bytes": hi,
+            "note": "pageable host memory through flate_hip_*_batch(MEM_HOST): H2D, kernels and D2H in sequence "
+                    "(not overlapped)"}
+
+
+def other_workloads(args, torch, eng, device):
+    """The north star's other inputs, smaller buffers, same run: level 6 raw."""
+    import numpy as np
+    from flate_amd import synth
+    res = {}
+    cases = [("zeros_256MiB_64KiB_chunks", lambda: torch.zeros(256 << 20, dtype=torch.uint8, device=device), CHUNK),
+             ("silesia_like_128MiB_64KiB_chunks",
+              lambda: torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA, 128 << 20)).to(device), CHUNK),
+             ("text_256MiB_1MiB_streams", lambda: synth.text_torch(synth.SEED_TEXT, 256 << 20, device=device), 1 << 20)]
+    for name, mk, chunk in cases:
+        d = mk()
+        job = CompressJob(torch, eng, d, chunk, 0, 6)
+        dt, prof = timed(torch, None, eng, job.step, 2, 1, 1)
+        lens = job.results()
+        ok = None
+        if not args.no_verify:
+            a = argparse.Namespace(container=0, mode=6)
+            verify_sample(a, d, job.off_np, job.out, job.out_off_np, lens, 8 if chunk == CHUNK else 2)
+            ok = True
+        res[name] = {"MBps": round(d.numel() * 2 / dt / 1e6, 1), "ratio": round(float(lens.sum()) / d.numel(), 4),
+                     "sampled_chunks_equal_oracle": ok}
+        del job, d
+    return res
 
 
 if __name__ == "__main__":

@@ -100,11 +100,19 @@ class _Compressor:
         self._emitted = 0    # bytes of the stream already handed to the writer
         self._done = False
 
+    def _live(self):
+        # the reference's compressor has no such check (writing after finish() emits a broken stream);
+        # the mirror refuses instead of handing the writer bytes that do not extend the finished stream
+        if self._done:
+            raise InvalidState("compressor used after finish()")
+
     def write(self, data):  # deflate.zig:363-367
+        self._live()
         self._buf += data
         return len(data)
 
     def compress(self, reader):  # deflate.zig:304-321
+        self._live()
         self._buf += _read_all(reader)
 
     def writer(self):  # deflate.zig:369-371
@@ -118,6 +126,7 @@ class _Compressor:
         self._emitted = len(out)
 
     def flush(self):  # deflate.zig:335-337: pending tokens out, then an empty stored block; history stays
+        self._live()
         self._flushes.append(len(self._buf))
         self._run(False)
 

@@ -413,7 +413,15 @@ int flate_hip_destroy(flate_hip_handle h) {
 
 int flate_hip_set_stream(flate_hip_handle h, void* hip_stream) {
     if (!h) return FLATE_HIP_E_INVALID_ARG;
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    if (next != h->stream) {
+        // work enqueued on the old stream still uses the workspace: drain it before the next call
+        // (which may grow, i.e. free, those buffers) runs on another stream
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        fold_profile(h);
+    }
+    h->stream = next;
     return FLATE_HIP_OK;
 }
 int flate_hip_set_sync(flate_hip_handle h, int s) {

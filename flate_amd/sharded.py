@@ -2,8 +2,8 @@
 independent, so each rank runs the single-GPU path on its own contiguous range of
 chunks with no data-path collective; the only exchange is the reassembly of the
 output: ranks all-gather their packed sizes (tiny) and then every rank's packed
-shard is broadcast to its peers over RCCL (xGMI is point to point: one shard per
-link, no ring).
+shard goes to each peer as one grouped send/recv batch over RCCL (xGMI is point to
+point: one shard per link, no ring), see OutputGather.
 
 torch.distributed is plumbing here (backend "nccl" = RCCL on ROCm; "gloo" in the
 CPU tests of the protocol).
@@ -14,6 +14,8 @@ import numpy as np
 def shard_ranges(sizes, world):
     """Contiguous chunk ranges balanced by input bytes: list of (lo, hi) per rank."""
     sizes = np.asarray(sizes, dtype=np.int64)
+    if world <= 0:
+        raise ValueError("world must be positive")
     total = int(sizes.sum())
     cs = np.concatenate(([0], np.cumsum(sizes)))
     bounds = [0]
@@ -56,39 +58,103 @@ def compact(out, out_slot_start, out_len, dst, dst_off, engine=None):
 class OutputGather:
     """Reassemble the compressed output of all ranks on every rank.
 
-    Every rank packs its streams back to back, the packed sizes are all-gathered (one int64
-    per rank), and the shards are exchanged with ONE all-gather of equal-sized slices (each
-    padded to the largest shard): on xGMI every GPU has a direct link to every peer, so all
-    shards move concurrently.  `gathered[r, :sizes[r]]` is rank r's packed output afterwards.
+    Every rank packs its streams back to back (HIP kernel of libflate_hip.so), the packed sizes are
+    all-gathered (one int64 per rank, they stay on the device) and every rank's shard travels to
+    every peer as one slice of a common width.  Two exchange forms:
+      "p2p"         one grouped batch of send/recv pairs (RCCL ncclGroupStart .. ncclSend / ncclRecv ..
+                    ncclGroupEnd): every GPU has a direct xGMI link to every peer, so the 7 shards of a
+                    rank move on 7 links at once -- the form SURVEY.md 8e prefers (default on nccl)
+      "all_gather"  one all_gather_into_tensor of the padded slices (the library picks the algorithm)
+    Width: `calibrate()` (once, outside a timed loop) fixes it from the first batch with some slack, after
+    which `run()` never touches the host; a shard that outgrows it raises a device-side flag
+    (`overflowed()`).  Without calibration `run()` reads the sizes on the host every time (exact width).
+    `gathered[r * width : r * width + sizes[r]]` is rank r's packed output afterwards.
+
+    Stream contract: the engine must run on torch's CURRENT stream (Engine.set_stream(
+    torch.cuda.current_stream().cuda_stream) with a non-default stream current): the pack kernel, the
+    collectives and the next step's kernels are then ordered by that one stream.
     """
 
-    def __init__(self, world, rank, device, local_cap, engine=None):
+    def __init__(self, world, rank, device, local_cap, engine=None, algo=None):
         import torch
+        import torch.distributed as dist
         from .engine import default_engine
         self.world, self.rank, self.device = world, rank, device
         self.engine = engine if engine is not None else (default_engine() if device.type == "cuda" else None)
-        self.local_cap = (int(local_cap) + 15) & ~15
+        # per-rank capacities differ when the shards are uneven: everybody allocates the largest
+        cap = torch.tensor([int(local_cap)], dtype=torch.int64, device=device)
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        self.local_cap = (int(cap.item()) + 15) & ~15
+        assert int(local_cap) <= self.local_cap
         self.packed = torch.empty(self.local_cap + 16, dtype=torch.uint8, device=device)
         self.sizes = torch.zeros(world, dtype=torch.int64, device=device)
-        # one flat buffer: a step uses its first world * width bytes as `world` equal slices, which
-        # is what all_gather_into_tensor wants (no per-rank tensor list, no staging copy)
         self.gathered = torch.empty(world * self.local_cap, dtype=torch.uint8, device=device)
+        self.over = torch.zeros(1, dtype=torch.int64, device=device)
         self.width = 0
+        self.calibrated = False
         self.dst_off = None
+        if algo is None:
+            algo = "p2p" if (dist.is_initialized() and dist.get_backend() == "nccl") else "all_gather"
+        self.algo = algo
 
-    def run(self, out, out_off, out_len):
-        """out_off: n+1 slot starts; out_len: n produced lengths.  Returns the per-rank packed sizes."""
+    def _pack(self, out, out_off, out_len):
         import torch
-        import torch.distributed as dist
         n = out_len.numel()
         if self.dst_off is None or self.dst_off.numel() != n + 1:
             self.dst_off = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
         pack_streams(self.engine, out, out_off, out_len, self.packed, self.dst_off)
+        return n
+
+    def _exchange(self, width):
+        import torch.distributed as dist
+        g = self.gathered
+        if self.algo == "all_gather" or self.world == 1:
+            dist.all_gather_into_tensor(g[: self.world * width], self.packed[:width])
+            return
+        ops = []
+        for d in range(1, self.world):
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            ops.append(dist.P2POp(dist.isend, self.packed[:width], to))
+            ops.append(dist.P2POp(dist.irecv, g[frm * width:(frm + 1) * width], frm))
+        g[self.rank * width:(self.rank + 1) * width].copy_(self.packed[:width])
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def calibrate(self, out, out_off, out_len, slack=1.05):
+        """Fix the slice width from this batch (one host sync): max packed size over the ranks * slack."""
+        import torch.distributed as dist
+        n = self._pack(out, out_off, out_len)
         dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
         sizes = [int(x) for x in self.sizes.cpu().tolist()]
-        self.width = (max(sizes) + 15) & ~15  # same slice width on every rank
-        dist.all_gather_into_tensor(self.gathered[: self.world * self.width], self.packed[: self.width])
+        assert max(sizes) <= self.local_cap, "a packed shard is larger than the gather buffer"
+        self.width = min(self.local_cap, (int(max(sizes) * slack) + 4096 + 15) & ~15)
+        self.calibrated = True
+        self.over.zero_()
         return sizes
+
+    def run(self, out, out_off, out_len):
+        """out_off: n+1 slot starts; out_len: n produced lengths.  Calibrated: no host access, returns
+        None (sizes stay in `self.sizes` on the device).  Otherwise returns the per-rank packed sizes."""
+        import torch
+        import torch.distributed as dist
+        n = self._pack(out, out_off, out_len)
+        dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
+        if self.calibrated:
+            self.over += (self.sizes.max() > self.width).to(torch.int64)
+            self._exchange(self.width)
+            return None
+        sizes = [int(x) for x in self.sizes.cpu().tolist()]
+        assert max(sizes) <= self.local_cap, "a packed shard is larger than the gather buffer"
+        self.width = (max(sizes) + 15) & ~15  # same slice width on every rank
+        self._exchange(self.width)
+        return sizes
+
+    def overflowed(self):
+        return bool(int(self.over.item()))
+
+    def sizes_host(self):
+        return [int(x) for x in self.sizes.cpu().tolist()]
 
     def shard(self, r, sizes):
         return self.gathered[r * self.width: r * self.width + sizes[r]]

@@ -43,11 +43,24 @@ def _worker(rank, world, port, q):
             z = O.compress(c, O.GZIP, 6)
             out[int(out_off[i]):int(out_off[i]) + len(z)] = torch.frombuffer(bytearray(z), dtype=torch.uint8)
             out_len[i] = len(z)
-        g = sharded.OutputGather(world, rank, torch.device("cpu"), int(out_off[-1]))
-        sizes = g.run(out, out_off, out_len)
-        whole = b"".join(g.shard(r, sizes).numpy().tobytes() for r in range(world))
         want = b"".join(O.compress(c, O.GZIP, 6) for c in chunks)
-        q.put((rank, whole == want, sizes, ranges))
+        ok = True
+        for algo in ("all_gather", "p2p"):
+            # exact mode: sizes read on the host every step
+            g = sharded.OutputGather(world, rank, torch.device("cpu"), int(out_off[-1]), algo=algo)
+            sizes = g.run(out, out_off, out_len)
+            whole = b"".join(g.shard(r, sizes).numpy().tobytes() for r in range(world))
+            ok = ok and whole == want
+            # calibrated mode: one host sync up front, then none; the sizes stay in a tensor
+            g2 = sharded.OutputGather(world, rank, torch.device("cpu"), int(out_off[-1]), algo=algo)
+            g2.calibrate(out, out_off, out_len)
+            assert g2.run(out, out_off, out_len) is None and not g2.overflowed()
+            s2 = g2.sizes_host()
+            ok = ok and s2 == sizes and b"".join(g2.shard(r, s2).numpy().tobytes() for r in range(world)) == want
+        # ranks with different slot capacities agree on one buffer size
+        g3 = sharded.OutputGather(world, rank, torch.device("cpu"), int(out_off[-1]) + 1000 * rank)
+        ok = ok and g3.local_cap >= int(out_off[-1]) + 1000 * rank
+        q.put((rank, ok, sizes, ranges, g3.local_cap))
     finally:
         dist.destroy_process_group()
 
@@ -76,6 +89,71 @@ def test_two_rank_gather_reassembles_every_shard_on_every_rank():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, ok, sizes, ranges in res:
+    for rank, ok, sizes, ranges, cap in res:
         assert ok, rank
         assert len(sizes) == world and all(s > 0 for s in sizes)
+    assert len({r[4] for r in res}) == 1  # one buffer size on every rank
+
+
+def _inflate(member):
+    r = O.decompress(member, O.GZIP)
+    assert r[0] == "Ok"
+    return r[1]
+
+
+def test_inflate_shards_by_isize():
+    """Config #5's partitioning: gzip members go to ranks by ISIZE (the trailer's
+    uncompressed size), contiguous and balanced; together the ranges cover every member once."""
+    rng = np.random.default_rng(5)
+    data = synth.text(synth.SEED_TEXT, 1 << 20).tobytes()
+    cuts = np.sort(rng.choice(np.arange(1, len(data)), 40, replace=False))
+    pieces = [data[a:b] for a, b in zip(np.r_[0, cuts], np.r_[cuts, len(data)])]
+    members = [O.compress(p, O.GZIP, 6) for p in pieces]
+    isize = [int.from_bytes(m[-4:], "little") for m in members]
+    assert isize == [len(p) for p in pieces]
+    for world in (2, 3, 8):
+        ranges = sharded.shard_ranges(isize, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(members)
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        per = [sum(isize[a:b]) for a, b in ranges]
+        assert max(per) - min(per) <= 2 * max(isize)
+        back = b"".join(_inflate(m) for a, b in ranges for m in members[a:b])
+        assert back == data
+
+
+def test_bench_spawns_the_ranks_itself():
+    """`bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N
+    ranks (checked without a GPU: the command line it would exec)."""
+    import importlib.util
+    import sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    old_execv, old_argv, old_ws = os.execv, sys.argv, os.environ.pop("WORLD_SIZE", None)
+    try:
+        os.execv = lambda exe, cmd: seen.setdefault("cmd", cmd)
+        sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"]
+        args = bench.parse()
+        bench.maybe_spawn(args)
+    finally:
+        os.execv, sys.argv = old_execv, old_argv
+        if old_ws is not None:
+            os.environ["WORLD_SIZE"] = old_ws
+    cmd = seen["cmd"]
+    assert "torch.distributed.run" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    # under a launcher nothing is spawned
+    os.environ["WORLD_SIZE"] = "4"
+    try:
+        seen.clear()
+        os.execv = lambda exe, cmd: seen.setdefault("cmd", cmd)
+        bench.maybe_spawn(args)
+        assert not seen
+    finally:
+        os.execv = old_execv
+        if old_ws is None:
+            os.environ.pop("WORLD_SIZE", None)
+        else:
+            os.environ["WORLD_SIZE"] = old_ws
