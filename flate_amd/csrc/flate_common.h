@@ -62,6 +62,15 @@ static __device__ __forceinline__ uint32_t fl_plan_wave_sum(uint32_t v) {
 #define FL_PLAN_SYNC()
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FL_PLAN_PROF)
+extern __device__ uint64_t g_fl_prof[];
+#define FL_PLAN_MARK(slot)                                                                          \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] = __builtin_readcyclecounter();    \
+    } while (0)
+#else
+#define FL_PLAN_MARK(slot)
+#endif
 #define FL_MAX_TOKENS 32768u     // consts.zig:7  tokens per block
 #define FL_MIN_MATCH 4u          // consts.zig:12
 #define FL_MAX_MATCH 258u        // consts.zig:13
@@ -188,6 +197,93 @@ struct fl_block_plan {
 // sentinel is 65535 (maxInt(u16), :189,282-287) whereas the "out of leaves and
 // pairs" test (:170) compares with maxInt(i32) and therefore never fires;
 // comparisons are strict `<` on u32.
+#if FL_PLAN_PARALLEL
+// Device form of the loop below: the same steps in the same order, but the state of level L
+// (last_freq, next_char_freq, next_pair_freq, needed, and the diagonal leaf count) lives in lane L
+// of five registers, read and written with v_readlane / v_writelane (a few cycles) instead of LDS
+// round trips; the sorted frequencies sit in five more registers.  Only the off-diagonal leaf
+// counts (copied row to row by the lanes) stay in LDS.  The CPU build (tests/cpu_shim) runs the
+// plain loop; both are checked against the reference's vectors and the oracle.
+static __device__ __forceinline__ uint32_t fl_rl(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+static __device__ __forceinline__ uint32_t fl_wl(uint32_t v, uint32_t x, uint32_t l) {
+    return FL_PLAN_LANE() == l ? x : v;
+}
+static __device__ void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
+    const uint16_t* freq = ws->list_freq;
+    if (max_bits > n - 1) max_bits = n - 1;
+    const uint32_t lane = FL_PLAN_LANE();
+    uint32_t fr[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) fr[k] = (64 * k + lane < n) ? (uint32_t)freq[64 * k + lane] : 65535u;
+    auto freq_at = [&](uint32_t idx) -> uint32_t {
+        const uint32_t r = idx >> 6, l = idx & 63;
+        uint32_t v = fl_rl(fr[0], l);
+        if (r == 1) v = fl_rl(fr[1], l);
+        if (r == 2) v = fl_rl(fr[2], l);
+        if (r == 3) v = fl_rl(fr[3], l);
+        if (r == 4) v = fl_rl(fr[4], l);
+        return v;
+    };
+    for (uint32_t i = lane; i < 17 * 16; i += 64) (&ws->leaf_counts[0][0])[i] = 0;
+    FL_PLAN_SYNC();
+    const uint32_t f0 = fl_rl(fr[0], 0), f1 = fl_rl(fr[0], 1), f2 = fl_rl(fr[0], 2);
+    const bool lv_on = lane >= 1 && lane <= max_bits;
+    uint32_t lastF = lv_on ? f1 : 0u, nChar = lv_on ? f2 : 0u;
+    uint32_t nPair = lv_on ? (lane == 1 ? 0x7fffffffu : f0 + f1) : 0u;
+    uint32_t need = lane == max_bits ? 2 * n - 4 : 0u;
+    uint32_t diag = lv_on ? 2u : 0u;  // leaf_counts[L][L]
+    uint32_t level = max_bits;
+    for (;;) {
+        level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);
+        const uint32_t npf = fl_rl(nPair, level), ncf = fl_rl(nChar, level);
+        if (npf == 0x7fffffffu && ncf == 0x7fffffffu) {
+            need = fl_wl(need, 0u, level);
+            nPair = fl_wl(nPair, 0x7fffffffu, level + 1);
+            level += 1;
+            continue;
+        }
+        const uint32_t prev_freq = fl_rl(lastF, level);
+        uint32_t lf;
+        if (ncf < npf) {
+            const uint32_t next = fl_rl(diag, level) + 1;
+            lf = ncf;
+            diag = fl_wl(diag, next, level);
+            nChar = fl_wl(nChar, next >= n ? 65535u : freq_at(next), level);
+        } else {
+            lf = npf;
+            // row level - 1 (with its diagonal) becomes the left part of row level
+            const uint32_t dprev = fl_rl(diag, level - 1);
+            if (lane < level) ws->leaf_counts[level][lane] = lane == level - 1 ? dprev : ws->leaf_counts[level - 1][lane];
+            FL_PLAN_SYNC();
+            need = fl_wl(need, 2u, level - 1);
+        }
+        lastF = fl_wl(lastF, lf, level);
+        const uint32_t nd = fl_rl(need, level) - 1;
+        need = fl_wl(need, nd, level);
+        if (nd == 0) {
+            if (level == max_bits) break;
+            nPair = fl_wl(nPair, prev_freq + lf, level + 1);
+            level += 1;
+        } else {
+            while (fl_rl(need, level - 1) > 0) {
+                level -= 1;
+                if (level == 0) break;
+            }
+        }
+    }
+    // bit_count[b] = leaf_counts[max][max - b + 1] - leaf_counts[max][max - b]   (huffman_encoder.zig:239-246)
+    if (lane < 17) ws->bit_count[lane] = 0;
+    FL_PLAN_SYNC();
+    const uint32_t dmax = fl_rl(diag, max_bits);
+    if (lane >= 1 && lane <= max_bits) {
+        const uint32_t hi = lane == max_bits ? dmax : ws->leaf_counts[max_bits][lane];
+        ws->bit_count[max_bits - lane + 1] = hi - ws->leaf_counts[max_bits][lane - 1];
+    }
+    FL_PLAN_SYNC();
+}
+#else
 FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
     const uint16_t* freq = ws->list_freq;
     fl_level_info* levels = ws->levels;
@@ -267,6 +363,8 @@ FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
         bits++;
     }
 }
+
+#endif
 
 // huffman_encoder.zig:62-95 + 251-278.
 FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq,
@@ -357,7 +455,9 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
         lfrq[j] = f;
     }
 #endif
+    if (nfreq == FL_NUM_LIT) FL_PLAN_MARK(49);
     fl_huff_bit_counts(ws, count, max_bits);
+    if (nfreq == FL_NUM_LIT) FL_PLAN_MARK(50);
     uint32_t used_bits = max_bits > count - 1 ? count - 1 : max_bits;
     uint32_t code = 0;
     uint32_t list_len = count;
@@ -616,6 +716,7 @@ FL_HD void fl_plan_token_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_
 // ---- planner for a huffman-only block: huffmanBlock, block_writer.zig:524-572 ----
 // ws->lit_freq[0..255] holds the byte histogram of the block's input.
 FL_HD void fl_plan_huffman_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t in_len, uint32_t eof) {
+    FL_PLAN_MARK(48);
     FL_PLAN_FOR(i, 256, FL_NUM_LIT) ws->lit_freq[i] = 0;
     FL_PLAN_SYNC();
     ws->lit_freq[FL_EOB] = 1;
@@ -631,8 +732,11 @@ FL_HD void fl_plan_huffman_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t i
     ws->dist_freq[0] = 1;
     ws->dist_codes[0].len = 1;
     fl_huff_generate(ws, ws->lit_freq, FL_NUM_LIT, 15, ws->lit_codes);
+    FL_PLAN_MARK(51);
     fl_generate_codegen(ws, num_literals, num_distances, ws->lit_codes, ws->dist_codes);
+    FL_PLAN_MARK(52);
     fl_huff_generate(ws, ws->cg_freq, FL_NUM_CG, 7, ws->cg_codes);
+    FL_PLAN_MARK(53);
     uint32_t num_codegens;
     uint32_t size = fl_dynamic_header_size(ws, &num_codegens) +
                     fl_huff_bit_length(ws->lit_codes, ws->lit_freq, FL_NUM_LIT) +
@@ -659,4 +763,5 @@ FL_HD void fl_plan_huffman_block(fl_plan_ws* ws, fl_block_plan* plan, uint32_t i
     }
     fl_hdr_finish(&w);
     plan->hdr_nbits = w.nbits;
+    FL_PLAN_MARK(54);
 }
