@@ -212,6 +212,11 @@ class _Decompressor:
         self._pos += self._used
         self._out, self._rp, self._ended = None, 0, False
 
+    def more_input(self):
+        """True when input is left after the stream just decoded (a further concatenated member)."""
+        self._decode()
+        return self._pos + self._used < len(self._in)
+
     def set_reader(self, new_reader):  # inflate.zig:283-288
         self._in, self._pos = _read_all(new_reader), 0
         self._out, self._rp, self._ended = None, 0, False

@@ -1,5 +1,6 @@
 """GPU parity tests of the inflate path: outputs and per-stream status (the reference's
 error names, inflate.zig:487-527) identical to the oracle's, through the C ABI."""
+import os
 import zlib as pyzlib
 
 import numpy as np
@@ -161,3 +162,73 @@ def test_differential_fuzz_against_oracle(flags):
             if got_name != name or (name == "Ok" and (outs[i] != want or used[i] != wused)):
                 bad.append((i, len(s), got_name, name, len(outs[i]), len(want), used[i], wused))
         assert not bad, (container, flags, len(bad), bad[:5])
+
+
+def test_gpu_inflate_agrees_with_puff_on_mutated_streams():
+    """The reference's differential harness (bin/fuzz_puff.zig:42-50): raw deflate input through
+    puff.c and through the inflater; both fail or both produce the same bytes.  Here the inflater
+    is the GPU kernel (default flags: RFC-conformant headers, as puff accepts them)."""
+    if not O.puff_available():
+        pytest.skip("oracle/_ref/libpuff.so not built")
+    eng = engine()
+    rng = np.random.default_rng(77)
+    from flate_amd import synth
+    base = [O.compress(synth.text(synth.SEED_TEXT + k, 3000 + 517 * k).tobytes(), O.RAW, lvl)
+            for k, lvl in enumerate((4, 6, 9, O.HUFFMAN, O.STORE))]
+    base += [O.compress(bytes(5000), O.RAW, 6), O.compress(rng.integers(0, 256, 4000, dtype=np.uint8).tobytes(), O.RAW, 6)]
+    cases = list(base)
+    for s in base:
+        b = bytearray(s)
+        for _ in range(12):
+            m = bytearray(b)
+            kind = int(rng.integers(0, 4))
+            if kind == 0 and len(m) > 4:
+                del m[int(rng.integers(1, len(m))):]
+            elif kind == 1:
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:
+                i = int(rng.integers(0, len(m)))
+                m[i:i + 3] = rng.integers(0, 256, 3, dtype=np.uint8).tobytes()
+            else:
+                m += rng.integers(0, 256, 5, dtype=np.uint8).tobytes()
+            cases.append(bytes(m))
+    outs, st, used = eng.decompress_many(cases, O.RAW, caps=[1 << 17] * len(cases))
+    agree_ok = agree_err = 0
+    for c, o, s in zip(cases, outs, st):
+        rc, want = O.puff(c, cap=1 << 17)
+        if rc == 0:
+            assert s == 0 and o == want, (rc, s)
+            agree_ok += 1
+        else:
+            assert s != 0, (rc, s)
+            agree_err += 1
+    assert agree_ok >= len(base) and agree_err > 0
+
+
+def test_cli_gzip_gunzip_round_trip(tmp_path):
+    """tools/gzip.py / tools/gunzip.py (bin/gzip.zig:20, bin/gunzip.zig:25-27): the .gz is the oracle's,
+    gunzip restores the file, a second member appended to the file is decoded too."""
+    import importlib.util
+    engine()
+    from conftest import ROOT
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    from flate_amd import synth
+    data = synth.text(synth.SEED_TEXT, 200001).tobytes()
+    f = tmp_path / "a.txt"
+    f.write_bytes(data)
+    assert load("gzip").main([str(f)]) == 0
+    gz = (tmp_path / "a.txt.gz").read_bytes()
+    assert gz == O.compress(data, O.GZIP, 6)
+    f.unlink()
+    assert load("gunzip").main([str(f) + ".gz"]) == 0
+    assert f.read_bytes() == data
+    (tmp_path / "b.gz").write_bytes(gz + O.compress(b"second member", O.GZIP, 9))
+    assert load("gunzip").main([str(tmp_path / "b.gz")]) == 0
+    assert (tmp_path / "b").read_bytes() == data + b"second member"
+    assert load("gunzip").main([str(f)]) == 1  # not a .gz name

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""gunzip <file>.gz: writes <file> with the MI355X engine -- the reference's bin/gunzip.zig:25-27
+(`gzip.decompress(br.reader(), output_file.writer())`; refuses names without the .gz suffix, :15-19).
+Concatenated members are decoded one after the other (Inflate.reset, inflate.zig:301-309)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 1:
+        print("usage: gunzip.py <file>.gz", file=sys.stderr)
+        return 2
+    name = argv[0]
+    if not name.endswith(".gz"):
+        print("not a .gz file", file=sys.stderr)
+        return 1
+    from flate_amd import gzip
+    with open(name, "rb") as src, open(name[:-3], "wb") as dst:
+        d = gzip.decompressor(src)
+        d.decompress(dst)
+        while d.more_input():  # further members of the same file
+            d.reset()
+            d.decompress(dst)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
