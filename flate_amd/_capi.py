@@ -23,6 +23,7 @@ SYMBOLS = [
     "flate_hip_profile_enable", "flate_hip_profile_read", "flate_hip_profile_reset",
     "flate_hip_debug_tokens", "flate_hip_gather_streams", "flate_hip_debug_phase_cycles",
     "flate_hip_compress_flush", "flate_hip_debug_write_block",
+    "flate_hip_compress_batch_sharded", "flate_hip_decompress_batch_sharded",
 ]
 
 
@@ -73,6 +74,12 @@ def lib():
     L.flate_hip_compress_flush.restype = C.c_int
     L.flate_hip_debug_write_block.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_uint64, vp]
     L.flate_hip_debug_write_block.restype = C.c_int
+    L.flate_hip_compress_batch_sharded.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp,
+                                                   u64p, u64p, i32p, vp, C.c_uint64, u64p, u64p]
+    L.flate_hip_compress_batch_sharded.restype = C.c_int
+    L.flate_hip_decompress_batch_sharded.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp,
+                                                     C.c_uint64, u64p, u64p, i32p, u64p]
+    L.flate_hip_decompress_batch_sharded.restype = C.c_int
     L.flate_hip_debug_tokens.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.flate_hip_debug_tokens.restype = C.c_int64
     _lib = L

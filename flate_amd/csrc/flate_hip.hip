@@ -4,6 +4,8 @@
 // usable gfx950 device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -957,6 +959,108 @@ int flate_hip_debug_write_block(flate_hip_handle h, const uint32_t* tokens, uint
     if (status != 0) return FLATE_HIP_E_INVALID_ARG;  // out_cap too small
     if (*out_len) HIP_OK(h, hipMemcpy(out, h->st_out.p, *out_len, hipMemcpyDeviceToHost));
     return FLATE_HIP_OK;
+}
+
+// ---- multi-GPU: the local shard through the single-GPU path, then the reassembly over RCCL ----
+// RCCL is not linked: the entry points bind to the RCCL the process already uses (the communicator
+// the caller hands over was made by it), or load librccl.so when none is loaded yet.
+namespace {
+struct RcclApi {
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* lib = RTLD_DEFAULT;
+        if (!dlsym(lib, "ncclAllGather")) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+            a.Send = (decltype(a.Send))dlsym(lib, "ncclSend");
+            a.Recv = (decltype(a.Recv))dlsym(lib, "ncclRecv");
+            a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
+            a.ok = a.AllGather && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
+        }
+        return a;
+    }();
+    return api;
+}
+enum { kNcclUint8 = 1, kNcclUint64 = 5 };  // ncclDataType_t (rccl.h)
+
+// every rank's slice of `gathered` to every peer: one grouped batch of sends and receives, so that
+// each of a GPU's xGMI links carries one peer's shard (no ring)
+int exchange_slices(flate_hip_ctx* h, void* comm, int rank, int world, uint8_t* gathered, uint64_t slice_bytes,
+                    uint64_t send_bytes) {
+    const RcclApi& r = rccl();
+    if (world == 1) return FLATE_HIP_OK;
+    if (r.GroupStart() != 0) return FLATE_HIP_E_LAUNCH;
+    for (int d = 1; d < world; d++) {
+        const int to = (rank + d) % world, from = (rank - d + world) % world;
+        if (r.Send(gathered + (uint64_t)rank * slice_bytes, send_bytes, kNcclUint8, to, comm, h->stream) != 0 ||
+            r.Recv(gathered + (uint64_t)from * slice_bytes, send_bytes, kNcclUint8, from, comm, h->stream) != 0) {
+            (void)r.GroupEnd();
+            h->last_error = "ncclSend / ncclRecv failed";
+            return FLATE_HIP_E_LAUNCH;
+        }
+    }
+    if (r.GroupEnd() != 0) {
+        h->last_error = "ncclGroupEnd failed";
+        return FLATE_HIP_E_LAUNCH;
+    }
+    return FLATE_HIP_OK;
+}
+}  // namespace
+
+int flate_hip_compress_batch_sharded(flate_hip_handle h, void* nccl_comm, int rank, int world, const uint8_t* in,
+                                     const uint64_t* in_off, uint32_t n_chunks, int container, int mode, uint8_t* out,
+                                     const uint64_t* out_off, uint64_t* out_len, int32_t* status, uint8_t* gathered,
+                                     uint64_t slice_bytes, uint64_t* sizes, uint64_t* dst_off) {
+    if (!h || !nccl_comm || world <= 0 || rank < 0 || rank >= world || !gathered || !sizes || !dst_off)
+        return FLATE_HIP_E_INVALID_ARG;
+    if (!rccl().ok) {
+        h->last_error = "RCCL (librccl.so) not available";
+        return FLATE_HIP_E_UNSUPPORTED;
+    }
+    const bool was_sync = h->sync;
+    h->sync = false;  // everything below is ordered on the handle's stream
+    int rc = compress_impl(h, in, in_off, n_chunks, container, mode, out, out_off, out_len, status,
+                           FLATE_HIP_MEM_DEVICE, nullptr);
+    // this rank's streams back to back at the head of its slice; dst_off[n_chunks] = packed size
+    if (!rc) rc = flate_hip_gather_streams(h, out, out_off, out_len, n_chunks, gathered + (uint64_t)rank * slice_bytes, dst_off);
+    if (!rc && rccl().AllGather(dst_off + n_chunks, sizes, 1, kNcclUint64, nccl_comm, h->stream) != 0) {
+        h->last_error = "ncclAllGather failed";
+        rc = FLATE_HIP_E_LAUNCH;
+    }
+    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, slice_bytes);
+    h->sync = was_sync;
+    if (!rc && h->sync) HIP_OK(h, hipStreamSynchronize(h->stream));
+    return rc;
+}
+
+int flate_hip_decompress_batch_sharded(flate_hip_handle h, void* nccl_comm, int rank, int world, const uint8_t* in,
+                                       const uint64_t* in_off, uint32_t n_chunks, int container, int flags,
+                                       uint8_t* gathered, uint64_t slice_bytes, const uint64_t* out_off,
+                                       uint64_t* out_len, int32_t* status, uint64_t* consumed) {
+    if (!h || !nccl_comm || world <= 0 || rank < 0 || rank >= world || !gathered) return FLATE_HIP_E_INVALID_ARG;
+    if (!rccl().ok) {
+        h->last_error = "RCCL (librccl.so) not available";
+        return FLATE_HIP_E_UNSUPPORTED;
+    }
+    const bool was_sync = h->sync;
+    h->sync = false;
+    // the outputs of this rank's streams go straight into its slice (out_off is relative to the slice)
+    int rc = flate_hip_decompress_batch(h, in, in_off, n_chunks, container, flags, gathered + (uint64_t)rank * slice_bytes,
+                                        out_off, out_len, status, consumed, FLATE_HIP_MEM_DEVICE);
+    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, slice_bytes);
+    h->sync = was_sync;
+    if (!rc && h->sync) HIP_OK(h, hipStreamSynchronize(h->stream));
+    return rc;
 }
 
 }  // extern "C"

@@ -163,6 +163,38 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
 int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint64_t* out_off,
                              const uint64_t* out_len, uint32_t n_chunks, uint8_t* dst, uint64_t* dst_off);
 
+/*
+ * Multi-GPU (one process per GPU): the caller shards the job's chunks over the ranks
+ * (contiguous ranges balanced by bytes; inflate: by ISIZE); each rank hands ITS chunks to these entry
+ * points together with an RCCL communicator (ncclComm_t as void*, made by the RCCL of the process --
+ * torch.distributed's or the caller's own; the library binds to it at run time, it does not link
+ * RCCL).  No collective touches the data path; the exchange is the reassembly of the output:
+ *
+ * compress: the local chunks are compressed exactly as flate_hip_compress_batch(MEM_DEVICE) does, the
+ *   produced streams are packed back to back at gathered + rank * slice_bytes (dst_off: n_chunks + 1
+ *   offsets inside the slice, device memory), the packed sizes are all-gathered into sizes[world]
+ *   (device memory), and every slice goes to every peer in ONE grouped batch of ncclSend / ncclRecv
+ *   (xGMI is point to point: each link carries one peer's shard, no ring).  slice_bytes must bound
+ *   every rank's packed shard (e.g. the sum of its compress bounds) and be the same on all ranks.
+ *   Afterwards gathered[r * slice_bytes .. + sizes[r]) is rank r's output on every rank -- what the
+ *   reference's writer would hold after compressing the ranks' chunks one after the other.
+ * decompress: the local streams are inflated straight into this rank's slice (out_off relative to
+ *   the slice), then the slices are exchanged the same way.
+ * All device memory; work is enqueued on the handle's stream (set_sync decides about the final wait).
+ * The reference has no counterpart: it is single-threaded; these replace the loop a
+ * caller would write around compress() / decompress() per file.
+ */
+int flate_hip_compress_batch_sharded(flate_hip_handle h, void* nccl_comm, int rank, int world,
+                                     const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
+                                     int container, int mode, uint8_t* out, const uint64_t* out_off,
+                                     uint64_t* out_len, int32_t* status, uint8_t* gathered,
+                                     uint64_t slice_bytes, uint64_t* sizes, uint64_t* dst_off);
+int flate_hip_decompress_batch_sharded(flate_hip_handle h, void* nccl_comm, int rank, int world,
+                                       const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks,
+                                       int container, int flags, uint8_t* gathered, uint64_t slice_bytes,
+                                       const uint64_t* out_off, uint64_t* out_len, int32_t* status,
+                                       uint64_t* consumed);
+
 const char* flate_hip_status_name(int status);
 const char* flate_hip_last_error(flate_hip_handle h);
 const char* flate_hip_version(void);

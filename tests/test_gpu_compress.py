@@ -300,3 +300,62 @@ def test_device_planner_matches_oracle_on_random_token_blocks():
             for fn in ("wb", "dyn"):
                 for inp in (data, None):
                     assert eng.debug_write_block(toks, inp, eof, fn == "dyn") == O.block_write(fn, toks, eof, inp)
+
+
+def test_sharded_entry_points_with_a_one_rank_rccl_communicator():
+    """flate_hip_{compress,decompress}_batch_sharded with a real RCCL communicator of one rank (what a
+    single-GPU box can run): local compress + pack + size all-gather; the slice holds the oracle's
+    streams back to back.  The multi-rank exchange itself is exercised by the gloo protocol tests."""
+    import ctypes as C
+    import torch
+    eng = engine()
+    import torch.distributed  # loads the RCCL that torch ships
+    from flate_amd import _capi, synth
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        data = synth.text(synth.SEED_TEXT + 3, 5 * 65535 + 99).tobytes()
+        chunks = [data[i:i + 65535] for i in range(0, len(data), 65535)]
+        n = len(chunks)
+        dev = torch.device("cuda", 0)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        in_off = torch.tensor(np.r_[0, np.cumsum([len(c) for c in chunks])], dtype=torch.int64, device=dev)
+        caps = [(eng.compress_bound(len(c), O.GZIP, 6) + 7) & ~7 for c in chunks]
+        out_off = torch.tensor(np.r_[0, np.cumsum(caps)], dtype=torch.int64, device=dev)
+        out = torch.zeros(sum(caps) + 8, dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        status = torch.zeros(n, dtype=torch.int32, device=dev)
+        slice_bytes = (sum(caps) + 15) & ~15
+        gathered = torch.zeros(slice_bytes, dtype=torch.uint8, device=dev)
+        sizes = torch.zeros(1, dtype=torch.int64, device=dev)
+        dst_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        L = _capi.lib()
+        rc = L.flate_hip_compress_batch_sharded(eng._h, comm, 0, 1, d_in.data_ptr(), in_off.data_ptr(), n, O.GZIP, 6,
+                                                out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), status.data_ptr(),
+                                                gathered.data_ptr(), slice_bytes, sizes.data_ptr(), dst_off.data_ptr())
+        assert rc == 0, eng._L.flate_hip_last_error(eng._h)
+        torch.cuda.synchronize()
+        want = b"".join(O.compress(c, O.GZIP, 6) for c in chunks)
+        assert int(sizes[0]) == len(want) and int(status.abs().sum()) == 0
+        assert gathered[:len(want)].cpu().numpy().tobytes() == want
+        # and back: the packed members inflate into the slice
+        back = torch.zeros(len(data) + 16, dtype=torch.uint8, device=dev)
+        dlen = torch.zeros(n, dtype=torch.int64, device=dev)
+        rc = L.flate_hip_decompress_batch_sharded(eng._h, comm, 0, 1, gathered.data_ptr(), dst_off.data_ptr(), n, O.GZIP, 0,
+                                                  back.data_ptr(), len(data) + 16, in_off.data_ptr(), dlen.data_ptr(),
+                                                  status.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(status.abs().sum()) == 0 and back[:len(data)].cpu().numpy().tobytes() == data
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
