@@ -141,8 +141,19 @@ class CompressJob:
         self.out = torch.empty(int(self.out_off_np[-1]) + 8, dtype=torch.uint8, device=device)
         self.out_len = torch.zeros(self.n_chunks, dtype=torch.int64, device=device)
         self.status = torch.zeros(self.n_chunks, dtype=torch.int32, device=device)
+        # the layout repeats every step: plan it once, then a step only enqueues kernels
+        # (inputs beyond 65535 bytes at levels 4..9 take the whole-stream path, which is not plannable)
+        self.plan = None
+        try:
+            self.plan = eng.plan_compress(self.off_np, self.out_off_np, container, mode)
+        except Exception:
+            self.plan = None
 
     def step(self):
+        if self.plan is not None:
+            self.eng.compress_planned(self.plan, self.data.data_ptr(), self.out.data_ptr(), self.out_len.data_ptr(),
+                                      self.status.data_ptr())
+            return
         self.eng.compress_device(self.data.data_ptr(), self.in_off.data_ptr(), self.n_chunks, self.container, self.mode,
                                  self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(),
                                  self.status.data_ptr())

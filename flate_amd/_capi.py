@@ -24,6 +24,7 @@ SYMBOLS = [
     "flate_hip_debug_tokens", "flate_hip_gather_streams", "flate_hip_debug_phase_cycles",
     "flate_hip_compress_flush", "flate_hip_debug_write_block",
     "flate_hip_compress_batch_sharded", "flate_hip_decompress_batch_sharded",
+    "flate_hip_plan_compress", "flate_hip_compress_planned", "flate_hip_plan_destroy",
 ]
 
 
@@ -80,6 +81,11 @@ def lib():
     L.flate_hip_decompress_batch_sharded.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp,
                                                      C.c_uint64, u64p, u64p, i32p, u64p]
     L.flate_hip_decompress_batch_sharded.restype = C.c_int
+    L.flate_hip_plan_compress.argtypes = [vp, u64p, u64p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.flate_hip_plan_compress.restype = C.c_int
+    L.flate_hip_compress_planned.argtypes = [vp, vp, vp, vp, u64p, i32p]
+    L.flate_hip_compress_planned.restype = C.c_int
+    L.flate_hip_plan_destroy.argtypes = [vp, vp]
     L.flate_hip_debug_tokens.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.flate_hip_debug_tokens.restype = C.c_int64
     _lib = L

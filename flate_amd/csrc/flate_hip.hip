@@ -52,6 +52,21 @@ struct DevBuf {
 
 }  // namespace
 
+// Offsets and per-pass tables of a compress batch whose layout does not change from call to call
+// (flate_hip_plan_compress): with them a call only enqueues kernels.
+struct flate_hip_plan {
+    std::vector<uint64_t> hin, hout;
+    uint32_t n_chunks = 0;
+    int container = 0, mode = 0;
+    struct Pass {
+        uint32_t nc = 0, nb = 0;
+        void* chunks = nullptr;     // fl_chunk[nc]
+        void* blk_chunk = nullptr;  // uint32_t[nb]
+    };
+    std::vector<Pass> passes;
+    bool ready = false;
+};
+
 struct flate_hip_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -348,6 +363,116 @@ int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind
     return FLATE_HIP_OK;
 }
 
+
+// workspace of a chunk-path pass of nc chunks (levels 4..9)
+int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc) {
+    int rc;
+    const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
+    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
+    return FLATE_HIP_OK;
+}
+
+// shared back end of every pass: block planner, offset scan, bit packer
+int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t nb, uint32_t c0, const fl_chunk* dch,
+                     const uint32_t* dbc, const fl_sblock* dsb, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_outlen,
+                     int32_t* d_status) {
+    hipStream_t st = h->stream;
+    const int mode = prm.mode;
+    fl_block_plan* dpl = (fl_block_plan*)h->plans.p;
+    uint32_t* dhist = (uint32_t*)h->hist.p;
+    uint32_t* dcks = (uint32_t*)h->cks.p;
+    {
+        ProfScope ps(h, K_PLAN);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, dsb, nb, dpl);
+        else
+            hipLaunchKernelGGL(k_plan, dim3((nb + FL_PLAN_WAVES - 1) / FL_PLAN_WAVES), dim3(64 * FL_PLAN_WAVES), 0, st,
+                               dch, dbc, dsb, prm, (const uint32_t*)dhist, dpl);
+    }
+    {
+        ProfScope ps(h, K_OFFSETS);
+        hipLaunchKernelGGL(k_offsets, dim3(nc), dim3(64), 0, st, dch, prm, h->crc, dpl, (const uint32_t*)dcks,
+                           d_out, d_outlen + c0, d_status + c0);
+    }
+    {
+        ProfScope ps(h, K_ENCODE);
+        if (mode >= 4)
+            hipLaunchKernelGGL(k_encode<true>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
+                               (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out);
+        else
+            hipLaunchKernelGGL(k_encode<false>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
+                               (const fl_block_plan*)dpl, (const uint32_t*)nullptr, (uint32_t*)d_out);
+    }
+    HIP_OK(h, hipGetLastError());
+    return FLATE_HIP_OK;
+}
+
+// one pass of the chunk path (levels 4..9, inputs <= 65535 bytes) or of a simple mode: checksums,
+// tokenizer / histograms, back end.  Only enqueues.
+int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t nb, uint32_t c0, const fl_chunk* dch,
+                 const uint32_t* dbc, const fl_sblock* dsb, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_outlen,
+                 int32_t* d_status) {
+    hipStream_t st = h->stream;
+    const int mode = prm.mode, container = prm.container;
+    int rc;
+    fl_block_plan* dpl = (fl_block_plan*)h->plans.p;
+    uint32_t* dhist = (uint32_t*)h->hist.p;
+    uint32_t* dcks = (uint32_t*)h->cks.p;
+    if (container != 0) {
+        ProfScope ps(h, K_CHECKSUM);
+        hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, dcks);
+    }
+    if (mode >= 4) {
+        if ((rc = ensure_lz_workspace(h, nc))) return rc;
+        {
+            ProfScope ps(h, K_LZ_SORT);
+            hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
+                               (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                               (uint16_t*)h->S.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_MATCH);
+            if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
+                hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+            else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
+                hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+            else
+                launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
+                                     (uint32_t*)h->rec.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_PARSE);
+            hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, dch, prm,
+                               (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_EMIT);
+            hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, prm,
+                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p,
+                               dhist, dpl, (uint32_t*)h->ntok.p);
+        }
+        h->dbg_pass_chunks = nc;
+        h->dbg_first_chunk = c0;
+        h->dbg_pos_off.resize(nc);
+        h->dbg_pieces.clear();
+        for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = (uint64_t)i * FL_CHUNK_STRIDE;
+    } else if (mode == 1) {
+        ProfScope ps(h, K_BYTE_HIST);
+        hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dsb, dhist);
+    }
+    return enqueue_back_end(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status);
+}
+
 }  // namespace
 
 extern "C" {
@@ -474,8 +599,12 @@ int flate_hip_profile_read(flate_hip_handle h, const char** names, double* total
 namespace {
 int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off, uint32_t n_chunks, int container,
                   int mode, uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int memkind,
-                  const FlushSpec* fs) {
-    if (!h || !in_off || !out_off || !out_len || !status) return FLATE_HIP_E_INVALID_ARG;
+                  const FlushSpec* fs, flate_hip_plan* pl = nullptr) {
+    // pl: the batch's layout is known (plan): no offsets are fetched; while the plan is being built
+    // (!pl->ready) the per-pass tables are made and kept and nothing is launched, afterwards they are
+    // used as they are and the call only enqueues work
+    const bool planning = pl && !pl->ready;
+    if (!h || (!pl && (!in_off || !out_off)) || (!planning && (!out_len || !status))) return FLATE_HIP_E_INVALID_ARG;
     if (container < 0 || container > 2) return FLATE_HIP_E_INVALID_ARG;
     fl_params prm{};
     if (!level_args(mode, prm)) return FLATE_HIP_E_INVALID_ARG;
@@ -487,11 +616,16 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     prm.dbg = getenv("FLATE_HIP_DBG") ? (uint32_t)atoi(getenv("FLATE_HIP_DBG")) : 0u;
     hipStream_t st = h->stream;
 
-    std::vector<uint64_t> hin, hout;
-    int rc = fetch_offsets(h, in_off, n_chunks, memkind, hin);
-    if (rc) return rc;
-    rc = fetch_offsets(h, out_off, n_chunks, memkind, hout);
-    if (rc) return rc;
+    std::vector<uint64_t> hin_, hout_;
+    int rc = 0;
+    if (!pl) {
+        rc = fetch_offsets(h, in_off, n_chunks, memkind, hin_);
+        if (rc) return rc;
+        rc = fetch_offsets(h, out_off, n_chunks, memkind, hout_);
+        if (rc) return rc;
+    }
+    const std::vector<uint64_t>& hin = pl ? pl->hin : hin_;
+    const std::vector<uint64_t>& hout = pl ? pl->hout : hout_;
     const uint64_t in_lo = hin[0], in_hi = hin[n_chunks];
     const uint64_t out_lo = hout[0], out_hi = hout[n_chunks];
 
@@ -520,8 +654,6 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
 
     // chunk table + initial status
     std::vector<fl_chunk> chunks(n_chunks);
-    std::vector<uint64_t> init_len(n_chunks, 0);
-    std::vector<int32_t> init_status(n_chunks, 0);
     for (uint32_t i = 0; i < n_chunks; i++) {
         fl_chunk& c = chunks[i];
         const uint64_t len = hin[i + 1] - hin[i];
@@ -537,11 +669,13 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         c.unfinished = (fs && !fs->finish) ? 1u : 0u;
         c.pad_ = 0;
     }
-    HIP_OK(h, hipMemcpyAsync(d_outlen, init_len.data(), sizeof(uint64_t) * n_chunks, hipMemcpyHostToDevice, st));
-    HIP_OK(h, hipMemcpyAsync(d_status, init_status.data(), sizeof(int32_t) * n_chunks, hipMemcpyHostToDevice, st));
+    if (!planning) {
+        HIP_OK(h, hipMemsetAsync(d_outlen, 0, sizeof(uint64_t) * n_chunks, st));
+        HIP_OK(h, hipMemsetAsync(d_status, 0, sizeof(int32_t) * n_chunks, st));
+    }
 
     // the bit packer ORs into the output: clear the slots first
-    if (out_hi > out_lo) {
+    if (out_hi > out_lo && !planning) {
         ProfScope ps(h, K_MEMSET);
         HIP_OK(h, hipMemsetAsync(d_out + (out_lo - out_shift), 0, out_hi - out_lo, st));
     }
@@ -551,6 +685,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     const size_t pass_limit = pass_chunk_limit();
     const uint64_t stream_pass_bytes = stream_pass_byte_limit();
     uint32_t nc = 0;
+    size_t pass_count = 0;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
         const bool stream = mode >= 4 && (fs || chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK);
         uint64_t pass_bytes = 0;
@@ -559,6 +694,23 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             if ((mode >= 4 && (fs || c.in_len > FLATE_HIP_MAX_LZ_CHUNK)) != stream) break;
             if (stream ? (nc > 0 && pass_bytes + c.in_len > stream_pass_bytes) : nc >= pass_limit) break;
             pass_bytes += c.in_len;
+        }
+        if (pl && stream) return FLATE_HIP_E_UNSUPPORTED;  // (whole-stream passes build more tables per call)
+        const size_t pass_index = pass_count++;
+        if (pl && pl->ready) {
+            // planned batch: the tables of this pass are on the device already
+            const flate_hip_plan::Pass& pp = pl->passes[pass_index];
+            const uint32_t nb = pp.nb;
+            prm.n_chunks = nc;
+            prm.n_blocks = nb;
+            prm.stream = 0;
+            if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)nb))) return rc;
+            if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320 * (size_t)nb))) return rc;
+            if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
+            if ((rc = enqueue_pass(h, prm, nc, nb, c0, (const fl_chunk*)pp.chunks, (const uint32_t*)pp.blk_chunk, nullptr,
+                                   d_in, d_out, d_outlen, d_status)))
+                return rc;
+            continue;
         }
         // block table of this pass
         std::vector<uint32_t> blk_chunk;
@@ -612,94 +764,38 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         // the host vectors must outlive the async copies
         HIP_OK(h, hipStreamSynchronize(st));
+        if (planning) {
+            // keep this pass's tables in the plan; size the workspace now so that planned calls never allocate
+            flate_hip_plan::Pass pp;
+            pp.nc = nc;
+            pp.nb = nb;
+            if (hipMalloc(&pp.chunks, sizeof(fl_chunk) * nc) != hipSuccess ||
+                hipMalloc(&pp.blk_chunk, sizeof(uint32_t) * std::max(nb, 1u)) != hipSuccess)
+                return FLATE_HIP_E_ALLOC;
+            HIP_OK(h, hipMemcpy(pp.chunks, h->chunks.p, sizeof(fl_chunk) * nc, hipMemcpyDeviceToDevice));
+            HIP_OK(h, hipMemcpy(pp.blk_chunk, h->blk_chunk.p, sizeof(uint32_t) * nb, hipMemcpyDeviceToDevice));
+            pl->passes.push_back(pp);
+            if (mode >= 4 && (rc = ensure_lz_workspace(h, nc))) return rc;
+            continue;
+        }
 
         const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
         const uint32_t* dbc = (const uint32_t*)h->blk_chunk.p;
-        fl_block_plan* dpl = (fl_block_plan*)h->plans.p;
-        uint32_t* dhist = (uint32_t*)h->hist.p;
-        uint32_t* dcks = (uint32_t*)h->cks.p;
-
-        if (container != 0) {
-            ProfScope ps(h, K_CHECKSUM);
-            hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, dcks);
-        }
         if (stream) {
+            if (container != 0) {
+                ProfScope ps(h, K_CHECKSUM);
+                hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc,
+                                   (uint32_t*)h->cks.p);
+            }
             if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, tabs))) return rc;
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;
             h->dbg_pos_off.clear();
             h->dbg_chunks.assign(chunks.begin() + c0, chunks.begin() + c0 + nc);
             h->dbg_pieces = tabs.pieces;
-        } else if (mode >= 4) {
-            const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
-            if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
-            if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
-            if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
-            {
-                ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint16_t*)h->S.p);
-            }
-            {
-                ProfScope ps(h, K_LZ_MATCH);
-                if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
-                    hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
-                else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
-                    hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
-                else
-                    launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
-                                         (uint32_t*)h->rec.p);
-            }
-            {
-                ProfScope ps(h, K_LZ_PARSE);
-                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, dch, prm,
-                                   (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
-            }
-            {
-                ProfScope ps(h, K_LZ_EMIT);
-                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p,
-                                   dhist, dpl, (uint32_t*)h->ntok.p);
-            }
-            h->dbg_pass_chunks = nc;
-            h->dbg_first_chunk = c0;
-            h->dbg_pos_off.resize(nc);
-            h->dbg_pieces.clear();
-            for (uint32_t i = 0; i < nc; i++) h->dbg_pos_off[i] = (uint64_t)i * FL_CHUNK_STRIDE;
-        } else if (mode == 1) {
-            ProfScope ps(h, K_BYTE_HIST);
-            hipLaunchKernelGGL(k_byte_hist, dim3(nb), dim3(256), 0, st, d_in, dch, dbc, dsb, dhist);
-        }
-        {
-            ProfScope ps(h, K_PLAN);
-            if (mode == 0)
-                hipLaunchKernelGGL(k_plan_store, dim3((nb + 255) / 256), dim3(256), 0, st, dch, dbc, dsb, nb, dpl);
-            else
-                hipLaunchKernelGGL(k_plan, dim3((nb + FL_PLAN_WAVES - 1) / FL_PLAN_WAVES), dim3(64 * FL_PLAN_WAVES), 0, st,
-                                   dch, dbc, dsb, prm, (const uint32_t*)dhist, dpl);
-        }
-        {
-            ProfScope ps(h, K_OFFSETS);
-            hipLaunchKernelGGL(k_offsets, dim3(nc), dim3(64), 0, st, dch, prm, h->crc, dpl, (const uint32_t*)dcks,
-                               d_out, d_outlen + c0, d_status + c0);
-        }
-        {
-            ProfScope ps(h, K_ENCODE);
-            if (mode >= 4)
-                hipLaunchKernelGGL(k_encode<true>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
-                                   (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out);
-            else
-                hipLaunchKernelGGL(k_encode<false>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
-                                   (const fl_block_plan*)dpl, (const uint32_t*)nullptr, (uint32_t*)d_out);
+            if ((rc = enqueue_back_end(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
+        } else {
+            if ((rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
         }
         HIP_OK(h, hipGetLastError());
     }
@@ -1061,6 +1157,51 @@ int flate_hip_decompress_batch_sharded(flate_hip_handle h, void* nccl_comm, int 
     h->sync = was_sync;
     if (!rc && h->sync) HIP_OK(h, hipStreamSynchronize(h->stream));
     return rc;
+}
+
+int flate_hip_plan_compress(flate_hip_handle h, const uint64_t* in_off, const uint64_t* out_off, uint32_t n_chunks,
+                            int container, int mode, flate_hip_plan_t* plan) {
+    if (!h || !in_off || !out_off || !plan || n_chunks == 0) return FLATE_HIP_E_INVALID_ARG;
+    *plan = nullptr;
+    flate_hip_plan* pl = new flate_hip_plan();
+    pl->hin.assign(in_off, in_off + n_chunks + 1);
+    pl->hout.assign(out_off, out_off + n_chunks + 1);
+    pl->n_chunks = n_chunks;
+    pl->container = container;
+    pl->mode = mode;
+    for (uint32_t i = 0; i < n_chunks; i++)
+        if (pl->hin[i + 1] < pl->hin[i] || pl->hout[i + 1] < pl->hout[i]) {
+            delete pl;
+            return FLATE_HIP_E_INVALID_ARG;
+        }
+    const int rc = compress_impl(h, nullptr, nullptr, n_chunks, container, mode, nullptr, nullptr, nullptr, nullptr,
+                                 FLATE_HIP_MEM_DEVICE, nullptr, pl);
+    if (rc) {
+        (void)flate_hip_plan_destroy(h, pl);
+        return rc;
+    }
+    pl->ready = true;
+    *plan = pl;
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_compress_planned(flate_hip_handle h, flate_hip_plan_t plan, const uint8_t* in, uint8_t* out,
+                               uint64_t* out_len, int32_t* status) {
+    if (!h || !plan || !plan->ready || !in || !out) return FLATE_HIP_E_INVALID_ARG;
+    return compress_impl(h, in, nullptr, plan->n_chunks, plan->container, plan->mode, out, nullptr, out_len, status,
+                         FLATE_HIP_MEM_DEVICE, nullptr, plan);
+}
+
+int flate_hip_plan_destroy(flate_hip_handle h, flate_hip_plan_t plan) {
+    if (!h || !plan) return FLATE_HIP_E_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& pp : plan->passes) {
+        if (pp.chunks) (void)hipFree(pp.chunks);
+        if (pp.blk_chunk) (void)hipFree(pp.blk_chunk);
+    }
+    delete plan;
+    return FLATE_HIP_OK;
 }
 
 }  // extern "C"

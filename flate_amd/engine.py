@@ -123,6 +123,25 @@ class Engine:
                                               out_off_ptr, out_len_ptr, status_ptr, MEM_DEVICE)
         self._check(rc, "flate_hip_compress_batch")
 
+    def plan_compress(self, in_off, out_off, container, mode):
+        """Plan a device batch whose layout repeats (host offset arrays, n + 1 entries each); returns a
+        handle for compress_planned / plan_destroy."""
+        a = np.ascontiguousarray(in_off, dtype=np.uint64)
+        b = np.ascontiguousarray(out_off, dtype=np.uint64)
+        plan = C.c_void_p()
+        rc = self._L.flate_hip_plan_compress(self._h, a.ctypes.data, b.ctypes.data, a.size - 1, container, mode,
+                                             C.byref(plan))
+        self._check(rc, "flate_hip_plan_compress")
+        return plan
+
+    def compress_planned(self, plan, in_ptr, out_ptr, out_len_ptr, status_ptr):
+        """Enqueue one planned batch: kernels only, nothing touches the host."""
+        rc = self._L.flate_hip_compress_planned(self._h, plan, in_ptr, out_ptr, out_len_ptr, status_ptr)
+        self._check(rc, "flate_hip_compress_planned")
+
+    def plan_destroy(self, plan):
+        self._L.flate_hip_plan_destroy(self._h, plan)
+
     def decompress_device(self, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr, out_off_ptr, out_len_ptr,
                           status_ptr, consumed_ptr=None):
         rc = self._L.flate_hip_decompress_batch(self._h, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr,

@@ -41,6 +41,7 @@ extern "C" {
 #endif
 
 typedef struct flate_hip_ctx* flate_hip_handle;
+typedef struct flate_hip_plan* flate_hip_plan_t;
 
 /* container tag -- container.zig:18-21 */
 enum { FLATE_HIP_RAW = 0, FLATE_HIP_GZIP = 1, FLATE_HIP_ZLIB = 2 };
@@ -125,6 +126,22 @@ int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64
                              uint32_t n_chunks, int container, int mode, uint8_t* out,
                              const uint64_t* out_off, uint64_t* out_len, int32_t* status,
                              int memkind);
+
+/*
+ * Asynchronous device batches.  flate_hip_compress_batch(MEM_DEVICE) has to read the offset arrays
+ * back and build its chunk / block tables on the host before it can launch (two short blocking
+ * copies per call).  A caller whose batch layout repeats -- the same chunk sizes and output slots call
+ * after call, as in a pipeline that compresses batch k + 1 while batch k's output is on the wire --
+ * plans it once from HOST copies of the offsets; flate_hip_compress_planned then only enqueues kernels on
+ * the handle's stream (no allocation, no copy from or to the host, no wait; with set_sync(0) it returns
+ * at once).  Inputs of more than 65535 bytes at levels 4..9 (the whole-stream path) are not plannable:
+ * FLATE_HIP_E_UNSUPPORTED.  Same output bytes as flate_hip_compress_batch.
+ */
+int flate_hip_plan_compress(flate_hip_handle h, const uint64_t* in_off_host, const uint64_t* out_off_host,
+                            uint32_t n_chunks, int container, int mode, flate_hip_plan_t* plan);
+int flate_hip_compress_planned(flate_hip_handle h, flate_hip_plan_t plan, const uint8_t* in, uint8_t* out,
+                               uint64_t* out_len, int32_t* status);
+int flate_hip_plan_destroy(flate_hip_handle h, flate_hip_plan_t plan);
 
 /*
  * One stream with sync-flush points (levels 4..9, huffman-only, store-only): what a Compressor

@@ -359,3 +359,67 @@ def test_sharded_entry_points_with_a_one_rank_rccl_communicator():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_planned_batches_only_enqueue():
+    """flate_hip_plan_compress / flate_hip_compress_planned: four batches enqueued back to back with
+    set_sync(0) return to the host while the GPU is still busy (event not reached, host time a small
+    fraction of the GPU time), and every output equals the synchronous path's."""
+    import time
+    import torch
+    from flate_amd import Engine, synth
+    eng = Engine(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        eng.set_stream(stream.cuda_stream)
+        n_bytes = 64 << 20
+        datas = [synth.text_torch(synth.SEED_TEXT + 11 * k, n_bytes, device=dev) for k in range(4)]
+        off = synth.split_offsets(n_bytes, 65535)
+        n = len(off) - 1
+        caps = np.array([(eng.compress_bound(int(off[i + 1] - off[i]), O.GZIP, 6) + 7) & ~7 for i in range(n)], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        outs = [torch.empty(int(out_off[-1]) + 8, dtype=torch.uint8, device=dev) for _ in range(4)]
+        lens = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(4)]
+        sts = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+        plan = eng.plan_compress(off, out_off, O.GZIP, 6)
+        eng.set_sync(False)
+        eng.compress_planned(plan, datas[0].data_ptr(), outs[0].data_ptr(), lens[0].data_ptr(), sts[0].data_ptr())  # warm
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        t0 = time.perf_counter()
+        for k in range(4):
+            eng.compress_planned(plan, datas[k].data_ptr(), outs[k].data_ptr(), lens[k].data_ptr(), sts[k].data_ptr())
+        host_s = time.perf_counter() - t0
+        e1.record(stream)
+        still_running = not e1.query()
+        torch.cuda.synchronize()
+        gpu_s = e0.elapsed_time(e1) * 1e-3
+        assert still_running, "the host waited for the GPU"
+        assert host_s < 0.25 * gpu_s, (host_s, gpu_s)
+        # same bytes as the synchronous entry point / the oracle
+        in_off_t = torch.from_numpy(off.astype(np.int64)).to(dev)
+        out_off_t = torch.from_numpy(out_off.astype(np.int64)).to(dev)
+        ref_out = torch.empty_like(outs[0])
+        ref_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        ref_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        eng.set_sync(True)
+        for k in range(4):
+            assert int(sts[k].abs().sum()) == 0
+            eng.compress_device(datas[k].data_ptr(), in_off_t.data_ptr(), n, O.GZIP, 6, ref_out.data_ptr(),
+                                out_off_t.data_ptr(), ref_len.data_ptr(), ref_st.data_ptr())
+            assert torch.equal(ref_len, lens[k])
+            for i in (0, n // 2, n - 1):
+                a, l = int(out_off[i]), int(ref_len[i])
+                assert torch.equal(ref_out[a:a + l], outs[k][a:a + l])
+            i = 3 + k
+            src = datas[k][int(off[i]):int(off[i + 1])].cpu().numpy().tobytes()
+            got = outs[k][int(out_off[i]):int(out_off[i]) + int(lens[k][i])].cpu().numpy().tobytes()
+            assert got == O.compress(src, O.GZIP, 6)
+        eng.plan_destroy(plan)
+        # a batch with an input beyond 65535 bytes at level 6 is not plannable
+        with pytest.raises(Exception):
+            eng.plan_compress(np.array([0, 70000], dtype=np.uint64), np.array([0, 80000], dtype=np.uint64), O.RAW, 6)
+    eng.close()
