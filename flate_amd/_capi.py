@@ -25,6 +25,7 @@ SYMBOLS = [
     "flate_hip_compress_flush", "flate_hip_debug_write_block",
     "flate_hip_compress_batch_sharded", "flate_hip_decompress_batch_sharded",
     "flate_hip_plan_compress", "flate_hip_compress_planned", "flate_hip_plan_destroy",
+    "flate_hip_checksum", "flate_hip_checksum_combine",
 ]
 
 
@@ -86,6 +87,10 @@ def lib():
     L.flate_hip_compress_planned.argtypes = [vp, vp, vp, vp, u64p, i32p]
     L.flate_hip_compress_planned.restype = C.c_int
     L.flate_hip_plan_destroy.argtypes = [vp, vp]
+    L.flate_hip_checksum.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+    L.flate_hip_checksum.restype = C.c_int
+    L.flate_hip_checksum_combine.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.flate_hip_checksum_combine.restype = C.c_uint32
     L.flate_hip_debug_tokens.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
     L.flate_hip_debug_tokens.restype = C.c_int64
     _lib = L

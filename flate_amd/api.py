@@ -89,15 +89,34 @@ def _read_all(reader):
     return reader.read()
 
 
+_HEADERS = {_capi.RAW: b"", _capi.GZIP: bytes([0x1F, 0x8B, 0x08, 0, 0, 0, 0, 0, 0, 0x03]), _capi.ZLIB: bytes([0x78, 0x9C])}
+_KEEP = 98304   # history a piece after a flush can depend on: 64 KiB window + one 32 KiB slide step
+_STEP = 32768
+
+
 class _Compressor:
-    """Deflate (deflate.zig:121-373) / SimpleCompressor (:449-529) seen from the caller."""
+    """Deflate (deflate.zig:121-373) / SimpleCompressor (:449-529) seen from the caller.
+
+    One-shot use (write / compress, then finish) is one GPU call over the whole input.  With flush()
+    (deflate.zig:335-337: pending tokens out, then an empty stored block; the LZ history stays) the
+    object works INCREMENTALLY: what the reference emits for the bytes after a flush point F depends
+    only on the stream from a 32 KiB-aligned position B <= F - 96 KiB on (its 64 KiB window has slid
+    past everything older, and the slide schedule is periodic in 32 KiB), so each flush() / finish()
+    runs flate_hip_compress_flush on the retained tail [B, now) only and hands the writer the bytes
+    after the previous flush's marker.  Cost per flush: O(new bytes + 128 KiB), memory: the tail.
+    The container header is written once, the footer's checksum is folded from per-piece checksums
+    (flate_hip_checksum / _combine)."""
 
     def __init__(self, container, mode, writer, engine=None):
         self._container, self._mode, self._wrt = container, int(mode), writer
         self._eng = engine or default_engine()
-        self._buf = bytearray()
-        self._flushes = []   # stream positions at which flush() was called
-        self._emitted = 0    # bytes of the stream already handed to the writer
+        self._buf = bytearray()  # stream bytes from absolute position self._base on
+        self._base = 0
+        self._total = 0          # bytes written so far
+        self._flushes = []       # absolute flush points >= self._base
+        self._nflush = 0         # flush() calls so far
+        self._rel_emitted = None  # bytes the tail [base, last flush) compresses to (cached while base stands)
+        self._cks, self._cks_pos = None, 0
         self._done = False
 
     def _live(self):
@@ -109,26 +128,63 @@ class _Compressor:
     def write(self, data):  # deflate.zig:363-367
         self._live()
         self._buf += data
+        self._total += len(data)
         return len(data)
 
     def compress(self, reader):  # deflate.zig:304-321
         self._live()
-        self._buf += _read_all(reader)
+        data = _read_all(reader)
+        self._buf += data
+        self._total += len(data)
 
     def writer(self):  # deflate.zig:369-371
         return self
 
-    def _run(self, finish):
-        out, st = self._eng.compress_flush(bytes(self._buf), self._flushes, finish, self._container, self._mode)
+    def _fold_checksum(self):
+        """checksum of everything written so far (gzip / zlib footer), piece by piece"""
+        if self._container == _capi.RAW:
+            return
+        new = bytes(self._buf[self._cks_pos - self._base:])
+        v = self._eng.checksum(new, self._container)
+        self._cks = v if self._cks is None else self._eng.checksum_combine(self._container, self._cks, v, len(new))
+        self._cks_pos = self._total
+
+    def _run_tail(self, finish):
+        """compress the retained tail with its flush points (raw container); returns the new bytes"""
+        rel = [f - self._base for f in self._flushes]
+        tail = bytes(self._buf)
+        if self._rel_emitted is None:
+            # how much of the tail's output was handed over already: the tail up to the previous flush
+            prev = rel[-2] if not finish else rel[-1]
+            done, st = self._eng.compress_flush(tail[:prev], rel[:-1] if not finish else rel, False, _capi.RAW, self._mode)
+            raise_for_status(st)
+            self._rel_emitted = len(done)
+        out, st = self._eng.compress_flush(tail, rel, finish, _capi.RAW, self._mode)
         raise_for_status(st)
-        # the stream so far is a prefix of the stream after more calls: hand over only what is new
-        self._wrt.write(out[self._emitted:])
-        self._emitted = len(out)
+        new = out[self._rel_emitted:]
+        self._rel_emitted = len(out)
+        return new
+
+    def _drop_history(self):
+        last = self._flushes[-1]
+        nb = ((last - _KEEP) // _STEP) * _STEP
+        if nb > self._base:
+            del self._buf[: nb - self._base]
+            self._flushes = [f for f in self._flushes if f >= nb]
+            self._base = nb
+            self._rel_emitted = None
 
     def flush(self):  # deflate.zig:335-337: pending tokens out, then an empty stored block; history stays
         self._live()
-        self._flushes.append(len(self._buf))
-        self._run(False)
+        self._fold_checksum()
+        first = self._nflush == 0
+        self._flushes.append(self._total)
+        self._nflush += 1
+        if first:
+            self._rel_emitted = 0
+            self._wrt.write(_HEADERS[self._container])
+        self._wrt.write(self._run_tail(False))
+        self._drop_history()
 
     def set_writer(self, new_writer):  # deflate.zig:351-354
         self._wrt = new_writer
@@ -136,8 +192,13 @@ class _Compressor:
     def finish(self):  # deflate.zig:344-347
         if self._done:
             return
-        if self._flushes:
-            self._run(True)
+        if self._nflush:
+            self._fold_checksum()
+            self._wrt.write(self._run_tail(True))
+            if self._container == _capi.GZIP:  # container.zig:92-96
+                self._wrt.write(self._cks.to_bytes(4, "little") + (self._total & 0xFFFFFFFF).to_bytes(4, "little"))
+            elif self._container == _capi.ZLIB:  # container.zig:104
+                self._wrt.write(self._cks.to_bytes(4, "big"))
         else:
             outs, st = self._eng.compress_many([bytes(self._buf)], self._container, self._mode)
             raise_for_status(st[0])

@@ -1204,4 +1204,53 @@ int flate_hip_plan_destroy(flate_hip_handle h, flate_hip_plan_t plan) {
     return FLATE_HIP_OK;
 }
 
+int flate_hip_checksum(flate_hip_handle h, const uint8_t* data, uint64_t n, int container, uint32_t* value) {
+    if (!h || !value || (n && !data) || (container != 1 && container != 2) || n > 0xfffffff0ull) return FLATE_HIP_E_INVALID_ARG;
+    if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
+    hipStream_t st = h->stream;
+    int rc;
+    // one huffman-only style chunk: block j = bytes [65535 j, ...)
+    fl_chunk ck{};
+    ck.in_len = (uint32_t)n;
+    ck.n_blocks = (uint32_t)(n / FL_BLOCK_BYTES + 1);
+    const uint32_t nb = ck.n_blocks;
+    std::vector<uint32_t> blk_chunk(nb, 0u);
+    fl_params prm{};
+    prm.n_chunks = 1;
+    prm.n_blocks = nb;
+    prm.container = container;
+    prm.mode = 1;
+    if ((rc = ensure(h, h->chunks, sizeof(fl_chunk)))) return rc;
+    if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * nb))) return rc;
+    if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb + 16))) return rc;
+    if ((rc = ensure(h, h->st_in, n + 16))) return rc;
+    if ((rc = ensure(h, h->st_status, 16))) return rc;
+    HIP_OK(h, hipMemcpyAsync(h->chunks.p, &ck, sizeof ck, hipMemcpyHostToDevice, st));
+    HIP_OK(h, hipMemcpyAsync(h->blk_chunk.p, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));
+    if (n) HIP_OK(h, hipMemcpyAsync(h->st_in.p, data, n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, (const uint8_t*)h->st_in.p, (const fl_chunk*)h->chunks.p,
+                       (const uint32_t*)h->blk_chunk.p, (const fl_sblock*)nullptr, prm, h->crc, (uint32_t*)h->cks.p);
+    hipLaunchKernelGGL(k_fold_checksum, dim3(1), dim3(64), 0, st, (const uint32_t*)h->cks.p, nb, container, h->crc,
+                       (uint32_t*)h->st_status.p);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipMemcpyAsync(value, h->st_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(h, hipStreamSynchronize(st));
+    return FLATE_HIP_OK;
+}
+
+uint32_t flate_hip_checksum_combine(int container, uint32_t a, uint32_t b, uint64_t len_b) {
+    if (container == 1) {
+        // crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in the reflected representation (as zlib's crc32_combine)
+        fl_crc_consts cc;
+        init_crc_consts(cc);
+        return fl_crc_mulmod(a, fl_crc_xpow8n(cc.xpow8, len_b)) ^ b;
+    }
+    // Adler-32: a = a1 + a2 - 1, b = b1 + b2 + |B| (a1 - 1)   (mod 65521)
+    const uint32_t a1 = a & 0xffff, b1 = a >> 16, a2 = b & 0xffff, b2 = b >> 16;
+    const uint32_t rem = (uint32_t)(len_b % 65521u);
+    const uint32_t an = (a1 + a2 + 65521u - 1u) % 65521u;
+    const uint32_t bn = (uint32_t)(((uint64_t)b1 + b2 + (uint64_t)rem * ((a1 + 65521u - 1u) % 65521u)) % 65521u);
+    return an | (bn << 16);
+}
+
 }  // extern "C"

@@ -267,6 +267,59 @@ __global__ __launch_bounds__(256) void k_plan_store(const fl_chunk* __restrict__
     plan->no_input = 0;
 }
 
+// Fold the checksum parts of n_blocks consecutive blocks (k_checksum: CRC-32 of each block / Adler-32
+// sums with a = b = 0 start, and the block lengths) into the checksum of their concatenation; all 64
+// lanes call it, the result is valid on every lane.  Every lane folds a contiguous run of blocks, then
+// the lanes' results are combined in order with the same associative rule (crc(A||B) = crc(A) x^(8|B|)
+// + crc(B); Adler-32: A = A1 + A2, B = B1 + |B| A1 + B2, the leading 1 added at the end).
+__device__ __forceinline__ uint32_t fl_fold_checksums(const uint32_t* __restrict__ cks_part, uint32_t first_block,
+                                                      uint32_t n_blocks, int container, const fl_crc_consts& cc,
+                                                      uint32_t lane) {
+    const uint32_t per = (n_blocks + 63) / 64;
+    const uint32_t j0 = min(lane * per, n_blocks), j1 = min(j0 + per, n_blocks);
+    uint32_t x = 0, y = 0;  // crc | (A, B) of this lane's run
+    uint64_t len = 0;       // bytes of this lane's run
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t pc = cks_part[2 * (uint64_t)(first_block + j)];
+        const uint32_t pl = cks_part[2 * (uint64_t)(first_block + j) + 1];
+        if (container == 1) {
+            const uint32_t sh = pl == FL_BLOCK_BYTES ? cc.pow65535 : fl_crc_xpow8n(cc.xpow8, pl);
+            x = fl_crc_mulmod(x, sh) ^ pc;
+        } else {
+            y = (uint32_t)(((uint64_t)y + (uint64_t)x * pl + (pc >> 16)) % 65521u);
+            x = (x + (pc & 0xffff)) % 65521u;
+        }
+        len += pl;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        // this lane = (lanes below, already folded) followed by its own run
+        const uint32_t ox = __shfl_up(x, d, 64), oy = __shfl_up(y, d, 64);
+        const uint64_t ol = __shfl_up(len, d, 64);
+        if (lane >= (uint32_t)d) {
+            if (container == 1) {
+                x = fl_crc_mulmod(ox, fl_crc_xpow8n(cc.xpow8, len)) ^ x;
+            } else {
+                y = (uint32_t)(((uint64_t)oy + (uint64_t)ox * (len % 65521u) + y) % 65521u);
+                x = (ox + x) % 65521u;
+            }
+            len += ol;
+        }
+    }
+    // lane 63 holds the fold over all blocks
+    const uint32_t fx = __shfl(x, 63, 64), fy = __shfl(y, 63, 64);
+    const uint64_t n = __shfl(len, 63, 64);
+    if (container == 1) return fx;
+    return ((1u + fx) % 65521u) | ((uint32_t)((n % 65521u + fy) % 65521u) << 16);  // a = 1 + A, b = n + B
+}
+
+// debug / wrapper seam: checksum of one buffer cut into 65535-byte units (flate_hip_checksum)
+__global__ __launch_bounds__(64) void k_fold_checksum(const uint32_t* __restrict__ cks_part, uint32_t n_blocks,
+                                                      int container, fl_crc_consts cc, uint32_t* __restrict__ out) {
+    const uint32_t v = fl_fold_checksums(cks_part, 0, n_blocks, container, cc, threadIdx.x);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
 // ------------------------------------------------------------------ offsets
 // Bit offset of every block inside its chunk's stream.  A Huffman block moves the
 // offset by its exact size; a stored block first pads to a byte boundary
@@ -380,51 +433,8 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
         }
     }
     if (prm.container != 0 && !(prm.mode >= 4 && !prm.stream)) {
-        // fold the per-block parts: every lane folds a contiguous run of blocks, then the lanes'
-        // results are combined in order with the same associative rule (crc(A||B) = crc(A) x^(8|B|) +
-        // crc(B); Adler-32: a = a1 + A2, b = b1 + |B| a1' + B2 with a1' the running a without its 1)
-        const uint32_t per = (ck.n_blocks + 63) / 64;
-        const uint32_t j0 = min(lane * per, ck.n_blocks), j1 = min(j0 + per, ck.n_blocks);
-        uint32_t x = 0, y = 0;   // crc | (A, B) of this lane's run
-        uint64_t len = 0;        // bytes of this lane's run
-        for (uint32_t j = j0; j < j1; j++) {
-            const uint32_t pc = cks_part[2 * (uint64_t)(ck.first_block + j)];
-            const uint32_t pl = cks_part[2 * (uint64_t)(ck.first_block + j) + 1];
-            if (prm.container == 1) {
-                const uint32_t sh = pl == FL_BLOCK_BYTES ? cc.pow65535 : fl_crc_xpow8n(cc.xpow8, pl);
-                x = fl_crc_mulmod(x, sh) ^ pc;
-            } else {
-                y = (uint32_t)(((uint64_t)y + (uint64_t)x * pl + (pc >> 16)) % 65521u);
-                x = (x + (pc & 0xffff)) % 65521u;
-            }
-            len += pl;
-        }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            // this lane = (lanes below, already folded) followed by its own run
-            const uint32_t ox = __shfl_up(x, d, 64), oy = __shfl_up(y, d, 64);
-            const uint64_t ol = __shfl_up(len, d, 64);
-            if (lane >= (uint32_t)d) {
-                if (prm.container == 1) {
-                    x = fl_crc_mulmod(ox, fl_crc_xpow8n(cc.xpow8, len)) ^ x;
-                } else {
-                    y = (uint32_t)(((uint64_t)oy + (uint64_t)ox * (len % 65521u) + y) % 65521u);
-                    x = (ox + x) % 65521u;
-                }
-                len += ol;
-            }
-        }
-        // lane 63 holds the fold over all blocks
-        const uint32_t fx = __shfl(x, 63, 64), fy = __shfl(y, 63, 64);
-        const uint64_t n = __shfl(len, 63, 64);
-        if (lane == 0) {
-            if (prm.container == 1) {
-                cks = fx;
-            } else {
-                // start values a = 1, b = 0: a = 1 + A, b = n + B
-                cks = ((1u + fx) % 65521u) | ((uint32_t)((n % 65521u + fy) % 65521u) << 16);
-            }
-        }
+        const uint32_t v = fl_fold_checksums(cks_part, ck.first_block, ck.n_blocks, prm.container, cc, lane);
+        if (lane == 0) cks = v;
     }
     if (lane == 0) {
         out_len[c] = fits ? total : 0;

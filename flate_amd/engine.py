@@ -88,6 +88,17 @@ class Engine:
         self._check(rc, "flate_hip_compress_flush")
         return out[: int(out_len[0])].tobytes(), int(status[0])
 
+    def checksum(self, data, container):
+        """CRC-32 (container 1) / Adler-32 (container 2) of a host buffer, by the checksum kernels."""
+        blob = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        v = np.zeros(1, dtype=np.uint32)
+        rc = self._L.flate_hip_checksum(self._h, blob.ctypes.data, len(data), container, v.ctypes.data)
+        self._check(rc, "flate_hip_checksum")
+        return int(v[0])
+
+    def checksum_combine(self, container, a, b, len_b):
+        return int(self._L.flate_hip_checksum_combine(container, a, b, len_b))
+
     def decompress_many(self, streams, container=0, flags=0, caps=None):
         """streams: sequence of bytes-like.  caps: output capacity per stream (default: generous guess).
         Returns (list of bytes, list of status codes, list of consumed input bytes)."""

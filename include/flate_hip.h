@@ -212,6 +212,14 @@ int flate_hip_decompress_batch_sharded(flate_hip_handle h, void* nccl_comm, int 
                                        const uint64_t* out_off, uint64_t* out_len, int32_t* status,
                                        uint64_t* consumed);
 
+/* The containers' checksums on their own (container.zig:168-206: std.hash.Crc32 / Adler32 over the raw
+ * input): container 1 = CRC-32, 2 = Adler-32 of a host buffer, computed by the checksum kernels; and the
+ * checksum of a concatenation from the checksums of its parts (value_b over len_b bytes follows value_a).
+ * The streaming compressor wrappers use them to write the footer of a stream they compressed piece by
+ * piece (flate_hip_compress_flush on the tail of the stream only). */
+int flate_hip_checksum(flate_hip_handle h, const uint8_t* data, uint64_t n, int container, uint32_t* value);
+uint32_t flate_hip_checksum_combine(int container, uint32_t value_a, uint32_t value_b, uint64_t len_b);
+
 const char* flate_hip_status_name(int status);
 const char* flate_hip_last_error(flate_hip_handle h);
 const char* flate_hip_version(void);

@@ -172,3 +172,57 @@ def test_simple_compressors_flush(mode):
             assert got == _oracle_stream(data, fl, finish, container, mode)[0], (mode, container, len(data), fl, finish)
             if finish:
                 assert pyzlib.decompress(got, WBITS[container]) == data
+
+
+@pytest.mark.parametrize("container", [O.RAW, O.GZIP, O.ZLIB])
+def test_incremental_compressor_object_matches_streaming_oracle(container):
+    """The Compressor mirror compresses only the retained tail of the stream at every flush (the
+    reference keeps its 64 KiB window, deflate.zig:335-337): same bytes as the oracle's streaming
+    compressor fed the same calls, for a stream many windows long, at levels 4 / 6 / 9 and in the
+    simple modes; the tail it keeps stays bounded."""
+    import io
+    from flate_amd import api, synth
+    rng = np.random.default_rng(99)
+    data = (synth.text(synth.SEED_TEXT + 2, 300000).tobytes() + bytes(70000) +
+            synth.silesia_like(synth.SEED_SILESIA + 2, 400000).tobytes())
+    cuts = sorted(set(int(x) for x in rng.integers(1, len(data), 14)) | {65536, 65535, 98304, 131072, 131073})
+    for mode in (4, 6, 9, O.HUFFMAN, O.STORE):
+        w = io.BytesIO()
+        c = api._Compressor(container, mode, w)
+        d = O.Deflate(container, mode)
+        prev = 0
+        for k, f in enumerate(cuts):
+            c.write(data[prev:f]); d.write(data[prev:f])
+            c.flush(); d.flush()
+            if k % 5 == 0:
+                c.flush(); d.flush()  # twice in a row
+            assert w.getvalue() == d.output(), (mode, k, f)
+            assert len(c._buf) <= api._KEEP + api._STEP + (f - prev) + 1
+            prev = f
+        c.write(data[prev:]); d.write(data[prev:])
+        c.finish(); d.finish()
+        assert w.getvalue() == d.output(), mode
+        with pytest.raises(api.InvalidState):
+            c.write(b"x")
+
+
+def test_flush_cost_does_not_grow_with_the_stream():
+    """flush k of n costs O(new bytes): late flushes of a long stream take about as long as early ones."""
+    import io
+    import time
+    from flate_amd import api, synth
+    data = synth.text(synth.SEED_TEXT + 5, 6 << 20).tobytes()
+    c = api._Compressor(O.GZIP, 6, io.BytesIO())
+    piece = 32768
+    times = []
+    for i in range(0, len(data), piece):
+        c.write(data[i:i + piece])
+        t0 = time.perf_counter()
+        c.flush()
+        times.append(time.perf_counter() - t0)
+    c.finish()
+    early = sorted(times[8:40])[16]
+    late = sorted(times[-32:])[16]
+    assert late < 2.0 * early, (early, late)
+    import zlib as pyzlib
+    assert pyzlib.decompress(c._wrt.getvalue(), 31) == data
