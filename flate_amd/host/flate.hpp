@@ -78,6 +78,13 @@ class Engine {
         out.resize(out_len);
         return out;
     }
+    uint32_t checksum(const uint8_t* p, size_t n, int container) {
+        uint32_t v = 0;
+        static const uint8_t dummy = 0;
+        const int rc = flate_hip_checksum(h_, n ? p : &dummy, n, container, &v);
+        if (rc != FLATE_HIP_OK) throw Error(rc, std::string("flate_hip_checksum: ") + flate_hip_last_error(h_));
+        return v;
+    }
     // the stream a Compressor has written after write/flush/.../[finish] (flate_hip_compress_flush)
     std::vector<uint8_t> compress_flush(const std::vector<uint8_t>& in, const std::vector<uint64_t>& flushes, bool finish,
                                         int container, int mode) {
@@ -135,46 +142,124 @@ inline void read_all(Reader& r, std::vector<uint8_t>& buf) {
     }
 }
 
-// Deflate (deflate.zig:121-373) / SimpleCompressor (:449-529) seen from the caller
+// Deflate (deflate.zig:121-373) / SimpleCompressor (:449-529) seen from the caller.
+// One-shot use is one GPU call.  With flush() (deflate.zig:335-337: pending tokens out, then an empty
+// stored block; the LZ history stays) the object works incrementally: what the reference emits after a
+// flush point F depends only on the stream from a 32 KiB-aligned position B <= F - 96 KiB on (its 64 KiB
+// window has slid past everything older, and the slide schedule is periodic in 32 KiB), so every flush /
+// finish runs flate_hip_compress_flush on the retained tail [B, now) only and hands the writer the bytes
+// after the previous flush's marker: O(new bytes + 128 KiB) per flush.  The container header goes out
+// once, the footer's checksum is folded from per-piece checksums (flate_hip_checksum / _combine).
 template <class Writer>
 class CompressorImpl {
    public:
     CompressorImpl(Writer& w, int container, int mode) : wrt_(&w), container_(container), mode_(mode) {}
     size_t write(const uint8_t* p, size_t n) {  // deflate.zig:363-367
+        live();
         buf_.insert(buf_.end(), p, p + n);
+        total_ += n;
         return n;
     }
     template <class Reader>
     void compress(Reader& r) {  // deflate.zig:304-321
+        live();
+        const size_t before = buf_.size();
         read_all(r, buf_);
+        total_ += buf_.size() - before;
     }
-    // deflate.zig:335-337: pending tokens out, then an empty stored block; the LZ history stays.
-    // The stream so far is re-run with its flush points; what a shorter prefix of the calls has
-    // produced is a prefix of it, so only the new bytes go to the writer.
     void flush() {
-        flushes_.push_back(buf_.size());
-        emit(Engine::instance().compress_flush(buf_, flushes_, false, container_, mode_));
+        live();
+        fold_checksum();
+        const bool first = nflush_ == 0;
+        flushes_.push_back(total_);
+        nflush_++;
+        if (first) {
+            rel_emitted_ = 0;
+            have_rel_ = true;
+            static const uint8_t gz[10] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0x03};  // container.zig:64
+            static const uint8_t zl[2] = {0x78, 0x9c};                                 // container.zig:78
+            if (container_ == 1) wrt_->write(gz, sizeof gz);
+            if (container_ == 2) wrt_->write(zl, sizeof zl);
+        }
+        run_tail(false);
+        // drop the history no later piece can depend on
+        const uint64_t last = flushes_.back();
+        if (last >= 98304) {
+            const uint64_t nb = ((last - 98304) / 32768) * 32768;
+            if (nb > base_) {
+                buf_.erase(buf_.begin(), buf_.begin() + (nb - base_));
+                std::vector<uint64_t> keep;
+                for (uint64_t f : flushes_)
+                    if (f >= nb) keep.push_back(f);
+                flushes_.swap(keep);
+                base_ = nb;
+                have_rel_ = false;
+            }
+        }
     }
     void setWriter(Writer& w) { wrt_ = &w; }  // deflate.zig:351-354
     void finish() {                           // deflate.zig:344-347
         if (done_) return;
-        if (flushes_.empty())
-            emit(Engine::instance().compress_one(buf_, container_, mode_));
-        else
-            emit(Engine::instance().compress_flush(buf_, flushes_, true, container_, mode_));
+        if (nflush_ == 0) {
+            const std::vector<uint8_t> out = Engine::instance().compress_one(buf_, container_, mode_);
+            wrt_->write(out.data(), out.size());
+        } else {
+            fold_checksum();
+            run_tail(true);
+            if (container_ == 1) {  // container.zig:92-96
+                uint8_t f[8];
+                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks_ >> (8 * i));
+                for (int i = 0; i < 4; i++) f[4 + i] = (uint8_t)(total_ >> (8 * i));
+                wrt_->write(f, 8);
+            } else if (container_ == 2) {  // container.zig:104
+                uint8_t f[4];
+                for (int i = 0; i < 4; i++) f[i] = (uint8_t)(cks_ >> (8 * (3 - i)));
+                wrt_->write(f, 4);
+            }
+        }
         done_ = true;
     }
 
    private:
-    void emit(const std::vector<uint8_t>& out) {
-        wrt_->write(out.data() + emitted_, out.size() - emitted_);
-        emitted_ = out.size();
+    void live() const {
+        // (the reference has no such check: writing after finish() emits a broken stream)
+        if (done_) throw Error(FLATE_HIP_E_INVALID_ARG, "compressor used after finish()");
+    }
+    void fold_checksum() {
+        if (container_ == 0) return;
+        const size_t from = (size_t)(cks_pos_ - base_);
+        const uint32_t v = Engine::instance().checksum(buf_.data() + from, buf_.size() - from, container_);
+        cks_ = have_cks_ ? flate_hip_checksum_combine(container_, cks_, v, buf_.size() - from) : v;
+        have_cks_ = true;
+        cks_pos_ = total_;
+    }
+    void run_tail(bool finish) {
+        std::vector<uint64_t> rel;
+        for (uint64_t f : flushes_) rel.push_back(f - base_);
+        Engine& e = Engine::instance();
+        if (!have_rel_) {
+            // how much of the tail's output went out already: the tail up to the previous flush
+            const uint64_t prev = finish ? rel.back() : rel[rel.size() - 2];
+            std::vector<uint64_t> r2(rel.begin(), finish ? rel.end() : rel.end() - 1);
+            const std::vector<uint8_t> head(buf_.begin(), buf_.begin() + prev);
+            rel_emitted_ = e.compress_flush(head, r2, false, 0, mode_).size();
+            have_rel_ = true;
+        }
+        const std::vector<uint8_t> out = e.compress_flush(buf_, rel, finish, 0, mode_);
+        wrt_->write(out.data() + rel_emitted_, out.size() - rel_emitted_);
+        rel_emitted_ = out.size();
     }
     Writer* wrt_;
     int container_, mode_;
-    std::vector<uint8_t> buf_;
-    std::vector<uint64_t> flushes_;
-    size_t emitted_ = 0;
+    std::vector<uint8_t> buf_;      // stream bytes from absolute position base_ on
+    uint64_t base_ = 0, total_ = 0;
+    std::vector<uint64_t> flushes_;  // absolute flush points >= base_
+    size_t nflush_ = 0;
+    size_t rel_emitted_ = 0;
+    bool have_rel_ = false;
+    uint32_t cks_ = 0;
+    bool have_cks_ = false;
+    uint64_t cks_pos_ = 0;
     bool done_ = false;
 };
 

@@ -86,6 +86,34 @@ int main() {
         zlib::decompress(r2, back);
         CHECK(back.data == big);
     }
+    // many flushes over a stream several windows long: the compressor keeps only the tail, and the
+    // stream equals the one-call stream with the same flush points (incremental == whole re-run)
+    {
+        std::vector<uint8_t> big(700000);
+        uint32_t x = 12345;
+        for (size_t i = 0; i < big.size(); i++) {
+            x = x * 1664525u + 1013904223u;
+            big[i] = (uint8_t)("the quick brown fox jumps over the lazy dog "[(i + (x >> 28)) % 44]);
+        }
+        VectorWriter w;
+        auto c = gzip::compressor(w, gzip::Options{Level::level_6});
+        std::vector<uint64_t> fl;
+        size_t pos = 0;
+        for (size_t step : {1000u, 64535u, 1u, 32768u, 200000u, 99999u, 131072u, 70000u}) {
+            c.write(big.data() + pos, step);
+            pos += step;
+            c.flush();
+            fl.push_back(pos);
+        }
+        c.write(big.data() + pos, big.size() - pos);
+        c.finish();
+        const std::vector<uint8_t> whole = Engine::instance().compress_flush(big, fl, true, 1, 6);
+        CHECK(w.data == whole);
+        BufferReader r3(w.data.data(), w.data.size());
+        VectorWriter back;
+        gzip::decompress(r3, back);
+        CHECK(back.data == big);
+    }
     printf("facade ok\n");
     return 0;
 }
