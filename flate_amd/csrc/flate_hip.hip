@@ -78,7 +78,7 @@ struct flate_hip_ctx {
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
-    DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed;
+    DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
     uint32_t dbg_first_chunk = 0;
@@ -348,6 +348,50 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     return FLATE_HIP_OK;
 }
 
+// Host-buffer calls: bring back only what was produced.  The slots are sized for the worst case (an
+// inflate caller may reserve 1000x the input); when the produced bytes are a small part of the slot
+// range they are packed on the device first (k_scan_lens + k_gather_copy), cross PCIe once, and are put
+// into their slots by the host; otherwise the range is copied as it is.  Bytes of a slot beyond
+// out_len[i] are never written in the caller's buffer.
+int copy_out_host(flate_hip_ctx* h, const uint8_t* d_out, const uint64_t* d_outlen, uint32_t n,
+                  const std::vector<uint64_t>& hout, uint64_t out_shift, uint8_t* out, const uint64_t* out_len) {
+    hipStream_t st = h->stream;
+    const uint64_t out_lo = hout[0], out_hi = hout[n];
+    if (out_hi <= out_lo) return FLATE_HIP_OK;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) total += out_len[i];
+    if (total == 0) return FLATE_HIP_OK;
+    if (total * 2 >= out_hi - out_lo) {
+        // dense: the range from the first slot to the end of the last produced byte
+        uint64_t end = out_lo;
+        for (uint32_t i = 0; i < n; i++)
+            if (out_len[i]) end = std::max(end, hout[i] + out_len[i]);
+        HIP_OK(h, hipMemcpyAsync(out + out_lo, d_out + (out_lo - out_shift), end - out_lo, hipMemcpyDeviceToHost, st));
+        HIP_OK(h, hipStreamSynchronize(st));
+        return FLATE_HIP_OK;
+    }
+    int rc;
+    if ((rc = ensure(h, h->st_pack, total + 16))) return rc;
+    if ((rc = ensure(h, h->st_packoff, sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    if ((rc = ensure(h, h->st_slot, sizeof(uint64_t) * ((size_t)n + 1)))) return rc;
+    std::vector<uint64_t> slot(n + 1);
+    for (uint32_t i = 0; i <= n; i++) slot[i] = hout[i] - out_shift;
+    HIP_OK(h, hipMemcpyAsync(h->st_slot.p, slot.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, st, d_outlen, n, (uint64_t*)h->st_packoff.p);
+    hipLaunchKernelGGL(k_gather_copy, dim3(n), dim3(256), 0, st, d_out, (const uint64_t*)h->st_slot.p, d_outlen,
+                       (uint8_t*)h->st_pack.p, (const uint64_t*)h->st_packoff.p);
+    HIP_OK(h, hipGetLastError());
+    std::vector<uint8_t> packed(total);
+    HIP_OK(h, hipMemcpyAsync(packed.data(), h->st_pack.p, total, hipMemcpyDeviceToHost, st));
+    HIP_OK(h, hipStreamSynchronize(st));
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (out_len[i]) memcpy(out + hout[i], packed.data() + at, out_len[i]);
+        at += out_len[i];
+    }
+    return FLATE_HIP_OK;
+}
+
 // Fetch the n+1 offsets to the host (the block tables are built there).
 int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind, std::vector<uint64_t>& host) {
     host.resize((size_t)n + 1);
@@ -530,7 +574,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
-                      &h->st_consumed})
+                      &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->own_stream);
@@ -803,9 +847,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     if (memkind == FLATE_HIP_MEM_HOST) {
         HIP_OK(h, hipMemcpyAsync(out_len, d_outlen, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_chunks, hipMemcpyDeviceToHost, st));
-        if (out_hi > out_lo)
-            HIP_OK(h, hipMemcpyAsync(out + out_lo, d_out, out_hi - out_lo, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipStreamSynchronize(st));
+        if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len))) return rc;
     } else if (h->sync) {
         HIP_OK(h, hipStreamSynchronize(st));
     }
@@ -918,9 +961,8 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         HIP_OK(h, hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_chunks, hipMemcpyDeviceToHost, st));
         if (consumed)
             HIP_OK(h, hipMemcpyAsync(consumed, d_consumed, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
-        if (out_hi > out_lo)
-            HIP_OK(h, hipMemcpyAsync(out + out_lo, d_out, out_hi - out_lo, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipStreamSynchronize(st));
+        if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len))) return rc;
     } else if (h->sync) {
         HIP_OK(h, hipStreamSynchronize(st));
     }
