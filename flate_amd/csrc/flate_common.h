@@ -57,6 +57,9 @@ static __device__ __forceinline__ uint32_t fl_plan_wave_sum(uint32_t v) {
 #define FL_PLAN_REDUCE(v) (v) = fl_plan_wave_sum(v)
 #else
 #define FL_PLAN_PARALLEL 0
+// CPU build: which form of the Huffman bit counts fl_huff_generate runs (tests flip it)
+static int fl_plan_cpu_use_pm = 0;
+#define FL_PLAN_CPU_USE_PM fl_plan_cpu_use_pm
 #define FL_PLAN_FOR(i, a, b) for (uint32_t i = (a); i < (b); i++)
 #define FL_PLAN_REDUCE(v)
 #define FL_PLAN_SYNC()
@@ -169,8 +172,13 @@ struct fl_plan_ws {
     uint16_t list_sym[FL_NUM_LIT + 1];
     uint16_t list_freq[FL_NUM_LIT + 1];
     uint32_t bit_count[17];
-    fl_level_info levels[18];
+    fl_level_info levels[18];  // the reference's lazy loop (run by the CPU build only: cross-check of the package-merge form)
     uint32_t leaf_counts[17][16];
+    // package-merge form of the same computation (fl_huff_bit_counts_pm)
+    uint32_t pm_w[2 * FL_NUM_LIT];   // weights of the current level's list (2n - 2 items)
+    uint32_t pm_p[FL_NUM_LIT];       // packages = pair sums of the previous level's list
+    uint32_t pm_mask[16][18];        // per level: bit r = item r of the list is a leaf
+    uint32_t pm_c[17];               // per level: leaves among the items the solution takes
 };
 
 // what the planner hands to the encode kernel (global memory, one per block)
@@ -197,93 +205,7 @@ struct fl_block_plan {
 // sentinel is 65535 (maxInt(u16), :189,282-287) whereas the "out of leaves and
 // pairs" test (:170) compares with maxInt(i32) and therefore never fires;
 // comparisons are strict `<` on u32.
-#if FL_PLAN_PARALLEL
-// Device form of the loop below: the same steps in the same order, but the state of level L
-// (last_freq, next_char_freq, next_pair_freq, needed, and the diagonal leaf count) lives in lane L
-// of five registers, read and written with v_readlane / v_writelane (a few cycles) instead of LDS
-// round trips; the sorted frequencies sit in five more registers.  Only the off-diagonal leaf
-// counts (copied row to row by the lanes) stay in LDS.  The CPU build (tests/cpu_shim) runs the
-// plain loop; both are checked against the reference's vectors and the oracle.
-static __device__ __forceinline__ uint32_t fl_rl(uint32_t v, uint32_t l) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
-}
-static __device__ __forceinline__ uint32_t fl_wl(uint32_t v, uint32_t x, uint32_t l) {
-    return FL_PLAN_LANE() == l ? x : v;
-}
-static __device__ void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
-    const uint16_t* freq = ws->list_freq;
-    if (max_bits > n - 1) max_bits = n - 1;
-    const uint32_t lane = FL_PLAN_LANE();
-    uint32_t fr[5];
-#pragma unroll
-    for (uint32_t k = 0; k < 5; k++) fr[k] = (64 * k + lane < n) ? (uint32_t)freq[64 * k + lane] : 65535u;
-    auto freq_at = [&](uint32_t idx) -> uint32_t {
-        const uint32_t r = idx >> 6, l = idx & 63;
-        uint32_t v = fl_rl(fr[0], l);
-        if (r == 1) v = fl_rl(fr[1], l);
-        if (r == 2) v = fl_rl(fr[2], l);
-        if (r == 3) v = fl_rl(fr[3], l);
-        if (r == 4) v = fl_rl(fr[4], l);
-        return v;
-    };
-    for (uint32_t i = lane; i < 17 * 16; i += 64) (&ws->leaf_counts[0][0])[i] = 0;
-    FL_PLAN_SYNC();
-    const uint32_t f0 = fl_rl(fr[0], 0), f1 = fl_rl(fr[0], 1), f2 = fl_rl(fr[0], 2);
-    const bool lv_on = lane >= 1 && lane <= max_bits;
-    uint32_t lastF = lv_on ? f1 : 0u, nChar = lv_on ? f2 : 0u;
-    uint32_t nPair = lv_on ? (lane == 1 ? 0x7fffffffu : f0 + f1) : 0u;
-    uint32_t need = lane == max_bits ? 2 * n - 4 : 0u;
-    uint32_t diag = lv_on ? 2u : 0u;  // leaf_counts[L][L]
-    uint32_t level = max_bits;
-    for (;;) {
-        level = (uint32_t)__builtin_amdgcn_readfirstlane((int)level);
-        const uint32_t npf = fl_rl(nPair, level), ncf = fl_rl(nChar, level);
-        if (npf == 0x7fffffffu && ncf == 0x7fffffffu) {
-            need = fl_wl(need, 0u, level);
-            nPair = fl_wl(nPair, 0x7fffffffu, level + 1);
-            level += 1;
-            continue;
-        }
-        const uint32_t prev_freq = fl_rl(lastF, level);
-        uint32_t lf;
-        if (ncf < npf) {
-            const uint32_t next = fl_rl(diag, level) + 1;
-            lf = ncf;
-            diag = fl_wl(diag, next, level);
-            nChar = fl_wl(nChar, next >= n ? 65535u : freq_at(next), level);
-        } else {
-            lf = npf;
-            // row level - 1 (with its diagonal) becomes the left part of row level
-            const uint32_t dprev = fl_rl(diag, level - 1);
-            if (lane < level) ws->leaf_counts[level][lane] = lane == level - 1 ? dprev : ws->leaf_counts[level - 1][lane];
-            FL_PLAN_SYNC();
-            need = fl_wl(need, 2u, level - 1);
-        }
-        lastF = fl_wl(lastF, lf, level);
-        const uint32_t nd = fl_rl(need, level) - 1;
-        need = fl_wl(need, nd, level);
-        if (nd == 0) {
-            if (level == max_bits) break;
-            nPair = fl_wl(nPair, prev_freq + lf, level + 1);
-            level += 1;
-        } else {
-            while (fl_rl(need, level - 1) > 0) {
-                level -= 1;
-                if (level == 0) break;
-            }
-        }
-    }
-    // bit_count[b] = leaf_counts[max][max - b + 1] - leaf_counts[max][max - b]   (huffman_encoder.zig:239-246)
-    if (lane < 17) ws->bit_count[lane] = 0;
-    FL_PLAN_SYNC();
-    const uint32_t dmax = fl_rl(diag, max_bits);
-    if (lane >= 1 && lane <= max_bits) {
-        const uint32_t hi = lane == max_bits ? dmax : ws->leaf_counts[max_bits][lane];
-        ws->bit_count[max_bits - lane + 1] = hi - ws->leaf_counts[max_bits][lane - 1];
-    }
-    FL_PLAN_SYNC();
-}
-#else
+#if !FL_PLAN_PARALLEL
 FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
     const uint16_t* freq = ws->list_freq;
     fl_level_info* levels = ws->levels;
@@ -365,6 +287,89 @@ FL_HD void fl_huff_bit_counts(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
 }
 
 #endif
+
+// The same bit counts without the serial walk.  The reference's loop is the boundary form of
+// package-merge (huffman_encoder.zig:122-247): level k's list is the merge of the leaves with the
+// pair sums ("packages") of level k-1's list, a package going first when the weights tie
+// (`next_char_freq < next_pair_freq` is strict, :172), and the solution takes the first 2n-2
+// items of the top level, for every package among them two more items one level down.  Q3 lives
+// on as leaves of weight 65535 that follow the real ones (:189).  Here every level's list is
+// built outright, each item finding its place by binary search -- the items of a level are
+// independent, so the wave's lanes share them; 15 levels of about 850 searches replace some
+// 8000 dependent steps.  Checked against the loop above on the CPU (tests/test_planner_cpu.py).
+#if FL_PLAN_PARALLEL
+#define FL_PLAN_OR(p, v) atomicOr((p), (v))
+#else
+#define FL_PLAN_OR(p, v) (*(p) |= (v))
+#endif
+FL_HD void fl_huff_bit_counts_pm(fl_plan_ws* ws, uint32_t n, uint32_t max_bits) {
+    const uint16_t* freq = ws->list_freq;  // ascending, n >= 3 entries
+    if (max_bits > n - 1) max_bits = n - 1;
+    const uint32_t T = 2 * n - 2, H = n - 1;  // items per list, packages per level
+    uint32_t* W = ws->pm_w;
+    uint32_t* P = ws->pm_p;
+    FL_PLAN_FOR(i, 0, T) W[i] = i < n ? (uint32_t)freq[i] : 65535u;  // level 1: leaves only
+    FL_PLAN_FOR(i, 0, 16 * 18) (&ws->pm_mask[0][0])[i] = 0;
+    FL_PLAN_SYNC();
+    for (uint32_t k = 2; k <= max_bits; k++) {
+        FL_PLAN_FOR(j, 0, H) P[j] = W[2 * j] + W[2 * j + 1];
+        FL_PLAN_SYNC();
+        FL_PLAN_FOR(i, 0, T) {  // leaf i goes behind the packages that weigh no more
+            const uint32_t lw = i < n ? (uint32_t)freq[i] : 65535u;
+            uint32_t lo = 0, hi = H;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (P[mid] <= lw) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t r = i + lo;
+            if (r < T) {
+                W[r] = lw;
+                FL_PLAN_OR(&ws->pm_mask[k][r >> 5], 1u << (r & 31));
+            }
+        }
+        FL_PLAN_FOR(j, 0, H) {  // package j goes behind the leaves that weigh less
+            const uint32_t pw = P[j];
+            if (pw <= 65535u) {  // (a heavier one lies behind all the 65535-leaves: never taken)
+                uint32_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)freq[mid] < pw) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t r = j + lo;
+                if (r < T) W[r] = pw;
+            }
+        }
+        FL_PLAN_SYNC();
+    }
+    // top down: of the m items taken at level k, c are leaves; the packages take two items each below
+    uint32_t m = T;
+    for (uint32_t k = max_bits; k >= 1; k--) {
+        uint32_t c = 0;
+        if (k == 1) {
+            c = m;
+        } else {
+            FL_PLAN_FOR(w, 0, 18) {
+                if (32 * w < m) {
+                    uint32_t bits = ws->pm_mask[k][w];
+                    if (m - 32 * w < 32) bits &= (1u << (m - 32 * w)) - 1u;
+                    c += (uint32_t)__builtin_popcount(bits);
+                }
+            }
+            FL_PLAN_REDUCE(c);
+        }
+        ws->pm_c[k] = c;
+        m = 2 * (m - c);
+    }
+    ws->pm_c[0] = 0;
+    FL_PLAN_SYNC();
+    // huffman_encoder.zig:239-246: symbols in the lists of levels lv..max only have max - lv + 1 bits
+    FL_PLAN_FOR(b, 0, 17) {
+        uint32_t v = 0;
+        if (b >= 1 && b <= max_bits) v = ws->pm_c[max_bits - b + 1] - ws->pm_c[max_bits - b];
+        ws->bit_count[b] = v;
+    }
+    FL_PLAN_SYNC();
+}
 
 // huffman_encoder.zig:62-95 + 251-278.
 FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq,
@@ -456,7 +461,14 @@ FL_HD void fl_huff_generate(fl_plan_ws* ws, const uint16_t* freq, uint32_t nfreq
     }
 #endif
     if (nfreq == FL_NUM_LIT) FL_PLAN_MARK(49);
-    fl_huff_bit_counts(ws, count, max_bits);
+#if FL_PLAN_PARALLEL
+    fl_huff_bit_counts_pm(ws, count, max_bits);
+#else
+    if (FL_PLAN_CPU_USE_PM)
+        fl_huff_bit_counts_pm(ws, count, max_bits);
+    else
+        fl_huff_bit_counts(ws, count, max_bits);
+#endif
     if (nfreq == FL_NUM_LIT) FL_PLAN_MARK(50);
     uint32_t used_bits = max_bits > count - 1 ? count - 1 : max_bits;
     uint32_t code = 0;

@@ -19,6 +19,7 @@
 #include "kernels_inflate.h"
 #include "kernels_lz.h"
 #include "kernels_match.h"
+#include "kernels_chain.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -30,6 +31,8 @@ enum KernelId {
     K_CHECKSUM,
     K_LZ_SORT,
     K_LZ_MATCH,
+    K_LZ_CHAIN,
+    K_LZ_WALK,
     K_LZ_PARSE,
     K_LZ_EMIT,
     K_ST_PARSE,
@@ -42,6 +45,7 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
+                                           "k_lz_chain", "k_lz_walk",
                                            "k_lz_parse", "k_lz_emit",   "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_gather"};
 
@@ -474,25 +478,39 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     }
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc))) return rc;
-        {
-            ProfScope ps(h, K_LZ_SORT);
-            hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
-                               (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                               (uint16_t*)h->S.p);
-        }
-        {
-            ProfScope ps(h, K_LZ_MATCH);
-            if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
-                hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
-            else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
-                hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
-            else
-                launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
-                                     (uint32_t*)h->rec.p);
+        if (prm.dbg & 128) {
+            // FLATE_HIP_DBG=128: hash chains walked by lanes (kernels_chain.h, an experiment that lost:
+            // DESIGN.md 4c); the chain array lives in the S buffer
+            {
+                ProfScope ps(h, K_LZ_CHAIN);
+                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_WALK);
+                hipLaunchKernelGGL(k_lz_walk, dim3(nc), dim3(FL_WALK_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+            }
+        } else {
+            {
+                ProfScope ps(h, K_LZ_SORT);
+                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                   (uint16_t*)h->S.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_MATCH);
+                if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
+                    hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
+                    hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                else
+                    launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
+                                         (uint32_t*)h->rec.p);
+            }
         }
         {
             ProfScope ps(h, K_LZ_PARSE);

@@ -36,6 +36,10 @@ void shim_huff_generate(const uint16_t* freq, uint32_t n, uint32_t max_bits, uin
     }
 }
 
+// which form of the Huffman bit counts the planner runs: 0 = the reference's lazy loop, 1 = package-merge
+// (the form the GPU runs)
+void shim_set_pm(int on) { fl_plan_cpu_use_pm = on; }
+
 void shim_tables(uint8_t* len_index /*256*/, uint8_t* len_extra /*29*/, uint8_t* len_base /*29*/,
                  uint8_t* dist_code /*32768*/, uint8_t* dist_extra /*30*/, uint16_t* dist_base /*30*/) {
     for (uint32_t i = 0; i < 256; i++) len_index[i] = (uint8_t)fl_len_index(i);

@@ -36,6 +36,7 @@ def shim():
     lib.shim_plan_block.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.shim_huff_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.shim_tables.argtypes = [C.c_void_p] * 6
+    lib.shim_set_pm.argtypes = [C.c_int]
     assert lib.shim_plan_sizeof() == C.sizeof(Plan)
     return lib
 
@@ -141,7 +142,65 @@ def test_tables_match_oracle(shim):
     assert list(db[:6]) == [0, 1, 2, 3, 4, 6] and db[29] == 0x6000 and db[28] == 0x4000
 
 
-def test_huffman_generate_matches_oracle(shim):
+@pytest.fixture(params=[0, 1], ids=["lazy-loop", "package-merge"])
+def pm(request, shim):
+    """Both forms of the Huffman bit counts: the reference's lazy loop and the package-merge form the GPU runs."""
+    shim.shim_set_pm(request.param)
+    yield request.param
+    shim.shim_set_pm(0)
+
+
+def test_package_merge_equals_the_lazy_loop(shim):
+    """huffman_encoder.zig:122-247 as package-merge (flate_common.h fl_huff_bit_counts_pm) against the loop
+    itself, on frequency sets that stress ties, the length limit and totals of exactly 65536 (Q3's 65535-leaves)."""
+    rng = np.random.default_rng(23)
+    n_cases = 0
+    for it in range(1600):
+        kind = it % 8
+        n = int(rng.integers(3, 287))
+        f = np.zeros(286, np.int64)
+        if kind == 0:
+            f = rng.integers(0, 50, 286)
+        elif kind == 1:
+            f = (rng.pareto(1.0, 286) * 20).clip(0, 60000).astype(np.int64)
+        elif kind == 2:
+            a, b = 1, 1
+            for i in range(min(n, 23)):
+                f[i] = a
+                a, b = b, a + b
+        elif kind == 3:
+            w = rng.dirichlet(np.ones(n) * 0.3)
+            f[:n] = np.floor(w * 65536).astype(np.int64)
+            f[0] += 65536 - f.sum()
+        elif kind == 4:
+            f[:n] = rng.integers(1, 4, n)
+        elif kind == 5:
+            f[:n] = (2.0 ** rng.integers(0, 12, n)).astype(np.int64)
+        elif kind == 6:
+            f[:n] = 1
+            f[rng.integers(0, n)] = 65535 - n
+        else:
+            f = rng.integers(0, 2000, 286) * (rng.random(286) < 0.4)
+        f = np.clip(f, 0, 65535)
+        while f.sum() > 65536:
+            f = (f + 1) // 2 * (f > 0)
+        rng.shuffle(f)
+        for sub, mb in ((f, 15), (f[:30], 15), (f[:19], 7)):
+            sub = np.ascontiguousarray(sub, dtype=np.uint16)
+            res = []
+            for form in (0, 1):
+                shim.shim_set_pm(form)
+                cs = np.zeros(sub.size, np.uint16)
+                ls = np.zeros(sub.size, np.uint16)
+                shim.shim_huff_generate(sub.ctypes.data, sub.size, mb, cs.ctypes.data, ls.ctypes.data)
+                res.append((cs, ls))
+            shim.shim_set_pm(0)
+            assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+            n_cases += 1
+    assert n_cases == 4800
+
+
+def test_huffman_generate_matches_oracle(shim, pm):
     rng = np.random.default_rng(7)
     cases = []
     for n, mb in ((286, 15), (30, 15), (19, 7)):
@@ -188,7 +247,7 @@ def _cases():
 
 
 @pytest.mark.parametrize("fn", ["wb", "dyn"])
-def test_planner_reproduces_block_writer_goldens(shim, fn):
+def test_planner_reproduces_block_writer_goldens(shim, pm, fn):
     n = 0
     for c in _cases():
         for with_input in (True, False):
@@ -205,7 +264,7 @@ def test_planner_reproduces_block_writer_goldens(shim, fn):
     assert n == 17
 
 
-def test_planner_reproduces_huffman_block_goldens(shim):
+def test_planner_reproduces_huffman_block_goldens(shim, pm):
     names = [c["input"] for c in _cases() if c["input"]] + ["huffman-rand-max.input"]
     for name in names:
         inp = golden("block_writer", name)
@@ -214,7 +273,7 @@ def test_planner_reproduces_huffman_block_goldens(shim):
         assert got == want, name
 
 
-def test_planner_matches_oracle_on_random_blocks(shim):
+def test_planner_matches_oracle_on_random_blocks(shim, pm):
     rng = np.random.default_rng(11)
     for trial in range(60):
         n = int(rng.integers(0, 3000))

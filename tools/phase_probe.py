@@ -21,7 +21,12 @@ seg("match: stage window", 8, 9); seg("match: bucket offsets", 9, 10); seg("matc
 seg("parse: (a) desc", 16, 17); seg("parse: (b) jump", 17, 18); seg("parse: (c) serial", 18, 19); seg("parse: (d) restore", 19, 20)
 seg("parse: (e) mark", 20, 21); seg("parse: total", 16, 21)
 seg("emit: stage", 24, 25); seg("emit: count", 25, 26); seg("emit: emit", 26, 27); seg("emit: total", 24, 27)
-if t[32:48].any():
+if t[32:40].any() and os.environ.get("FL_WALK_PROF"):
+    for k, nm in {32: "walk: iterations", 33: "walk: refill rounds", 34: "walk: verify rounds", 35: "walk: walking lanes (sum)",
+                  36: "walk: free lanes at refill (sum)", 37: "walk: lanes verified (sum)", 38: "walk: sleeps"}.items():
+        print("%-34s %10d" % (nm, t[k] // 2))
+    seg("walk: stage", 8, 9); seg("walk: loop", 9, 11)
+elif t[32:48].any():
     names = {32: "m2: slice init", 33: "m2: tile build", 34: "m2: bin + perm", 35: "m2: (unused)", 36: "m2: group setup", 37: "m2: cut search", 38: "m2: unit loop + deep", 39: "m2: records",
              40: "m2: # groups",
              43: "m2: # deep loop iterations"}
