@@ -17,6 +17,7 @@
 #include "kernels_block.h"
 #include "kernels_common.h"
 #include "kernels_inflate.h"
+#include "kernels_inflate_par.h"
 #include "kernels_lz.h"
 #include "kernels_match.h"
 #include "kernels_chain.h"
@@ -41,13 +42,14 @@ enum KernelId {
     K_OFFSETS,
     K_ENCODE,
     K_INFLATE,
+    K_INFLATE_PAR,
     K_GATHER,
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
                                            "k_lz_chain", "k_lz_walk",
                                            "k_lz_parse", "k_lz_emit",   "k_st_parse", "k_st_emit", "k_plan",
-                                           "k_offsets",  "k_encode",    "k_inflate",  "k_gather"};
+                                           "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_gather"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -958,6 +960,22 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * n_chunks))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), sizeof(fl_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     HIP_OK(h, hipStreamSynchronize(st));
+    // Long streams of a batch that has few of them: a workgroup per stream (kernels_inflate_par.h).  It marks
+    // what it does not finish (short streams, anything irregular) FL_PAR_REDO, and k_inflate takes those.
+    const int32_t* redo_only = nullptr;
+    {
+        const char* e = getenv("FLATE_HIP_INFLATE_PAR");  // 0: never; else the minimum stream size in bytes
+        const uint32_t min_bytes = e ? (uint32_t)atoi(e) : 32768u;
+        uint32_t n_big = 0;
+        for (uint32_t i = 0; i < n_chunks; i++)  // long input, or an output slot that says the output is long
+            n_big += (chunks[i].in_len >= min_bytes || chunks[i].out_cap >= 16ull * min_bytes) ? 1u : 0u;
+        if (min_bytes && n_big && n_big <= 2048u && !(flags & 1)) {
+            ProfScope ps(h, K_INFLATE_PAR);
+            hipLaunchKernelGGL(k_inflate_par, dim3(n_chunks), dim3(FP_THREADS), 0, st, d_in, (const fl_chunk*)h->chunks.p,
+                               container, flags, min_bytes, h->crc, d_out, d_outlen, d_status, d_consumed);
+            redo_only = d_status;
+        }
+    }
     {
         ProfScope ps(h, K_INFLATE);
         // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
@@ -967,11 +985,11 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         if (large)
             hipLaunchKernelGGL(k_inflate<FL_INF_RING_LARGE>, dim3(n_chunks), dim3(64), 0, st, d_in,
                                (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
-                               d_consumed);
+                               d_consumed, redo_only);
         else
             hipLaunchKernelGGL(k_inflate<FL_INF_RING_SMALL>, dim3(n_chunks), dim3(64), 0, st, d_in,
                                (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
-                               d_consumed);
+                               d_consumed, redo_only);
     }
     HIP_OK(h, hipGetLastError());
     if (memkind == FLATE_HIP_MEM_HOST) {

@@ -892,7 +892,8 @@ template <uint32_t RING>
 __global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
                                                 int container, int flags, fl_crc_consts cc,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
-                                                int32_t* __restrict__ status, uint64_t* __restrict__ consumed) {
+                                                int32_t* __restrict__ status, uint64_t* __restrict__ consumed,
+                                                const int32_t* redo_only /* non-null: only streams marked -1 */) {
     __shared__ fl_inflate_ws ws_mem;
     __shared__ alignas(8) uint8_t ring_mem[RING];
     __shared__ uint32_t inring_mem[FL_INF_INRING / 4];
@@ -903,6 +904,7 @@ __global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const u
     const fl_chunk ck = chunks[c];
     const uint32_t lane = threadIdx.x;
     if (ck.skip) return;
+    if (redo_only && redo_only[c] != -1) return;  // k_inflate_par has decoded this stream
     fl_bitr r;
     r.data = in + ck.in_off;
     r.nbytes = ck.in_len;

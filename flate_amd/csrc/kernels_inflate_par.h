@@ -1,0 +1,810 @@
+// kernels_inflate_par.h -- inflate of ONE long stream by a whole workgroup (16 waves).
+//
+// Reference path: Inflate.step / dynamicBlockHeader / dynamicBlock / storedBlock
+// (inflate.zig:89-280), HuffmanDecoder.find (huffman_decoder.zig:156-175), CircularBuffer.writeMatch
+// (CircularBuffer.zig:44-75), container header / footer (container.zig:111-166).
+//
+// k_inflate gives a stream one wavefront; its serial symbol walk costs about 400 cycles per token,
+// so a batch of few long streams (BASELINE.json configs[4]: 128 x 1 MiB per GPU) leaves the chip
+// idle at 1.7 GB/s.  Here the symbols of one stream are decoded by 16 waves at once:
+//
+//  * A block is decoded in rounds over a WINDOW of 4 KiB of compressed bytes; wave w owns the
+//    2048 bits that start at window bit 2048 w.  A Huffman stream synchronises itself: decoding
+//    from a wrong bit offset falls in step with the true symbol boundaries after a few symbols.
+//    So every wave decodes its range from its nominal start, and remembers the set of bit positions
+//    at which it saw a token start (a 2048-bit map).  Inside a wave, 64 lanes decode the tokens that
+//    would start at 64 consecutive bit offsets from table lookups, and a short scalar walk over the
+//    per-lane token lengths picks the offsets that are real starts.
+//  * Stitch: the true path enters wave w's range at the bit where wave w-1's valid tokens end.
+//    Each wave has already followed every one of the 48 possible entry bits through the per-offset
+//    token lengths of its first 256 bits until it meets the wave's own path ("join"); the tokens
+//    before the join come from that short walk, those after it are the wave's own.  No join within
+//    256 bits: the window ends there and the next round starts at that bit.
+//  * Output: the window's tokens get their output offsets from prefix sums.  Literal bytes and
+//    bytes copied from the previous 32 KiB (kept in an LDS ring) are final at once; a byte copied
+//    from inside the window points at its source and is resolved by pointer jumping over byte
+//    positions (a few rounds: the depth of the copy-of-a-copy chains), so the LZ77 copies of a
+//    window need no serial order.  A window that would produce more than 16 KiB is cut at a token.
+//  * Block headers, the container header / footer and the code tables use the symbol-at-a-time
+//    code of kernels_inflate.h, run by wave 0.
+//
+// This kernel only ever reports success.  Anything else -- an invalid code or
+// distance on the true path, a checksum mismatch, an output slot that is too small, a truncated
+// stream -- marks the stream FL_PAR_REDO and k_inflate decodes it again from the start: the
+// reference's error names and their order stay the business of that one implementation.
+//
+// Bound: vector-ALU issue of the table decode (about 90 instructions per 64 bit offsets) and LDS
+// latency; no MFMA (bit and byte work).
+#pragma once
+#include "kernels_inflate.h"
+#include "kernels_lz.h"
+
+#define FL_PAR_REDO (-1)  // status written for streams that k_inflate has to decode
+
+// phase cycles of workgroup 0 (tuning aid, -DFL_PAR_PROF; read by tools/par_probe.py)
+#ifdef FL_PAR_PROF
+#define FP_WHY(n) (g_fl_prof[60] = (n), 1u)
+#define FP_T(slot)                                                        \
+    do {                                                                  \
+        const uint64_t t_now_ = __builtin_readcyclecounter();             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] += t_now_ - t_prof_; \
+        t_prof_ = t_now_;                                                 \
+    } while (0)
+#define FP_CNT(slot, v)                                                   \
+    do {                                                                  \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] += (v);  \
+    } while (0)
+#else
+#define FP_WHY(n) 1u
+#define FP_T(slot)
+#define FP_CNT(slot, v)
+#endif
+
+#define FP_WAVES 16
+#define FP_THREADS (64 * FP_WAVES)
+#define FP_SUBW 32                               // 64-bit sub-windows per wave and round
+#define FP_WBITS (64 * FP_SUBW)                  // bits per wave and round
+#define FP_WIN_BYTES (FP_WAVES * FP_WBITS / 8)   // compressed bytes per round
+#define FP_STAGE_DW (FP_WIN_BYTES / 4 + 8)       // + the bytes the last tokens reach into
+#define FP_TOK_CAP 512                           // tokens per wave and round
+#define FP_JOIN_BITS 1024                        // bits of a wave's range within which an entering path must join
+#define FP_MAX_FIX 96                            // tokens an entering path may take before it joins
+#define FP_ENTRIES 48                            // a token has at most 48 bits: entry bit < 48
+#define FP_OUT_CAP 16384u                        // output bytes per round
+#define FP_RING (32768u + FP_OUT_CAP)            // history + window
+#define FP_RES 0xffffu                           // ptr value: byte is final
+#define FP_NOJOIN 0xffffu
+#define FP_JTERM 0x8000u
+
+enum { FP_X_NORMAL = 0, FP_X_EOB = 1, FP_X_BAIL = 2, FP_X_FULL = 3, FP_X_CUT = 4 };
+
+// tokens: literal = byte; match = 1 << 31 | length << 16 | distance - 1; terminators (never in a
+// token list, only in the per-offset tables): 1 << 30 | kind << 8 | code bits
+#define FP_TOK_MATCH(len, dist) (0x80000000u | ((len) << 16) | ((dist)-1u))
+#define FP_TOK_TERM(kind, bits) (0x40000000u | ((uint32_t)(kind) << 8) | (bits))
+
+struct fp_long {
+    uint32_t lim[16], first[16], index[16];
+};
+
+struct fp_shared {
+    fl_inflate_ws ws;
+    uint32_t inring[FL_INF_INRING / 4];  // wave 0's symbol-at-a-time reader
+    uint32_t stage[FP_STAGE_DW];         // the window's compressed bytes
+    uint32_t tok[FP_WAVES][FP_TOK_CAP];
+    uint32_t bitmap[FP_WAVES][FP_WBITS / 32];
+    uint8_t tb[FP_WAVES][FP_JOIN_BITS];    // per bit offset of the first 512 bits: bits of the token that would start there (255 = terminator)
+    uint16_t join[FP_WAVES][FP_ENTRIES];   // entry bit -> join position | FP_JTERM
+    uint8_t join_n[FP_WAVES][FP_ENTRIES];  // ... and the tokens before it
+    uint32_t fixtok[FP_WAVES][FP_MAX_FIX];
+    uint16_t fixpos[FP_WAVES][FP_MAX_FIX];
+    uint8_t ring[FP_RING];
+    uint16_t ptr[FP_OUT_CAP];
+    // per wave
+    uint32_t w_ntok[FP_WAVES], w_xkind[FP_WAVES], w_xpos[FP_WAVES];
+    uint32_t w_valid[FP_WAVES], w_entry[FP_WAVES], w_fv[FP_WAVES], w_nfix[FP_WAVES], w_nown[FP_WAVES];
+    uint32_t w_total[FP_WAVES], w_base[FP_WAVES];
+    // stream / round state
+    uint64_t bitpos, wp;
+    fp_long lit_long, dst_long;
+    uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
+    uint32_t redo, blk_done, blk_final, blk_type, unresolved;
+    uint32_t st_len;  // stored block: bytes
+    uint32_t wbits;   // bits per wave and round
+    uint32_t crc, adA, adB;
+};
+
+// Codes longer than the lookup table, without a loop: canonical codes of one length are consecutive
+// numbers, so a 15-bit window (first stream bit = most significant) belongs to length L iff it is
+// below lim[L] = (first code of L + count of L) << (15 - L) and not below lim[L - 1]
+// (huffman_decoder.zig:156-175 finds the same symbol bit by bit).
+template <class H>
+__device__ __forceinline__ void fp_long_build(const FL_LDS H* d, FL_LDS fp_long* t, uint32_t lane) {
+    uint32_t code = 0, idx = 0;
+    for (uint32_t len = 1; len <= 15; len++) {  // (every lane the same values, lane 0 stores)
+        const uint32_t count = d->count[len];
+        if (lane == 0) {
+            t->first[len] = code;
+            t->index[len] = idx;
+            t->lim[len] = (code + count) << (15 - len);
+        }
+        code = (code + count) << 1;
+        idx += count;
+    }
+    fl_wave_lds_sync();
+}
+template <int TBITS, class H>
+__device__ __forceinline__ int fp_find_long(const FL_LDS H* d, const FL_LDS fp_long* t, uint32_t peek15, uint32_t& sym,
+                                            uint32_t& code_bits) {
+    const uint32_t c = __brev(peek15) >> 17;
+    uint32_t len = TBITS + 1;
+#pragma unroll
+    for (int k = TBITS + 1; k <= 14; k++) len += c >= t->lim[k] ? 1u : 0u;
+    if (c >= t->lim[15]) return 7;  // InvalidCode
+    sym = d->symbol[t->index[len] + ((c >> (15 - len)) - t->first[len])];
+    code_bits = len;
+    return 0;
+}
+
+// The token that would start at a bit offset whose next 64 stream bits are hi:lo.
+// bits = its length in bits (terminators: the code's bits), pay = the token.
+__device__ __forceinline__ void fp_decode_at(const FL_LDS fp_shared* sh, uint32_t lo, uint32_t hi, uint32_t& bits,
+                                             uint32_t& pay) {
+    const FL_LDS fl_inflate_ws* ws = &sh->ws;
+    uint32_t le = ws->lit_lut[lo & ((1u << FL_INF_LIT_BITS) - 1)];
+    if (le == 0) {
+        uint32_t sym, cb;
+        if (fp_find_long<FL_INF_LIT_BITS>(&ws->lit, &sh->lit_long, lo & 0x7fffu, sym, cb)) {
+            bits = 0;
+            pay = FP_TOK_TERM(FP_X_BAIL, 0);
+            return;
+        }
+        uint32_t eb, val;
+        if (sym < 256) {
+            eb = 0;
+            val = sym;
+        } else if (sym == 256) {
+            eb = 0;
+            val = 0;
+        } else {
+            eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
+            val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
+        }
+        le = sym | (cb << 9) | (eb << 13) | (val << 17);
+    }
+    const uint32_t sym = le & 511, cb = (le >> 9) & 15, eb = (le >> 13) & 15, val = le >> 17;
+    if (eb == 15) {
+        bits = 0;
+        pay = FP_TOK_TERM(FP_X_BAIL, 0);
+        return;
+    }
+    if (sym < 256) {
+        bits = cb;
+        pay = val;
+        return;
+    }
+    if (sym == 256) {
+        bits = cb;
+        pay = FP_TOK_TERM(FP_X_EOB, cb);
+        return;
+    }
+    const uint32_t length = val + ((lo >> cb) & ((1u << eb) - 1));
+    const uint32_t lb = cb + eb;  // <= 20
+    const uint32_t dw = (uint32_t)((((uint64_t)hi << 32) | lo) >> lb);
+    uint32_t de = ws->dst_lut[dw & ((1u << FL_INF_DST_BITS) - 1)];
+    if (de == 0) {
+        uint32_t dsym, dcb;
+        if (fp_find_long<FL_INF_DST_BITS>(&ws->dst, &sh->dst_long, dw & 0x7fffu, dsym, dcb)) {
+            bits = 0;
+            pay = FP_TOK_TERM(FP_X_BAIL, 0);
+            return;
+        }
+        const uint32_t deb = dsym <= 29 ? fl_dist_extra_bits(dsym) : 15u;
+        const uint32_t dval = dsym <= 29 ? fl_dist_base_scaled(dsym) + 1 : 0u;
+        de = dsym | (dcb << 9) | (deb << 13) | (dval << 17);
+    }
+    const uint32_t dcb = (de >> 9) & 15, deb = (de >> 13) & 15, dval = de >> 17;
+    if (deb == 15) {
+        bits = 0;
+        pay = FP_TOK_TERM(FP_X_BAIL, 0);
+        return;
+    }
+    const uint32_t distance = dval + ((dw >> dcb) & ((1u << deb) - 1));
+    bits = lb + dcb + deb;  // <= 48
+    pay = FP_TOK_MATCH(length, distance);
+}
+
+// the 64 stream bits that start at window bit `bp`
+__device__ __forceinline__ void fp_fetch64(const FL_LDS uint32_t* stage, uint32_t bp, uint32_t& lo, uint32_t& hi) {
+    const uint32_t di = bp >> 5, sh = bp & 31;
+    const uint32_t d0 = stage[di], d1 = stage[di + 1], d2 = stage[di + 2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+}
+
+__device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  // rel in [-32768, FP_OUT_CAP)
+    uint32_t x = wbase + (uint32_t)((int32_t)FP_RING + rel);  // wbase < FP_RING
+    if (x >= FP_RING) x -= FP_RING;
+    if (x >= FP_RING) x -= FP_RING;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t fp_tok_len(uint32_t t) { return (t >> 31) ? ((t >> 16) & 0x1ffu) : 1u; }
+
+// One workgroup per stream.  `min_bytes`: shorter streams are left to k_inflate.
+__global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __restrict__ in,
+                                                               const fl_chunk* __restrict__ chunks, int container,
+                                                               int flags, uint32_t min_bytes, fl_crc_consts cc,
+                                                               uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
+                                                               int32_t* __restrict__ status,
+                                                               uint64_t* __restrict__ consumed) {
+    __shared__ fp_shared sh_mem;
+    FL_LDS fp_shared* sh = (FL_LDS fp_shared*)&sh_mem;
+    FL_LDS fl_inflate_ws* ws = &sh->ws;
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((ck.in_len < min_bytes && ck.out_cap < 16ull * min_bytes) || (flags & 1)) {  // (reference-strict Q6 headers: k_inflate's job as well)
+        if (tid == 0) status[c] = FL_PAR_REDO;
+        return;
+    }
+    const uint8_t* src = in + ck.in_off;
+    uint8_t* dst = out + ck.out_off;
+    const uint64_t total_bits = (uint64_t)ck.in_len * 8;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+    fl_bitr r;  // wave 0 only
+    r.data = src;
+    r.nbytes = ck.in_len;
+    r.lane = lane;
+    r.inring = (FL_LDS uint32_t*)sh->inring;
+    r.left = (int64_t)total_bits;
+    auto reader_at = [&](uint64_t bitpos) {  // restart the symbol-at-a-time reader at a bit position
+        r.left = (int64_t)(total_bits - bitpos);
+        fl_br_seek(r, (uint32_t)(bitpos >> 3));
+        const uint32_t k = (uint32_t)bitpos & 7;
+        if (k) {
+            fl_br_refill(r);
+            r.buf >>= k;
+            r.have -= k;
+        }
+    };
+    auto reader_pos = [&]() -> uint64_t { return total_bits - (uint64_t)r.left; };
+
+    if (tid == 0) {
+        sh->redo = 0;
+        sh->wp = 0;
+        sh->wbits = FP_WBITS;
+    }
+    if (wave == 0) {
+        fl_br_seek(r, 0);
+        const int rc = fl_inf_header(r, container);
+        if (lane == 0) {
+            if (rc) sh->redo = FP_WHY(1);
+            sh->bitpos = reader_pos();
+        }
+    }
+    __syncthreads();
+
+#ifdef FL_PAR_PROF
+    uint64_t t_prof_ = __builtin_readcyclecounter();
+#endif
+    // ================================================================ blocks
+    for (;;) {
+        if (sh->redo) break;
+        FP_T(32);
+        // ---- block header (wave 0)
+        if (wave == 0) {
+            reader_at(sh->bitpos);
+            uint32_t bfinal = 0, btype = 3;
+            int rc = fl_br_read(r, 1, bfinal);
+            if (!rc) rc = fl_br_read(r, 2, btype);
+            uint32_t stlen = 0;
+            if (!rc && btype == 2) {
+                rc = fl_inf_dynamic_header(r, ws, flags, lane);
+                if (!rc) {
+                    fp_long_build(&ws->lit, &sh->lit_long, lane);
+                    fp_long_build(&ws->dst, &sh->dst_long, lane);
+                }
+            } else if (!rc && btype == 1) {
+                // fixed codes (RFC 1951 3.2.6, inflate.zig:104-121) through the same tables: lengths 8/9/7/8
+                // for the 288 literal/length codes, 5 for the 32 distance codes (286, 287, 30, 31: invalid)
+                fl_wave_lds_sync();
+                for (uint32_t i = lane; i < 320; i += 64)
+                    ws->lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+                fl_wave_lds_sync();
+                rc = fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 288, 286, 15, lane);
+                if (!rc) rc = fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 32, 30, 15, lane);
+                if (!rc) {
+                    fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
+                    fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+                    fp_long_build(&ws->lit, &sh->lit_long, lane);
+                    fp_long_build(&ws->dst, &sh->dst_long, lane);
+                }
+            } else if (!rc && btype == 0) {
+                fl_br_align(r);
+                uint32_t len = 0, nlen = 0;
+                rc = fl_br_read(r, 16, len);
+                if (!rc) rc = fl_br_read(r, 16, nlen);
+                if (!rc && len != ((~nlen) & 0xffff)) rc = 13;
+                if (!rc && (int64_t)len * 8 > r.left) rc = 1;
+                stlen = len;
+            } else if (!rc) {
+                rc = 12;  // invalid block type: k_inflate
+            }
+            if (lane == 0) {
+                if (rc) sh->redo = FP_WHY(2);
+                sh->bitpos = reader_pos();
+                sh->blk_final = bfinal;
+                sh->blk_type = btype;
+                sh->st_len = stlen;
+                sh->blk_done = 0;
+            }
+        }
+        __syncthreads();
+        FP_T(33);
+        if (sh->redo) break;
+
+        if (sh->blk_type == 0) {
+            // ---- stored block (inflate.zig:89-102): bytes go out as they are, the ring keeps the last of them
+            const uint32_t len = sh->st_len;
+            const uint64_t wp = sh->wp;
+            const uint32_t from = (uint32_t)(sh->bitpos >> 3);
+            if (wp + len > ck.out_cap) {
+                if (tid == 0) sh->redo = FP_WHY(3);
+            } else {
+                for (uint32_t i = tid; i < len; i += FP_THREADS) dst[wp + i] = src[from + i];
+                const uint32_t tail = min(len, FP_RING);
+                for (uint32_t i = tid; i < tail; i += FP_THREADS) {
+                    const uint64_t o = wp + len - tail + i;
+                    sh->ring[(uint32_t)(o % FP_RING)] = src[from + len - tail + i];
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                sh->wp = wp + len;
+                sh->bitpos += (uint64_t)len * 8;
+            }
+            __syncthreads();
+        } else {
+            // ---- Huffman block: rounds over windows of 4 KiB
+            for (;;) {
+                const uint64_t bitpos = sh->bitpos;
+                const uint64_t wp = sh->wp;
+                const uint32_t byte0 = (uint32_t)(bitpos >> 3), bit0 = (uint32_t)bitpos & 7;
+                const uint32_t wbase = (uint32_t)(wp % FP_RING);
+                // bits per wave: halved (for the rest of the stream) when a wave ran out of token slots
+                const uint32_t wbits = sh->wbits, jbits = min(wbits, (uint32_t)FP_JOIN_BITS);
+                // (1) stage the window
+                for (uint32_t i = tid; i < FP_STAGE_DW; i += FP_THREADS)
+                    sh->stage[i] = fl_load_u32_clamped(src, byte0 + 4 * i, ck.in_len);
+                sh->bitmap[wave][lane] = 0;
+                __syncthreads();
+                FP_T(34);
+                FP_CNT(48, 1);
+                // (2) every wave decodes its 2048 bits from its nominal start
+                {
+                    const uint32_t wb0 = bit0 + wave * wbits;
+                    uint32_t carry = 0, ntok = 0, xkind = FP_X_NORMAL, xpos = 0;
+                    uint32_t s_tab = 0;  // sub-windows whose per-offset token lengths are stored
+                    for (uint32_t s = 0; s < wbits / 64; s++) {
+                        if (ntok > FP_TOK_CAP - 64) {
+                            xkind = FP_X_FULL;
+                            xpos = 64 * s + carry;
+                            break;
+                        }
+                        uint32_t lo, hi, bits, pay;
+                        fp_fetch64(sh->stage, wb0 + 64 * s + lane, lo, hi);
+                        fp_decode_at(sh, lo, hi, bits, pay);
+                        const uint32_t nextv = ((pay >> 30) == 1) ? 255u : lane + bits;
+                        if (s < jbits / 64) {
+                            sh->tb[wave][64 * s + lane] = nextv == 255u ? (uint8_t)255 : (uint8_t)bits;
+                            s_tab = s + 1;
+                        }
+                        // scalar walk over the real starts of this sub-window
+                        uint64_t mask = 0;
+                        uint32_t p = carry, term = 0;
+                        do {
+                            mask |= 1ull << p;
+                            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nextv, (int)p);
+                            if (n == 255u) {
+                                term = p + 1;
+                                break;
+                            }
+                            p = n;
+                        } while (p < 64);
+                        if (lane == 0) {
+                            sh->bitmap[wave][2 * s] = (uint32_t)mask;
+                            sh->bitmap[wave][2 * s + 1] = (uint32_t)(mask >> 32);
+                        }
+                        const uint64_t tokmask = term ? (mask & ~(1ull << (term - 1))) : mask;
+                        if ((tokmask >> lane) & 1) sh->tok[wave][ntok + (uint32_t)__popcll(tokmask & lt_mask)] = pay;
+                        ntok += (uint32_t)__popcll(tokmask);
+                        if (term) {
+                            const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)pay, (int)(term - 1));
+                            xkind = (tp >> 8) & 0xff;
+                            xpos = 64 * s + (term - 1) + (xkind == FP_X_EOB ? (tp & 0xff) : 0u);
+                            break;
+                        }
+                        carry = p - 64;
+                    }
+                    if (xkind == FP_X_NORMAL) xpos = wbits + carry;
+                    for (uint32_t s = s_tab; s < jbits / 64; s++) {  // (the wave's own path ended early)
+                        uint32_t lo, hi, bits, pay;
+                        fp_fetch64(sh->stage, wb0 + 64 * s + lane, lo, hi);
+                        fp_decode_at(sh, lo, hi, bits, pay);
+                        sh->tb[wave][64 * s + lane] = ((pay >> 30) == 1) ? (uint8_t)255 : (uint8_t)bits;
+                    }
+                    if (lane == 0) {
+                        sh->w_ntok[wave] = ntok;
+                        sh->w_xkind[wave] = xkind;
+                        sh->w_xpos[wave] = xpos;
+                    }
+                    fl_lds_order();
+                    // (3) where would a path entering at bit c join this wave's path?
+                    if (lane < FP_ENTRIES) {
+                        uint32_t p = lane, nfix = 0, res = FP_NOJOIN;
+                        for (uint32_t it = 0; it <= FP_MAX_FIX; it++) {
+                            if (p >= jbits) break;
+                            if ((sh->bitmap[wave][p >> 5] >> (p & 31)) & 1) {
+                                res = p;
+                                break;
+                            }
+                            const uint32_t t = sh->tb[wave][p];
+                            if (t == 255u) {
+                                res = p | FP_JTERM;
+                                break;
+                            }
+                            if (nfix == FP_MAX_FIX) break;
+                            p += t;
+                            nfix++;
+                        }
+                        sh->join[wave][lane] = (uint16_t)res;
+                        sh->join_n[wave][lane] = (uint8_t)nfix;
+                    }
+                }
+                __syncthreads();
+                FP_T(35);
+                // (4) stitch.  Once a path has joined a wave's own path it leaves the wave where that one does,
+                // whatever its entry bit was: every wave can judge its own entry, the window ends at the first
+                // wave that ends it.
+                if (lane == 0) {
+                    const uint32_t w = wave;
+                    uint32_t fv = 0, nfix = 0, e = 0, endk = FP_X_NORMAL, endp = 0;  // endk != NORMAL: the window ends in this wave
+                    bool enter = true;  // false: the window ends before this wave's tokens
+                    const uint32_t ntok = sh->w_ntok[w];
+                    uint32_t xk = sh->w_xkind[w], xp = sh->w_xpos[w];
+                    if (w > 0) {
+                        if (sh->w_xkind[w - 1] != FP_X_NORMAL) {
+                            enter = false;  // (an earlier wave ends the window anyway)
+                            endk = FP_X_CUT;
+                        } else {
+                            e = sh->w_xpos[w - 1] - wbits;
+                            const uint32_t j = e < FP_ENTRIES ? sh->join[w][e] : FP_NOJOIN;
+                            if (j == FP_NOJOIN) {  // the window ends where this wave's range is entered
+                                enter = false;
+                                endk = FP_X_CUT;
+                                endp = e;
+                                FP_CNT(57, 1);
+                            } else {
+                                const uint32_t jp = j & 0x7ff;
+                                nfix = sh->join_n[w][e];
+                                if (j & FP_JTERM) {  // the entering path ends before it joins: EOB or a bad code
+                                    uint32_t lo, hi, tbits, tp;
+                                    fp_fetch64(sh->stage, bit0 + w * wbits + jp, lo, hi);
+                                    fp_decode_at(sh, lo, hi, tbits, tp);
+                                    xk = (tp >> 8) & 0xff;
+                                    xp = jp + (xk == FP_X_EOB ? (tp & 0xff) : 0u);
+                                    fv = ntok;
+                                } else {
+                                    for (uint32_t k = 0; k < (jp >> 5); k++) fv += (uint32_t)__popc(sh->bitmap[w][k]);
+                                    fv += (uint32_t)__popc(sh->bitmap[w][jp >> 5] & ((1u << (jp & 31)) - 1u));
+                                    if (fv > ntok) fv = ntok;  // a join at the wave's terminator: no own tokens
+                                }
+                            }
+                        }
+                    }
+                    if (enter && xk != FP_X_NORMAL) {
+                        endk = xk;
+                        endp = xp;
+                    }
+                    sh->w_valid[w] = enter ? 1u : 0u;
+                    sh->w_entry[w] = e;
+                    sh->w_fv[w] = fv;
+                    sh->w_nfix[w] = nfix;
+                    sh->w_nown[w] = ntok - fv;
+                    sh->w_total[w] = endk;   // (borrowed until the layout step)
+                    sh->w_base[w] = endp;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t nvalid = FP_WAVES, kind = FP_X_NORMAL, next = FP_WAVES * wbits + (sh->w_xpos[FP_WAVES - 1] - wbits);
+                    for (uint32_t w = 0; w < FP_WAVES; w++) {
+                        const uint32_t endk = sh->w_total[w];
+                        if (endk != FP_X_NORMAL) {
+                            nvalid = w + (sh->w_valid[w] ? 1u : 0u);
+                            kind = endk;
+                            next = w * wbits + sh->w_base[w];
+                            break;
+                        }
+                    }
+                    FP_CNT(52 + kind, 1);
+                    sh->r_nvalid = nvalid;
+                    sh->r_kind = kind;
+                    sh->r_next = next;  // window bit where the next round / block starts
+                    sh->r_cutwave = 0xffffffffu;
+                    if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
+                }
+                __syncthreads();
+                FP_T(36);
+                if (sh->redo) break;
+                const uint32_t nvalid = sh->r_nvalid;
+                FP_CNT(49, nvalid);
+                // (5) the tokens of the entering paths; output bytes per wave
+                if (wave < nvalid) {
+                    const uint32_t nfix = sh->w_nfix[wave];
+                    uint32_t p = sh->w_entry[wave];
+                    for (uint32_t k0 = 0; k0 < nfix; k0 += 64) {
+                        // positions of the path's tokens (a wave-uniform walk), then their tokens, one per lane
+                        uint32_t myp = 0;
+                        for (uint32_t k = k0; k < min(nfix, k0 + 64); k++) {
+                            if (lane == k - k0) myp = p;
+                            p += sh->tb[wave][p];
+                        }
+                        if (k0 + lane < nfix) {
+                            uint32_t lo, hi, tbits, tp;
+                            fp_fetch64(sh->stage, bit0 + wave * wbits + myp, lo, hi);
+                            fp_decode_at(sh, lo, hi, tbits, tp);
+                            sh->fixtok[wave][k0 + lane] = tp;
+                            sh->fixpos[wave][k0 + lane] = (uint16_t)myp;
+                        }
+                    }
+                    fl_lds_order();
+                    const uint32_t nown = sh->w_nown[wave], fv = sh->w_fv[wave], n = nfix + nown;
+                    uint32_t sum = 0;
+                    for (uint32_t k = lane; k < n; k += 64)
+                        sum += fp_tok_len(k < nfix ? sh->fixtok[wave][k] : sh->tok[wave][fv + k - nfix]);
+                    sum = fl_wave_sum(sum);
+                    if (lane == 0) sh->w_total[wave] = sum;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t run = 0;
+                    for (uint32_t w = 0; w < nvalid; w++) {
+                        sh->w_base[w] = run;
+                        if (run + sh->w_total[w] > FP_OUT_CAP && sh->r_cutwave == 0xffffffffu) {
+                            sh->r_cutwave = w;  // the window is cut at a token of this wave
+                            sh->r_cutbudget = FP_OUT_CAP - run;
+                            sh->r_nvalid = w + 1;
+                            break;
+                        }
+                        run += sh->w_total[w];
+                    }
+                    sh->r_nout = run;  // (the cut wave adds what fits)
+                    sh->unresolved = 0;
+                }
+                __syncthreads();
+                FP_T(37);
+                const uint32_t nv2 = sh->r_nvalid, cutwave = sh->r_cutwave;
+                // (6) fill: literals and copies from the history are final, the rest points at its source
+                if (wave < nv2) {
+                    const uint32_t nfix = sh->w_nfix[wave], nown = sh->w_nown[wave], fv = sh->w_fv[wave];
+                    const uint32_t n = nfix + nown;
+                    const bool cut = wave == cutwave;
+                    const uint32_t budget = cut ? sh->r_cutbudget : 0xffffffffu;
+                    uint32_t off = sh->w_base[wave], used = 0;
+                    for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        uint32_t t = 0, len = 0;
+                        if (k < n) {
+                            t = k < nfix ? sh->fixtok[wave][k] : sh->tok[wave][fv + k - nfix];
+                            len = fp_tok_len(t);
+                        }
+                        const uint32_t incl = fl_wave_incl_scan(len, lane);
+                        uint64_t okm = __ballot(k < n && used + incl <= budget);
+                        uint32_t stop = 64;
+                        if (cut) {
+                            const uint64_t over = __ballot(k < n && used + incl > budget);
+                            if (over) {
+                                stop = (uint32_t)__builtin_ctzll(over);
+                                okm &= (1ull << stop) - 1ull;
+                            }
+                        }
+                        const uint32_t my_off = off + used + incl - len;
+                        const bool ok = (okm >> lane) & 1;
+                        if (ok && !(t >> 31)) {
+                            sh->ring[fp_ring_idx(wbase, (int32_t)my_off)] = (uint8_t)t;
+                            sh->ptr[my_off] = (uint16_t)FP_RES;
+                        }
+                        // a copied byte points at its source: window position + 32768 (below: the 32 KiB before
+                        // the window); short copies are written by their own lanes, long ones by the wave
+                        const bool is_m = ok && (t >> 31);
+                        const uint32_t mlen_l = (t >> 16) & 0x1ff, mdist_l = (t & 0xffff) + 1;
+                        if (is_m && (uint64_t)mdist_l > wp + my_off) sh->redo = FP_WHY(5);  // reaches before the start of the output
+                        const uint32_t src0 = my_off + 32768u - mdist_l;
+                        const uint32_t shortmax = fl_wave_max(is_m && mlen_l <= 32 ? mlen_l : 0u);
+                        for (uint32_t i = 0; i < shortmax; i++)
+                            if (is_m && mlen_l <= 32 && i < mlen_l) sh->ptr[my_off + i] = (uint16_t)(src0 + i);
+                        uint64_t mm = __ballot(is_m && mlen_l > 32);
+                        while (mm) {
+                            const uint32_t l0 = (uint32_t)__builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)mlen_l, (int)l0);
+                            const uint32_t mo = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)l0);
+                            const uint32_t ms = (uint32_t)__builtin_amdgcn_readlane((int)src0, (int)l0);
+                            for (uint32_t i = lane; i < mlen; i += 64) sh->ptr[mo + i] = (uint16_t)(ms + i);
+                        }
+                        if (stop < 64) {
+                            // the token at k0 + stop does not fit: the next round starts at its bit
+                            const uint32_t kc = k0 + stop;
+                            const uint32_t fit = stop ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(stop - 1)) : 0u;
+                            uint32_t pos;
+                            if (kc < nfix) {
+                                pos = sh->fixpos[wave][kc];
+                            } else {
+                                // own token number fv + kc - nfix = that set bit of the wave's map
+                                uint32_t want = fv + kc - nfix, wd = 0;
+                                while (wd < FP_WBITS / 32 && want >= (uint32_t)__popc(sh->bitmap[wave][wd])) {
+                                    want -= (uint32_t)__popc(sh->bitmap[wave][wd]);
+                                    wd++;
+                                }
+                                uint32_t bitsw = wd < FP_WBITS / 32 ? sh->bitmap[wave][wd] : 0u;
+                                for (uint32_t q = 0; q < want; q++) bitsw &= bitsw - 1;
+                                pos = 32 * wd + (bitsw ? (uint32_t)__builtin_ctz(bitsw) : 0u);
+                            }
+                            if (lane == 0) {
+                                sh->r_kind = FP_X_CUT;
+                                sh->r_next = wave * wbits + pos;
+                                sh->r_nout = off + used + fit;
+                            }
+                            break;
+                        }
+                        used += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
+                }
+                __syncthreads();
+                FP_T(38);
+                if (sh->redo) break;
+                const uint32_t nout = sh->r_nout;
+                FP_CNT(50, nout);
+                if (wp + nout > ck.out_cap) {  // OutputTooSmall is k_inflate's to report
+                    if (tid == 0) sh->redo = FP_WHY(6);
+                    __syncthreads();
+                    break;
+                }
+                // (7) resolve the copies inside the window by pointer jumping over byte positions
+                for (;;) {
+                    bool mine = false;
+                    for (uint32_t j = tid; j < nout; j += FP_THREADS) {
+                        const uint32_t v = sh->ptr[j];
+                        if (v != FP_RES) {
+                            if (v < 32768u) {  // the source lies before the window: final
+                                sh->ring[fp_ring_idx(wbase, (int32_t)j)] = sh->ring[fp_ring_idx(wbase, (int32_t)v - 32768)];
+                                asm volatile("" ::: "memory");  // the flag is written after the byte
+                                sh->ptr[j] = (uint16_t)FP_RES;
+                            } else {
+                                const uint32_t pv = sh->ptr[v - 32768u];
+                                asm volatile("" ::: "memory");  // the source byte is read after its flag
+                                if (pv == FP_RES) {
+                                    sh->ring[fp_ring_idx(wbase, (int32_t)j)] = sh->ring[fp_ring_idx(wbase, (int32_t)v - 32768)];
+                                    asm volatile("" ::: "memory");
+                                    sh->ptr[j] = (uint16_t)FP_RES;
+                                } else {
+                                    sh->ptr[j] = (uint16_t)pv;  // the source's source
+                                    mine = true;
+                                }
+                            }
+                        }
+                    }
+                    FP_CNT(51, 1);
+                    if (__any(mine) && lane == 0) sh->unresolved = 1;
+                    __syncthreads();
+                    const uint32_t again = sh->unresolved;
+                    __syncthreads();
+                    if (!again) break;
+                    if (tid == 0) sh->unresolved = 0;
+                    __syncthreads();
+                }
+                FP_T(39);
+                // (8) the window's bytes leave
+                for (uint32_t j = tid; j < nout; j += FP_THREADS) dst[wp + j] = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
+                __syncthreads();
+                if (tid == 0) {
+                    const uint64_t nb = bitpos + sh->r_next;  // r_next counts from the window's first bit
+                    if (nb > total_bits || (nb <= bitpos && sh->r_kind != FP_X_EOB)) sh->redo = FP_WHY(7);  // past the end / no progress
+                    sh->bitpos = nb;
+                    sh->wp = wp + nout;
+                    sh->blk_done = sh->r_kind == FP_X_EOB;
+                    if (sh->r_kind == FP_X_FULL && wbits > 512) sh->wbits = wbits >> 1;  // 512 bits hold at most 512 tokens
+                }
+                __syncthreads();
+                FP_T(40);
+                if (sh->redo || sh->blk_done) break;
+            }
+            if (sh->redo) break;
+        }
+        if (sh->blk_final) break;
+    }
+    __syncthreads();
+    if (sh->redo) {
+        if (tid == 0) status[c] = FL_PAR_REDO;
+        return;
+    }
+
+    // ================================================================ footer (container.zig:154-166)
+    const uint64_t n_out = sh->wp;
+    if (container != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        FL_LDS uint32_t* tab = (FL_LDS uint32_t*)ws->lit_lut;  // the code tables are no longer needed
+        if (container == 1) {
+            for (uint32_t t = tid; t < 256; t += FP_THREADS) {
+                uint32_t v = t;
+                for (int k = 0; k < 8; k++) v = (v & 1) ? (FL_CRC_POLY ^ (v >> 1)) : (v >> 1);
+                tab[t] = v;
+            }
+        }
+        if (tid == 0) {
+            sh->crc = 0;
+            sh->adA = 0;
+            sh->adB = 0;
+        }
+        __syncthreads();
+        const uint64_t per = (n_out + FP_THREADS - 1) / FP_THREADS;
+        const uint64_t lo = min(n_out, (uint64_t)tid * per), hi = min(n_out, lo + per);
+        if (container == 1) {
+            uint32_t v = 0xffffffffu;
+            for (uint64_t i = lo; i < hi; i++) v = tab[(v ^ dst[i]) & 0xff] ^ (v >> 8);
+            v = hi > lo ? ~v : 0u;
+            v = fl_crc_mulmod(v, fl_crc_xpow8n(cc.xpow8, n_out - hi));
+            v = fl_wave_xor(v);
+            if (lane == 0) atomicXor(&sh_mem.crc, v);
+        } else {
+            uint32_t A = 0, B = 0;
+            uint64_t i = lo;
+            while (i < hi) {
+                const uint64_t e = min(hi, i + 5552);
+                for (; i < e; i++) {
+                    A += dst[i];
+                    B += A;
+                }
+                A %= 65521u;
+                B %= 65521u;
+            }
+            const uint64_t after = (n_out - hi) % 65521u;
+            uint32_t Bm = (uint32_t)((B + (uint64_t)A * after) % 65521u);
+            const uint32_t As = fl_wave_sum(A), Bs = fl_wave_sum(Bm);  // 64 values < 65521
+            if (lane == 0) {
+                atomicAdd(&sh_mem.adA, As);  // 16 partial sums < 2^22: no overflow
+                atomicAdd(&sh_mem.adB, Bs);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        reader_at(sh->bitpos);
+        fl_br_align(r);
+        int rc = 0;
+        uint32_t v = 0;
+        if (container == 1) {
+            rc = fl_br_read(r, 32, v);
+            if (!rc && v != sh->crc) rc = 4;
+            if (!rc) rc = fl_br_read(r, 32, v);
+            if (!rc && v != (uint32_t)n_out) rc = 5;
+        } else if (container == 2) {
+            const uint32_t a = (1 + sh->adA % 65521u) % 65521u;
+            const uint32_t b = (uint32_t)((n_out % 65521u + sh->adB % 65521u) % 65521u);
+            rc = fl_br_read(r, 32, v);
+            if (!rc && v != __builtin_bswap32(a | (b << 16))) rc = 6;
+        }
+        if (lane == 0) {
+            if (rc) {
+                status[c] = FL_PAR_REDO;
+            } else {
+                out_len[c] = n_out;
+                status[c] = 0;
+                if (consumed) consumed[c] = fl_br_consumed(r);
+            }
+        }
+    }
+}

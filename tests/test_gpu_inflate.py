@@ -14,6 +14,18 @@ from test_oracle_inflate_pins import ABCD, DYN, FIXED, FUZZ, GZ_HDR, HELLO, STOR
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wave", "workgroup"])
+def inflate_path(request, monkeypatch):
+    """Every test of this file runs twice: with the library's own choice (these short streams go to k_inflate,
+    one wave per stream) and with every stream sent through k_inflate_par first (a workgroup per stream;
+    what it does not finish -- every error case -- is decoded again by k_inflate)."""
+    if request.param == "workgroup":
+        monkeypatch.setenv("FLATE_HIP_INFLATE_PAR", "1")
+    else:
+        monkeypatch.delenv("FLATE_HIP_INFLATE_PAR", raising=False)
+    return request.param
+
+
 def test_reference_vectors():
     eng = engine()
     outs, st, used = eng.decompress_many([STORED, FIXED, DYN], 0)
@@ -103,6 +115,76 @@ def test_gpu_compress_then_gpu_inflate():
         assert st == [0] * len(chunks)
         outs, st, _ = eng.decompress_many(comp, container, caps=[65536] * len(chunks))
         assert st == [0] * len(chunks) and b"".join(outs) == data
+
+
+def _long_streams():
+    from flate_amd import synth
+    rng = np.random.default_rng(77)
+    text = synth.text(synth.SEED_TEXT + 5, 3 << 20).tobytes()
+    sil = synth.silesia_like(synth.SEED_SILESIA, 2 << 20).tobytes()
+    cases = []
+
+    def z(name, data, level=6, strategy=pyzlib.Z_DEFAULT_STRATEGY):
+        for container, wbits in ((0, -15), (1, 31), (2, 15)):
+            co = pyzlib.compressobj(level, pyzlib.DEFLATED, wbits, 9, strategy)
+            cases.append((name, container, data, co.compress(data) + co.flush()))
+
+    z("text-l6", text[:1 << 20])
+    z("text-l1", text[1 << 20:(1 << 20) + 700001], 1)
+    z("text-l9", text[2 << 20:(2 << 20) + 333333], 9)
+    z("mix", sil[:1500000])
+    z("random", rng.integers(0, 256, 300000, dtype=np.uint8).tobytes())
+    z("huffman-only", text[:400000], 6, pyzlib.Z_HUFFMAN_ONLY)
+    z("rle", text[:400000], 6, pyzlib.Z_RLE)
+    z("fixed", text[:150000], 6, pyzlib.Z_FIXED)
+    z("zeros", bytes(3 << 20))
+    z("period-2", b"ab" * 400000, 9)
+    z("period-7", b"abcdefg" * 90000, 9)
+    z("sparse", bytes(np.where(rng.random(500000) < 0.01, rng.integers(1, 256, 500000), 0).astype(np.uint8)))
+    return cases
+
+
+def test_long_streams(inflate_path):
+    """Streams long enough for k_inflate_par by the library's own rule (zlib-made: other block sizes and tree
+    shapes than the reference's encoder, fixed and stored blocks, runs), all containers; bytes and consumed
+    counts; then the same streams damaged, against the oracle's status names."""
+    eng = engine()
+    cases = _long_streams()
+    for container in (0, 1, 2):
+        grp = [c for c in cases if c[1] == container]
+        outs, st, used = eng.decompress_many([c[3] for c in grp], container, caps=[len(c[2]) + 8 for c in grp])
+        for c, o, s_, u in zip(grp, outs, st, used):
+            assert s_ == 0 and o == c[2] and u == len(c[3]), (c[0], container, s_, len(o), u)
+    # the library's own long streams (one stream per input, levels 6 and huffman-only)
+    data = cases[0][2]
+    for mode in (6, 1):
+        comp, st = eng.compress_many([data, data[:500000]], 1, mode)
+        assert st == [0, 0]
+        outs, st, _ = eng.decompress_many(comp, 1, caps=[len(data) + 8] * 2)
+        assert st == [0, 0] and outs == [data, data[:500000]]
+    # damaged long streams: same status name as the oracle (= the reference's error), same bytes when it decodes
+    rng = np.random.default_rng(78)
+    muts = []
+    for name, container, data, comp in cases:
+        if name not in ("text-l9", "fixed", "period-7", "random") or len(comp) < 100:
+            continue
+        m = bytearray(comp)
+        muts.append((container, bytes(m[:len(m) // 2]), len(data)))
+        m2 = bytearray(comp)
+        m2[int(rng.integers(len(m2) // 2, len(m2)))] ^= 0x10
+        muts.append((container, bytes(m2), len(data)))
+        m3 = bytearray(comp)
+        m3[-1] ^= 0xFF
+        muts.append((container, bytes(m3), len(data)))
+        muts.append((container, comp + b"trailing bytes", len(data)))
+    for container in (0, 1, 2):
+        grp = [m for m in muts if m[0] == container]
+        outs, st, used = eng.decompress_many([m[1] for m in grp], container, caps=[m[2] + 8 for m in grp])
+        for m, o, s_, u in zip(grp, outs, st, used):
+            name, want, wused = O.decompress(m[1], container, 0, cap=m[2] + 8)
+            assert O.STATUS[s_] == name, (container, len(m[1]), O.STATUS[s_], name)
+            if name == "Ok":
+                assert o == want and u == wused
 
 
 def _mutants(seed, n_per_base=120):
