@@ -94,8 +94,6 @@ struct fp_shared {
     uint32_t tok[FP_WAVES][FP_TOK_CAP];
     uint32_t bitmap[FP_WAVES][FP_WBITS / 32];
     uint8_t tb[FP_WAVES][FP_JOIN_BITS];    // per bit offset of the first 512 bits: bits of the token that would start there (255 = terminator)
-    uint16_t join[FP_WAVES][FP_ENTRIES];   // entry bit -> join position | FP_JTERM
-    uint8_t join_n[FP_WAVES][FP_ENTRIES];  // ... and the tokens before it
     uint32_t fixtok[FP_WAVES][FP_MAX_FIX];
     uint16_t fixpos[FP_WAVES][FP_MAX_FIX];
     uint8_t ring[FP_RING];
@@ -146,72 +144,79 @@ __device__ __forceinline__ int fp_find_long(const FL_LDS H* d, const FL_LDS fp_l
     return 0;
 }
 
+// Table entries of this kernel (converted from k_inflate's after every block header):
+//   literal / length: code bits | extra bits << 4 | value << 8 (byte, or base length) | EOB << 30 | length << 31
+//   distance:         code bits | extra bits << 4 | base distance << 8
+//   bit 29: not a valid symbol (286, 287 / 30, 31); 0: the code is longer than the table
+#define FP_E_BAD (1u << 29)
+#define FP_E_EOB (1u << 30)
+#define FP_E_LEN (1u << 31)
+__device__ __forceinline__ uint32_t fp_lit_entry(uint32_t sym, uint32_t cb) {
+    if (sym < 256) return cb | (sym << 8);
+    if (sym == 256) return cb | FP_E_EOB;
+    if (sym > 285) return cb | FP_E_BAD;
+    return cb | (fl_len_extra_bits(sym - 257) << 4) | ((fl_len_base_scaled(sym - 257) + 3) << 8) | FP_E_LEN;
+}
+__device__ __forceinline__ uint32_t fp_dst_entry(uint32_t sym, uint32_t cb) {
+    if (sym > 29) return cb | FP_E_BAD;
+    return cb | (fl_dist_extra_bits(sym) << 4) | ((fl_dist_base_scaled(sym) + 1) << 8);
+}
+// k_inflate's entry (symbol | code_bits << 9 | ...) -> this kernel's
+__device__ __noinline__ void fp_convert_luts(FL_LDS fl_inflate_ws* ws, uint32_t lane) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (uint32_t i = lane; i < (1u << FL_INF_LIT_BITS); i += 64) {
+        const uint32_t e = ws->lit_lut[i];
+        uint32_t v = 0;
+        if (e != 0) v = fp_lit_entry(e & 511, (e >> 9) & 15);
+        ws->lit_lut[i] = v;
+    }
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (uint32_t i = lane; i < (1u << FL_INF_DST_BITS); i += 64) {
+        const uint32_t e = ws->dst_lut[i];
+        uint32_t v = 0;
+        if (e != 0) v = fp_dst_entry(e & 511, (e >> 9) & 15);
+        ws->dst_lut[i] = v;
+    }
+    fl_wave_lds_sync();
+}
+
 // The token that would start at a bit offset whose next 64 stream bits are hi:lo.
-// bits = its length in bits (terminators: the code's bits), pay = the token.
+// bits = its length in bits (terminators: the code's bits), pay = the token.  Straight-line for the
+// common case; codes longer than the tables take fp_find_long (whole wave, when any lane needs it).
 __device__ __forceinline__ void fp_decode_at(const FL_LDS fp_shared* sh, uint32_t lo, uint32_t hi, uint32_t& bits,
                                              uint32_t& pay) {
     const FL_LDS fl_inflate_ws* ws = &sh->ws;
     uint32_t le = ws->lit_lut[lo & ((1u << FL_INF_LIT_BITS) - 1)];
-    if (le == 0) {
-        uint32_t sym, cb;
-        if (fp_find_long<FL_INF_LIT_BITS>(&ws->lit, &sh->lit_long, lo & 0x7fffu, sym, cb)) {
-            bits = 0;
-            pay = FP_TOK_TERM(FP_X_BAIL, 0);
-            return;
+    FP_CNT(61, 1);
+    if (__any(le == 0)) {
+        FP_CNT(62, 1);
+        if (le == 0) {
+            uint32_t sym, cb;
+            le = fp_find_long<FL_INF_LIT_BITS>(&ws->lit, &sh->lit_long, lo & 0x7fffu, sym, cb) ? FP_E_BAD : fp_lit_entry(sym, cb);
         }
-        uint32_t eb, val;
-        if (sym < 256) {
-            eb = 0;
-            val = sym;
-        } else if (sym == 256) {
-            eb = 0;
-            val = 0;
-        } else {
-            eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
-            val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
-        }
-        le = sym | (cb << 9) | (eb << 13) | (val << 17);
     }
-    const uint32_t sym = le & 511, cb = (le >> 9) & 15, eb = (le >> 13) & 15, val = le >> 17;
-    if (eb == 15) {
-        bits = 0;
-        pay = FP_TOK_TERM(FP_X_BAIL, 0);
-        return;
-    }
-    if (sym < 256) {
-        bits = cb;
-        pay = val;
-        return;
-    }
-    if (sym == 256) {
-        bits = cb;
-        pay = FP_TOK_TERM(FP_X_EOB, cb);
-        return;
-    }
-    const uint32_t length = val + ((lo >> cb) & ((1u << eb) - 1));
+    const uint32_t cb = le & 15, eb = (le >> 4) & 15, val = (le >> 8) & 0x1ff;
+    const uint32_t length = val + ((lo >> cb) & ((1u << eb) - 1u));
     const uint32_t lb = cb + eb;  // <= 20
-    const uint32_t dw = (uint32_t)((((uint64_t)hi << 32) | lo) >> lb);
+    const uint32_t dw = lb ? ((lo >> lb) | (hi << (32 - lb))) : lo;  // lb <= 20
     uint32_t de = ws->dst_lut[dw & ((1u << FL_INF_DST_BITS) - 1)];
-    if (de == 0) {
-        uint32_t dsym, dcb;
-        if (fp_find_long<FL_INF_DST_BITS>(&ws->dst, &sh->dst_long, dw & 0x7fffu, dsym, dcb)) {
-            bits = 0;
-            pay = FP_TOK_TERM(FP_X_BAIL, 0);
-            return;
+    const bool is_len = (le >> 31) != 0;
+    if (__any(is_len && de == 0)) {
+        FP_CNT(63, 1);
+        if (is_len && de == 0) {
+            uint32_t dsym, dcb;
+            de = fp_find_long<FL_INF_DST_BITS>(&ws->dst, &sh->dst_long, dw & 0x7fffu, dsym, dcb) ? FP_E_BAD : fp_dst_entry(dsym, dcb);
         }
-        const uint32_t deb = dsym <= 29 ? fl_dist_extra_bits(dsym) : 15u;
-        const uint32_t dval = dsym <= 29 ? fl_dist_base_scaled(dsym) + 1 : 0u;
-        de = dsym | (dcb << 9) | (deb << 13) | (dval << 17);
     }
-    const uint32_t dcb = (de >> 9) & 15, deb = (de >> 13) & 15, dval = de >> 17;
-    if (deb == 15) {
+    const uint32_t dcb = de & 15, deb = (de >> 4) & 15, dval = (de >> 8) & 0xffff;
+    const uint32_t distance = dval + ((dw >> dcb) & ((1u << deb) - 1u));
+    const bool bad = (le & FP_E_BAD) || (is_len && (de & FP_E_BAD));
+    bits = is_len ? lb + dcb + deb : cb;  // <= 48
+    pay = is_len ? FP_TOK_MATCH(length, distance) : ((le & FP_E_EOB) ? FP_TOK_TERM(FP_X_EOB, cb) : val);
+    if (bad) {
         bits = 0;
         pay = FP_TOK_TERM(FP_X_BAIL, 0);
-        return;
     }
-    const uint32_t distance = dval + ((dw >> dcb) & ((1u << deb) - 1));
-    bits = lb + dcb + deb;  // <= 48
-    pay = FP_TOK_MATCH(length, distance);
 }
 
 // the 64 stream bits that start at window bit `bp`
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 if (!rc) {
                     fp_long_build(&ws->lit, &sh->lit_long, lane);
                     fp_long_build(&ws->dst, &sh->dst_long, lane);
+                    fp_convert_luts(ws, lane);
                 }
             } else if (!rc && btype == 1) {
                 // fixed codes (RFC 1951 3.2.6, inflate.zig:104-121) through the same tables: lengths 8/9/7/8
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                     fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
                     fp_long_build(&ws->lit, &sh->lit_long, lane);
                     fp_long_build(&ws->dst, &sh->dst_long, lane);
+                    fp_convert_luts(ws, lane);
                 }
             } else if (!rc && btype == 0) {
                 fl_br_align(r);
@@ -402,18 +409,17 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                             sh->tb[wave][64 * s + lane] = nextv == 255u ? (uint8_t)255 : (uint8_t)bits;
                             s_tab = s + 1;
                         }
-                        // scalar walk over the real starts of this sub-window
+                        // scalar walk over the real starts of this sub-window (kept to a handful of scalar
+                        // instructions per token: the one scalar unit of the CU serves all 16 waves)
                         uint64_t mask = 0;
-                        uint32_t p = carry, term = 0;
-                        do {
+                        uint32_t p = carry, nx;
+                        for (;;) {
                             mask |= 1ull << p;
-                            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nextv, (int)p);
-                            if (n == 255u) {
-                                term = p + 1;
-                                break;
-                            }
-                            p = n;
-                        } while (p < 64);
+                            nx = (uint32_t)__builtin_amdgcn_readlane((int)nextv, (int)p);
+                            if (nx >= 64) break;
+                            p = nx;
+                        }
+                        const uint32_t term = nx == 255u ? p + 1 : 0u;  // the token at p ends the wave's path
                         if (lane == 0) {
                             sh->bitmap[wave][2 * s] = (uint32_t)mask;
                             sh->bitmap[wave][2 * s + 1] = (uint32_t)(mask >> 32);
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                             xpos = 64 * s + (term - 1) + (xkind == FP_X_EOB ? (tp & 0xff) : 0u);
                             break;
                         }
-                        carry = p - 64;
+                        carry = nx - 64;
                     }
                     if (xkind == FP_X_NORMAL) xpos = wbits + carry;
                     for (uint32_t s = s_tab; s < jbits / 64; s++) {  // (the wave's own path ended early)
@@ -442,34 +448,14 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         sh->w_xpos[wave] = xpos;
                     }
                     fl_lds_order();
-                    // (3) where would a path entering at bit c join this wave's path?
-                    if (lane < FP_ENTRIES) {
-                        uint32_t p = lane, nfix = 0, res = FP_NOJOIN;
-                        for (uint32_t it = 0; it <= FP_MAX_FIX; it++) {
-                            if (p >= jbits) break;
-                            if ((sh->bitmap[wave][p >> 5] >> (p & 31)) & 1) {
-                                res = p;
-                                break;
-                            }
-                            const uint32_t t = sh->tb[wave][p];
-                            if (t == 255u) {
-                                res = p | FP_JTERM;
-                                break;
-                            }
-                            if (nfix == FP_MAX_FIX) break;
-                            p += t;
-                            nfix++;
-                        }
-                        sh->join[wave][lane] = (uint16_t)res;
-                        sh->join_n[wave][lane] = (uint8_t)nfix;
-                    }
+                    FP_T(41);
                 }
                 __syncthreads();
                 FP_T(35);
                 // (4) stitch.  Once a path has joined a wave's own path it leaves the wave where that one does,
                 // whatever its entry bit was: every wave can judge its own entry, the window ends at the first
                 // wave that ends it.
-                if (lane == 0) {
+                {
                     const uint32_t w = wave;
                     uint32_t fv = 0, nfix = 0, e = 0, endk = FP_X_NORMAL, endp = 0;  // endk != NORMAL: the window ends in this wave
                     bool enter = true;  // false: the window ends before this wave's tokens
@@ -480,28 +466,47 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                             enter = false;  // (an earlier wave ends the window anyway)
                             endk = FP_X_CUT;
                         } else {
-                            e = sh->w_xpos[w - 1] - wbits;
-                            const uint32_t j = e < FP_ENTRIES ? sh->join[w][e] : FP_NOJOIN;
-                            if (j == FP_NOJOIN) {  // the window ends where this wave's range is entered
+                            // follow the entering path through the per-offset token lengths until it meets the
+                            // wave's own path (wave-uniform; its tokens are decoded in step 5)
+                            e = fl_uni(sh->w_xpos[w - 1]) - wbits;
+                            uint32_t p = e;
+                            int how = 0;  // 1 joined, 2 ended by a terminator, 0 no join
+                            for (;;) {
+                                if (p >= jbits) break;
+                                if ((fl_uni(sh->bitmap[w][p >> 5]) >> (p & 31)) & 1) {
+                                    how = 1;
+                                    break;
+                                }
+                                const uint32_t t = fl_uni(sh->tb[w][p]);
+                                if (t == 255u) {
+                                    how = 2;
+                                    break;
+                                }
+                                if (nfix == FP_MAX_FIX) break;
+                                if (lane == 0) sh->fixpos[w][nfix] = (uint16_t)p;
+                                p += t;
+                                nfix++;
+                            }
+                            if (how == 0) {  // the window ends where this wave's range is entered
                                 enter = false;
                                 endk = FP_X_CUT;
                                 endp = e;
+                                nfix = 0;
                                 FP_CNT(57, 1);
+                            } else if (how == 2) {  // the entering path ends before it joins: EOB or a bad code
+                                uint32_t lo, hi, tbits, tp;
+                                fp_fetch64(sh->stage, bit0 + w * wbits + p, lo, hi);
+                                fp_decode_at(sh, lo, hi, tbits, tp);
+                                tp = fl_uni(tp);
+                                xk = (tp >> 8) & 0xff;
+                                xp = p + (xk == FP_X_EOB ? (tp & 0xff) : 0u);
+                                fv = ntok;
                             } else {
-                                const uint32_t jp = j & 0x7ff;
-                                nfix = sh->join_n[w][e];
-                                if (j & FP_JTERM) {  // the entering path ends before it joins: EOB or a bad code
-                                    uint32_t lo, hi, tbits, tp;
-                                    fp_fetch64(sh->stage, bit0 + w * wbits + jp, lo, hi);
-                                    fp_decode_at(sh, lo, hi, tbits, tp);
-                                    xk = (tp >> 8) & 0xff;
-                                    xp = jp + (xk == FP_X_EOB ? (tp & 0xff) : 0u);
-                                    fv = ntok;
-                                } else {
-                                    for (uint32_t k = 0; k < (jp >> 5); k++) fv += (uint32_t)__popc(sh->bitmap[w][k]);
-                                    fv += (uint32_t)__popc(sh->bitmap[w][jp >> 5] & ((1u << (jp & 31)) - 1u));
-                                    if (fv > ntok) fv = ntok;  // a join at the wave's terminator: no own tokens
-                                }
+                                uint32_t cnt = 0;
+                                if (lane < (p >> 5)) cnt = (uint32_t)__popc(sh->bitmap[w][lane]);
+                                if (lane == (p >> 5)) cnt = (uint32_t)__popc(sh->bitmap[w][lane] & ((1u << (p & 31)) - 1u));
+                                fv = fl_wave_sum(cnt);
+                                if (fv > ntok) fv = ntok;  // a join at the wave's terminator: no own tokens
                             }
                         }
                     }
@@ -509,13 +514,15 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         endk = xk;
                         endp = xp;
                     }
-                    sh->w_valid[w] = enter ? 1u : 0u;
-                    sh->w_entry[w] = e;
-                    sh->w_fv[w] = fv;
-                    sh->w_nfix[w] = nfix;
-                    sh->w_nown[w] = ntok - fv;
-                    sh->w_total[w] = endk;   // (borrowed until the layout step)
-                    sh->w_base[w] = endp;
+                    if (lane == 0) {
+                        sh->w_valid[w] = enter ? 1u : 0u;
+                        sh->w_entry[w] = e;
+                        sh->w_fv[w] = fv;
+                        sh->w_nfix[w] = nfix;
+                        sh->w_nown[w] = ntok - fv;
+                        sh->w_total[w] = endk;  // (borrowed until the layout step)
+                        sh->w_base[w] = endp;
+                    }
                 }
                 __syncthreads();
                 if (tid == 0) {
@@ -544,21 +551,11 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 // (5) the tokens of the entering paths; output bytes per wave
                 if (wave < nvalid) {
                     const uint32_t nfix = sh->w_nfix[wave];
-                    uint32_t p = sh->w_entry[wave];
-                    for (uint32_t k0 = 0; k0 < nfix; k0 += 64) {
-                        // positions of the path's tokens (a wave-uniform walk), then their tokens, one per lane
-                        uint32_t myp = 0;
-                        for (uint32_t k = k0; k < min(nfix, k0 + 64); k++) {
-                            if (lane == k - k0) myp = p;
-                            p += sh->tb[wave][p];
-                        }
-                        if (k0 + lane < nfix) {
-                            uint32_t lo, hi, tbits, tp;
-                            fp_fetch64(sh->stage, bit0 + wave * wbits + myp, lo, hi);
-                            fp_decode_at(sh, lo, hi, tbits, tp);
-                            sh->fixtok[wave][k0 + lane] = tp;
-                            sh->fixpos[wave][k0 + lane] = (uint16_t)myp;
-                        }
+                    for (uint32_t k = lane; k < nfix; k += 64) {
+                        uint32_t lo, hi, tbits, tp;
+                        fp_fetch64(sh->stage, bit0 + wave * wbits + sh->fixpos[wave][k], lo, hi);
+                        fp_decode_at(sh, lo, hi, tbits, tp);
+                        sh->fixtok[wave][k] = tp;
                     }
                     fl_lds_order();
                     const uint32_t nown = sh->w_nown[wave], fv = sh->w_fv[wave], n = nfix + nown;
