@@ -49,6 +49,7 @@ struct fl_inflate_ws {
     uint8_t lens[320];
     uint8_t cl_lens[20];
     uint16_t offs[18];
+    uint16_t cl_lut[128];  // code-length code: symbol | code bits << 8 | 0x8000 by the next 7 stream bits, 0 = no code
 };
 
 #define FL_INF_INRING 1024u  // compressed bytes staged in LDS (two 512-byte halves)
@@ -156,24 +157,36 @@ __device__ __forceinline__ uint64_t fl_br_consumed(const fl_bitr& r) {
     return (pos + 7) >> 3;
 }
 
-// huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order).  Runs on all
-// lanes redundantly except the LDS writes (lane 0).
+// huffman_decoder.zig:71-153 (checkCompletnes + canonical symbol order), spread over the wave: lane l
+// holds symbols l, l + 64, ...; per code length one ballot per 64 symbols counts the codes and ranks
+// the symbols (a symbol's place among the codes of its length = the symbols of that length before it).
 template <class H>
 __device__ __forceinline__ int fl_hdec_generate(FL_LDS H* d, const FL_LDS uint8_t* lens, FL_LDS uint16_t* offs,
                                                 int n, int alphabet, int max_code_bits, uint32_t lane) {
     if (alphabet == 286 && lens[256] == 0) return 10;  // MissingEndOfBlockCode
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t cnt[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cnt[i] = 0;
-    int mx = 0;
-    for (int i = 0; i < n; i++) {
-        const int l = lens[i];
-        if (l == 0) continue;
-        if (l > mx) mx = l;
+    uint32_t ml[5], mr[5];  // this lane's symbols: length, rank among the symbols of that length
 #pragma unroll
-        for (int k = 1; k < 16; k++)
-            if (k == l) cnt[k]++;
+    for (int c = 0; c < 5; c++) {
+        const int i = c * 64 + (int)lane;
+        ml[c] = (c * 64 < n && i < n) ? lens[i] : 0u;
+        mr[c] = 0;
+        if (c * 64 < n) {
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                const uint64_t m = __ballot(ml[c] == (uint32_t)k);
+                if (ml[c] == (uint32_t)k) mr[c] = cnt[k] + (uint32_t)__popcll(m & lt_mask);
+                cnt[k] += (uint32_t)__popcll(m);
+            }
+        }
     }
+    int mx = 0;
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        if (cnt[k]) mx = k;
     if (mx != 0) {
         int left = 1;
         for (int len = 1; len <= max_code_bits; len++) {
@@ -193,17 +206,18 @@ __device__ __forceinline__ int fl_hdec_generate(FL_LDS H* d, const FL_LDS uint8_
     if (lane == 0) {
         offs[1] = 0;
         d->count[0] = 0;
-        for (int len = 1; len < 16; len++) {
-            uint32_t cl = 0;
+        uint32_t run = 0;
 #pragma unroll
-            for (int k = 1; k < 16; k++)
-                if (k == len) cl = cnt[k];
-            d->count[len] = (uint16_t)cl;
-            offs[len + 1] = (uint16_t)(offs[len] + cl);
+        for (int len = 1; len < 16; len++) {
+            d->count[len] = (uint16_t)cnt[len];
+            offs[len] = (uint16_t)run;
+            run += cnt[len];
         }
-        for (int i = 0; i < n; i++)
-            if (lens[i] != 0) d->symbol[offs[lens[i]]++] = (uint16_t)i;
     }
+    fl_wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        if (ml[c] != 0) d->symbol[offs[ml[c]] + mr[c]] = (uint16_t)(c * 64 + (int)lane);
     fl_wave_lds_sync();
     return 0;
 }
@@ -468,7 +482,12 @@ __device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws
     while (pos < want) {
         FL_TRY(fl_br_fill(r, 7));
         uint32_t sym, cb;
-        FL_TRY(fl_hdec_find(&ws->cl, fl_br_peek(r, 7), 7, sym, cb));
+        {
+            const uint32_t e = ws->cl_lut[fl_br_peek(r, 7)];
+            if (e == 0) return 7;  // InvalidCode (huffman_decoder.zig:156-175)
+            sym = e & 0xff;
+            cb = (e >> 8) & 15;
+        }
         FL_TRY(fl_br_shift(r, cb));
         if (boundary && sym == 16 && pos == boundary) crossed = true;
         if (pos >= lens_len) return 14;
@@ -519,6 +538,11 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
     }
     fl_wave_lds_sync();
     FL_TRY(fl_hdec_generate(&ws->cl, ws->cl_lens, ws->offs, 19, 19, 7, lane));
+    for (uint32_t i = lane; i < 128; i += 64) {  // every 7-bit window decoded once, by the same walk
+        uint32_t sy, cb;
+        ws->cl_lut[i] = fl_hdec_find(&ws->cl, i, 7, sy, cb) == 0 ? (uint16_t)(sy | (cb << 8) | 0x8000u) : (uint16_t)0;
+    }
+    fl_wave_lds_sync();
     bool crossed = false;
     int rc;
     if (flags & 1) {

@@ -101,12 +101,12 @@ struct fp_shared {
     // per wave
     uint32_t w_ntok[FP_WAVES], w_xkind[FP_WAVES], w_xpos[FP_WAVES];
     uint32_t w_valid[FP_WAVES], w_entry[FP_WAVES], w_fv[FP_WAVES], w_nfix[FP_WAVES], w_nown[FP_WAVES];
-    uint32_t w_total[FP_WAVES], w_base[FP_WAVES];
+    uint32_t w_total[FP_WAVES], w_base[FP_WAVES], w_endk[FP_WAVES], w_endp[FP_WAVES];
     // stream / round state
     uint64_t bitpos, wp;
     fp_long lit_long, dst_long;
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
-    uint32_t redo, blk_done, blk_final, blk_type, unresolved;
+    uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
     uint32_t st_len;  // stored block: bytes
     uint32_t wbits;   // bits per wave and round
     uint32_t crc, adA, adB;
@@ -520,68 +520,65 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         sh->w_fv[w] = fv;
                         sh->w_nfix[w] = nfix;
                         sh->w_nown[w] = ntok - fv;
-                        sh->w_total[w] = endk;  // (borrowed until the layout step)
-                        sh->w_base[w] = endp;
+                        sh->w_endk[w] = endk;
+                        sh->w_endp[w] = endp;
+                    }
+                    // (5) the tokens of the entering path; output bytes of this wave's part of the window
+                    // (for every wave: which ones count is known after the barrier)
+                    if (enter) {
+                        for (uint32_t k = lane; k < nfix; k += 64) {
+                            uint32_t lo, hi, tbits, tp;
+                            fp_fetch64(sh->stage, bit0 + wave * wbits + sh->fixpos[wave][k], lo, hi);
+                            fp_decode_at(sh, lo, hi, tbits, tp);
+                            sh->fixtok[wave][k] = tp;
+                        }
+                        fl_lds_order();
+                        const uint32_t nown = ntok - fv, n = nfix + nown;
+                        uint32_t sum = 0;
+                        for (uint32_t k = lane; k < n; k += 64)
+                            sum += fp_tok_len(k < nfix ? sh->fixtok[wave][k] : sh->tok[wave][fv + k - nfix]);
+                        sum = fl_wave_sum(sum);
+                        if (lane == 0) sh->w_total[wave] = sum;
                     }
                 }
                 __syncthreads();
+                FP_T(36);
                 if (tid == 0) {
                     uint32_t nvalid = FP_WAVES, kind = FP_X_NORMAL, next = FP_WAVES * wbits + (sh->w_xpos[FP_WAVES - 1] - wbits);
                     for (uint32_t w = 0; w < FP_WAVES; w++) {
-                        const uint32_t endk = sh->w_total[w];
+                        const uint32_t endk = sh->w_endk[w];
                         if (endk != FP_X_NORMAL) {
                             nvalid = w + (sh->w_valid[w] ? 1u : 0u);
                             kind = endk;
-                            next = w * wbits + sh->w_base[w];
+                            next = w * wbits + sh->w_endp[w];
                             break;
                         }
                     }
                     FP_CNT(52 + kind, 1);
-                    sh->r_nvalid = nvalid;
+                    FP_CNT(49, nvalid);
                     sh->r_kind = kind;
                     sh->r_next = next;  // window bit where the next round / block starts
                     sh->r_cutwave = 0xffffffffu;
                     if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
-                }
-                __syncthreads();
-                FP_T(36);
-                if (sh->redo) break;
-                const uint32_t nvalid = sh->r_nvalid;
-                FP_CNT(49, nvalid);
-                // (5) the tokens of the entering paths; output bytes per wave
-                if (wave < nvalid) {
-                    const uint32_t nfix = sh->w_nfix[wave];
-                    for (uint32_t k = lane; k < nfix; k += 64) {
-                        uint32_t lo, hi, tbits, tp;
-                        fp_fetch64(sh->stage, bit0 + wave * wbits + sh->fixpos[wave][k], lo, hi);
-                        fp_decode_at(sh, lo, hi, tbits, tp);
-                        sh->fixtok[wave][k] = tp;
-                    }
-                    fl_lds_order();
-                    const uint32_t nown = sh->w_nown[wave], fv = sh->w_fv[wave], n = nfix + nown;
-                    uint32_t sum = 0;
-                    for (uint32_t k = lane; k < n; k += 64)
-                        sum += fp_tok_len(k < nfix ? sh->fixtok[wave][k] : sh->tok[wave][fv + k - nfix]);
-                    sum = fl_wave_sum(sum);
-                    if (lane == 0) sh->w_total[wave] = sum;
-                }
-                __syncthreads();
-                if (tid == 0) {
                     uint32_t run = 0;
                     for (uint32_t w = 0; w < nvalid; w++) {
                         sh->w_base[w] = run;
-                        if (run + sh->w_total[w] > FP_OUT_CAP && sh->r_cutwave == 0xffffffffu) {
+                        if (run + sh->w_total[w] > FP_OUT_CAP) {
                             sh->r_cutwave = w;  // the window is cut at a token of this wave
                             sh->r_cutbudget = FP_OUT_CAP - run;
-                            sh->r_nvalid = w + 1;
+                            nvalid = w + 1;
                             break;
                         }
                         run += sh->w_total[w];
                     }
+                    sh->r_nvalid = nvalid;
                     sh->r_nout = run;  // (the cut wave adds what fits)
-                    sh->unresolved = 0;
+                    sh->unresolved[0] = 0;
+                    sh->unresolved[1] = 0;
+                    sh->unresolved[2] = 0;
                 }
                 __syncthreads();
+                if (sh->redo) break;
                 FP_T(37);
                 const uint32_t nv2 = sh->r_nvalid, cutwave = sh->r_cutwave;
                 // (6) fill: literals and copies from the history are final, the rest points at its source
@@ -671,7 +668,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                     break;
                 }
                 // (7) resolve the copies inside the window by pointer jumping over byte positions
-                for (;;) {
+                for (uint32_t rr = 0;;) {
                     bool mine = false;
                     for (uint32_t j = tid; j < nout; j += FP_THREADS) {
                         const uint32_t v = sh->ptr[j];
@@ -695,13 +692,13 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         }
                     }
                     FP_CNT(51, 1);
-                    if (__any(mine) && lane == 0) sh->unresolved = 1;
+                    // round r's flag is read after this barrier by everyone and cleared two rounds later,
+                    // before the barrier of round r + 2: every wave has read it by then
+                    if (__any(mine) && lane == 0) sh->unresolved[rr] = 1;
+                    if (tid == 0) sh->unresolved[rr == 2 ? 0 : rr + 1] = 0;
                     __syncthreads();
-                    const uint32_t again = sh->unresolved;
-                    __syncthreads();
-                    if (!again) break;
-                    if (tid == 0) sh->unresolved = 0;
-                    __syncthreads();
+                    if (!sh->unresolved[rr]) break;
+                    rr = rr == 2 ? 0 : rr + 1;
                 }
                 FP_T(39);
                 // (8) the window's bytes leave
