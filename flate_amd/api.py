@@ -207,28 +207,58 @@ class _Compressor:
 
 
 class _Decompressor:
-    """Inflate (inflate.zig:43-355) seen from the caller."""
+    """Inflate (inflate.zig:43-355) seen from the caller.  The reader is consumed as far as the current stream
+    needs it, in steps that double: a decode that runs out of input (EndOfStream) while the reader still has
+    bytes is repeated with twice as much -- the input read past the end of a stream stays buffered for reset()
+    (inflate.zig:301-309), and the GPU work is at most twice that of the final decode."""
 
     CHUNK = 65536  # the reference hands out at most its 64 KiB ring per next() (inflate.zig:322-336)
+    FIRST_READ = 1 << 16
 
     def __init__(self, container, reader, engine=None, flags=0):
         self._container, self._flags = container, flags
         self._eng = engine or default_engine()
-        self._in = _read_all(reader)
-        self._pos = 0      # start of the current stream in the input
+        self._set_input(reader)
         self._out = None   # decoded bytes of the current stream
         self._rp = 0
         self._ended = False
 
+    def _set_input(self, reader):
+        if isinstance(reader, (bytes, bytearray, memoryview)):
+            reader = io.BytesIO(bytes(reader))
+        self._rd = reader
+        self._in = bytearray()  # bytes read from the reader and not yet given up
+        self._pos = 0           # start of the current stream in _in
+        self._eof = False
+
+    def _fill(self, want):
+        """Have `want` bytes of the current stream buffered, or the reader at its end."""
+        while not self._eof and len(self._in) - self._pos < want:
+            got = self._rd.read(want - (len(self._in) - self._pos))
+            if not got:
+                self._eof = True
+                break
+            self._in += got
+
     def _decode(self):
         if self._out is not None:
             return
-        data = self._in[self._pos:]
-        cap = max(1 << 16, len(data) * 64)
+        if self._pos > (1 << 20):  # drop what earlier streams consumed
+            del self._in[:self._pos]
+            self._pos = 0
+        want = self.FIRST_READ
         while True:
-            outs, st, used = self._eng.decompress_many([data], self._container, self._flags, caps=[cap])
-            if st[0] == 100 and cap < (1 << 34):
-                cap *= 8
+            self._fill(want)
+            data = bytes(self._in[self._pos:])
+            cap = max(1 << 16, len(data) * 64)
+            while True:
+                outs, st, used = self._eng.decompress_many([data], self._container, self._flags, caps=[cap])
+                if st[0] == 100 and cap < (1 << 34):
+                    cap *= 8
+                    continue
+                break
+            if st[0] == 1 and not self._eof:  # EndOfStream with input still to come: not an error yet
+                want = 2 * max(want, len(data))
                 continue
             break
         raise_for_status(st[0])
@@ -276,10 +306,12 @@ class _Decompressor:
     def more_input(self):
         """True when input is left after the stream just decoded (a further concatenated member)."""
         self._decode()
+        if self._pos + self._used >= len(self._in):
+            self._fill(self._used + 1)
         return self._pos + self._used < len(self._in)
 
     def set_reader(self, new_reader):  # inflate.zig:283-288
-        self._in, self._pos = _read_all(new_reader), 0
+        self._set_input(new_reader)
         self._out, self._rp, self._ended = None, 0, False
 
 

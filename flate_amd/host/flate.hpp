@@ -264,10 +264,13 @@ class CompressorImpl {
 };
 
 // Inflate (inflate.zig:43-355) seen from the caller
+// Inflate (inflate.zig:43-355) seen from the caller.  The reader is consumed as far as the current stream
+// needs it, in steps that double: a decode that runs out of input (EndOfStream) while the reader still has
+// bytes is repeated with twice as much; what was read past the end of a stream stays buffered for reset().
 template <class Reader>
 class DecompressorImpl {
    public:
-    DecompressorImpl(Reader& r, int container) : container_(container) { read_all(r, in_); }
+    DecompressorImpl(Reader& r, int container) : rd_(&r), container_(container) {}
     // next(): slices of at most 64 KiB, empty = end of stream (inflate.zig:315-336)
     std::pair<const uint8_t*, size_t> next() {
         decode();
@@ -303,15 +306,37 @@ class DecompressorImpl {
     }
 
    private:
+    void fill(size_t want) {  // `want` bytes of the current stream buffered, or the reader at its end
+        uint8_t tmp[65536];
+        while (!eof_ && in_.size() - pos_ < want) {
+            const size_t k = rd_->read(tmp, std::min(sizeof tmp, want - (in_.size() - pos_)));
+            if (k == 0) {
+                eof_ = true;
+                break;
+            }
+            in_.insert(in_.end(), tmp, tmp + k);
+        }
+    }
     void decode() {
         if (decoded_) return;
-        used_ = Engine::instance().decompress_one(in_.data() + pos_, in_.size() - pos_, container_, out_);
+        size_t want = 65536;
+        for (;;) {
+            fill(want);
+            try {
+                used_ = Engine::instance().decompress_one(in_.data() + pos_, in_.size() - pos_, container_, out_);
+                break;
+            } catch (const Error& e) {
+                if (e.status != 1 /* EndOfStream */ || eof_) throw;
+                want = 2 * std::max(want, in_.size() - pos_);  // input still to come: not an error yet
+            }
+        }
         decoded_ = true;
     }
+    Reader* rd_;
     int container_;
     std::vector<uint8_t> in_, out_;
     size_t pos_ = 0, used_ = 0, rp_ = 0;
-    bool decoded_ = false, ended_ = false;
+    bool decoded_ = false, ended_ = false, eof_ = false;
 };
 
 }  // namespace detail

@@ -51,6 +51,25 @@ int main() {
     auto dcp = zlib::decompressor(rr);
     uint8_t buf[64];
     CHECK(dcp.read(buf, sizeof buf) == plain.size() && memcmp(buf, plain.data(), plain.size()) == 0);
+    // the decompressor reads its reader as it goes (inflate.zig:283-353): two members, then 4 MiB of other bytes
+    {
+        std::vector<uint8_t> a(150000), b(90);
+        for (size_t i = 0; i < a.size(); i++) a[i] = (uint8_t)("stream one "[i % 11] + (i / 3000) % 5);
+        for (size_t i = 0; i < b.size(); i++) b[i] = (uint8_t)('a' + i % 7);
+        auto ca = run([](auto& r, auto& w) { gzip::compress(r, w); }, a);
+        auto cb = run([](auto& r, auto& w) { gzip::compress(r, w); }, b);
+        std::vector<uint8_t> blob(ca);
+        blob.insert(blob.end(), cb.begin(), cb.end());
+        blob.resize(blob.size() + (4u << 20), 0);
+        BufferReader br(blob.data(), blob.size());
+        auto d = gzip::decompressor(br);
+        VectorWriter w1, w2;
+        d.decompress(w1);
+        d.reset();
+        d.decompress(w2);
+        CHECK(w1.data == a && w2.data == b);
+        CHECK(br.pos < ca.size() + cb.size() + (1u << 20));
+    }
     auto h1 = run([](auto& r, auto& w) { flate::huffman::compress(r, w); }, plain);
     CHECK(run([](auto& r, auto& w) { flate::decompress(r, w); }, h1) == plain);
     // error names (flate.zig:267-295)

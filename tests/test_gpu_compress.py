@@ -199,6 +199,52 @@ def test_api_mirror_roundtrip():
         assert d.reader().read() == plain
 
 
+def test_decompressor_takes_from_the_reader_what_the_stream_needs():
+    """inflate.zig:283-353: a decompressor reads its reader as it goes.  Three gzip members followed by a lot of
+    unrelated bytes: every member decodes, reset() moves to the next one, and the reader is not drained."""
+    from flate_amd import gzip, synth
+
+    class CountingReader:
+        def __init__(self, data):
+            self.data, self.pos = data, 0
+
+        def read(self, n=-1):
+            if n is None or n < 0:
+                n = len(self.data) - self.pos
+            out = self.data[self.pos:self.pos + n]
+            self.pos += len(out)
+            return out
+
+    parts = [synth.text(synth.SEED_TEXT + 40 + i, n).tobytes() for i, n in enumerate((300000, 10, 70000))]
+    members = []
+    for part in parts:
+        c = io.BytesIO()
+        gzip.compress(io.BytesIO(part), c, gzip.Options())
+        members.append(c.getvalue())
+    blob = b"".join(members) + bytes(8 << 20)
+    rd = CountingReader(blob)
+    d = gzip.decompressor(rd)
+    got = []
+    for i in range(3):
+        pieces = []
+        while True:
+            buf = d.next()
+            if buf is None:
+                break
+            assert len(buf) <= 65536
+            pieces.append(buf)
+        got.append(b"".join(pieces))
+        if i < 2:
+            assert d.more_input()
+            d.reset()
+    assert got == parts
+    assert rd.pos < len(b"".join(members)) + (2 << 20)  # far from the 8 MiB that follow
+    # a truncated stream still is EndOfStream once the reader has nothing more
+    from flate_amd.api import EndOfStream
+    with pytest.raises(EndOfStream):
+        gzip.decompressor(CountingReader(members[0][:len(members[0]) // 2])).next()
+
+
 def test_chunk_passes_are_split_and_mixed_with_streams():
     # FLATE_HIP_MAX_PASS_CHUNKS bounds one chunk-path pass; short and long inputs alternate, so the
     # call becomes many passes of both kinds: same bytes as in one go
