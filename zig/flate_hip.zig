@@ -218,17 +218,36 @@ fn DecompressorImpl(comptime container: c_int, comptime ReaderType: type) type {
             if (self.out) |o| gpa.free(o.ptr[0..self.out_cap]);
             self.input.deinit();
         }
+        /// at least `want` bytes of the current stream buffered, or the reader at its end
+        fn fill(self: *Self, want: usize) !void {
+            var tmp: [65536]u8 = undefined;
+            while (!self.loaded and self.input.items.len - self.pos < want) {
+                const n = try self.rdr.read(&tmp);
+                if (n == 0) {
+                    self.loaded = true; // end of the reader
+                    break;
+                }
+                self.input.appendSlice(tmp[0..n]) catch return error.OutOfMemory;
+            }
+        }
+        /// The reader is consumed as far as the stream needs it, in doubling steps: EndOfStream while the
+        /// reader still has bytes means "read more and decode again" (inflate.zig:283-353 reads as it goes).
         fn decode(self: *Self) !void {
             if (self.out != null) return;
-            if (!self.loaded) {
-                var tmp: [65536]u8 = undefined;
-                while (true) {
-                    const n = try self.rdr.readAll(&tmp);
-                    self.input.appendSlice(tmp[0..n]) catch return error.OutOfMemory;
-                    if (n < tmp.len) break;
-                }
-                self.loaded = true;
+            var want: usize = 65536;
+            while (true) {
+                try self.fill(want);
+                self.decodeBuffered() catch |e| {
+                    if (e == error.EndOfStream and !self.loaded) {
+                        want = 2 * @max(want, self.input.items.len - self.pos);
+                        continue;
+                    }
+                    return e;
+                };
+                return;
             }
+        }
+        fn decodeBuffered(self: *Self) !void {
             const h = try engine();
             const data = self.input.items[self.pos..];
             var cap: usize = @max(@as(usize, 1) << 16, data.len * 8);
