@@ -158,7 +158,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
                                                               const fl_tile* __restrict__ tiles,
                                                               const uint32_t* __restrict__ fpts,
                                                               uint32_t* __restrict__ n_sorted,
-                                                              uint16_t* __restrict__ S) {
+                                                              uint16_t* __restrict__ S, uint32_t dbg) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t e = slice0 + (r + 4 + u) * 64 + lane;
             const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < Ms;
             ppn[u] = okn ? tmp[e] : 0;
-            a0n[u] = okn ? fl_gather_u32(src, ppn[u], N) : 0;
+            a0n[u] = okn ? ((dbg & 1024) ? ppn[u] * 0x01010101u : fl_gather_u32(src, ppn[u], N)) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t d = fl_hash_le(a0[u]) >> 8;
             const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-            if (valid) So[cnt2[wave][d] + rank] = (uint16_t)pp[u];
+            if (valid) So[(dbg & 512) ? e : cnt2[wave][d] + rank] = (uint16_t)pp[u];
             fl_lds_order();
             if (valid && rank == np - 1) cnt2[wave][d] += np;
             fl_lds_order();
