@@ -283,7 +283,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            if (prm.chain <= FL_M3_BACK && !(prm.dbg & (2 | 64 | 256)))  // levels 4..6: third generation
+            if (prm.chain <= FL_M3_BACK && (prm.dbg & 2048))  // rolling-buffer experiment (kernels_match3.h)
                 hipLaunchKernelGGL(k_lz_match3<true>, dim3(nt), dim3(FL_M3_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
             else if (!(prm.dbg & (2 | 64)))
@@ -505,11 +505,11 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
-                if (prm.chain <= FL_M3_BACK && !(prm.dbg & (2 | 64 | 256)))  // levels 4..6: third generation
+                if (prm.chain <= FL_M3_BACK && (prm.dbg & 2048))  // rolling-buffer experiment (kernels_match3.h)
                     hipLaunchKernelGGL(k_lz_match3<false>, dim3(nc), dim3(FL_M3_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
                                        (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
-                else if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (levels 7..9)
+                else if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
                     hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
                                        (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);

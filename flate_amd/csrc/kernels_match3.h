@@ -1,4 +1,9 @@
-// kernels_match3.h -- the match finder of levels 4..6 (chain <= 128), third generation.
+// kernels_match3.h -- match finder experiment (FLATE_HIP_DBG=2048, levels 4..6): k_lz_match with a rolling
+// LDS buffer instead of rebuilt tiles.  Bit-exact on the whole GPU suite, NOT the default: it issues
+// fewer instructions (PMC per 64 KiB of text: 825 k VALU / 64 k LDS against 884 k / 174 k) but its
+// buffers leave room for only 16 waves per CU instead of 32, and the window walks of the 8-byte
+// candidates (a third of the instructions, latency bound) then cost 9 ms instead of 4.5: 30.6 ms per
+// GiB against 25.9.  Kept for the measurements DESIGN.md 4 quotes.
 //
 // Reference path: Deflate.findMatch (deflate.zig:233-266) with SlidingWindow.match
 // (SlidingWindow.zig:81-104) over the hash chains of Lookup (Lookup.zig:12-84), for EVERY position:
@@ -7,14 +12,11 @@
 // Same decomposition as k_lz_match (kernels_lz.h): S = the positions sorted by (hash, position), the
 // chain candidates of a sorted entry are the entries just before it in its bucket, lane = entry,
 // loop = candidate number, candidates scored branch-free on their first 8 window bytes, the window
-// itself only meets the candidates that agree in all 8.  What changed is everything around the
-// candidate loop, which was half of the instructions of k_lz_match (PMC: 884 k VALU per 64 KiB of
-// text, 380 k of them in the loop):
+// itself only meets the candidates that agree in all 8.  What differs:
 //  * a wave STREAMS through its slice of the sorted array (8192 consecutive entries) and keeps
 //    the 8-byte prefixes and positions of the last 128 entries in a rolling LDS buffer, so every
-//    entry's prefix is gathered from the window exactly once (k_lz_match rebuilt a tile of 96
-//    prefixes per 32 candidates per batch), and candidate number k of lane l is slot 128 + l - k:
-//    consecutive lanes read consecutive 8-byte words, no bank conflicts, immediate offsets.
+//    entry's prefix is gathered from the window exactly once, and candidate number k of lane l is
+//    slot 128 + l - k: consecutive lanes read consecutive 8-byte words, no bank conflicts.
 //  * bucket offsets (how many candidates an entry has) come from the hashes of the prefixes that
 //    are in registers anyway: no pre-pass over the sorted array, no NQ array in HBM.
 //  * a candidate is valid iff its number is <= n; the position rules (distance <= 32768, position
