@@ -35,8 +35,7 @@ enum KernelId {
     K_LZ_MATCH,
     K_LZ_CHAIN,
     K_LZ_WALK,
-    K_LZ_PARSE,
-    K_LZ_EMIT,
+    K_LZ_TOK,
     K_ST_PARSE,
     K_ST_EMIT,
     K_PLAN,
@@ -49,7 +48,7 @@ enum KernelId {
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
                                            "k_lz_chain", "k_lz_walk",
-                                           "k_lz_parse", "k_lz_emit",   "k_st_parse", "k_st_emit", "k_plan",
+                                           "k_lz_tok", "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_gather"};
 
 struct DevBuf {
@@ -423,10 +422,8 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc) {
     int rc;
     const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
     if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(h, h->marks, (size_t)nc * 2048 * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
     return FLATE_HIP_OK;
@@ -523,15 +520,9 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             }
         }
         {
-            ProfScope ps(h, K_LZ_PARSE);
-            hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(FL_PARSE_THREADS), 0, st, dch, prm,
-                               (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
-        }
-        {
-            ProfScope ps(h, K_LZ_EMIT);
-            hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, prm,
-                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p,
-                               dhist, dpl, (uint32_t*)h->ntok.p);
+            ProfScope ps(h, K_LZ_TOK);
+            hipLaunchKernelGGL(k_lz_tok, dim3(nc), dim3(FL_TOK_THREADS), 0, st, d_in, dch, prm,
+                               (const uint32_t*)h->rec.p, (uint32_t*)h->tokens.p, dhist, dpl, (uint32_t*)h->ntok.p);
         }
         h->dbg_pass_chunks = nc;
         h->dbg_first_chunk = c0;

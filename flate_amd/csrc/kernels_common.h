@@ -46,6 +46,16 @@ __device__ __forceinline__ uint32_t fl_wave_incl_scan(uint32_t v, uint32_t lane)
     }
     return v;
 }
+// the same on the cross-lane data path (DPP row shifts and row broadcasts: no LDS round trips)
+__device__ __forceinline__ uint32_t fl_wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // make this wave's LDS writes visible to its own later reads (cross-lane through LDS)
 __device__ __forceinline__ void fl_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

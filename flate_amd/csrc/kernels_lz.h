@@ -17,11 +17,10 @@
 //   k_lz_match  for EVERY position, the longest-match record the reference's findMatch
 //               would return, for the full chain budget and for chain >> 2
 //               (deflate.zig:241-245); window staged in LDS.
-//   k_lz_parse  the lazy-matching automaton (deflate.zig:154-205) as a function
+//   k_lz_tok    the lazy-matching automaton (deflate.zig:154-205) as a function
 //               "anchor -> next anchor", resolved with pointer jumping instead of a
-//               serial walk: descriptors per position + the set of anchors.
-//   k_lz_emit   token list, per-block histograms and the block boundaries
-//               (32768 tokens, deflate.zig:227-230) by prefix sums over the anchors.
+//               serial walk; then the token list, per-block histograms and the block
+//               boundaries (32768 tokens, deflate.zig:227-230) by prefix sums over the anchors.
 //
 // Bounds: k_lz_match is bound by vector-ALU issue, the others by latency and by the traffic
 // of the per-position scratch arrays in HBM; no MFMA.
@@ -724,7 +723,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     fl_prof_mark(11);
 }
 
-// ------------------------------------------------------------------ k_lz_parse
+// ------------------------------------------------------------------ anchor descriptors
 // desc[p]: what an anchor at p emits.  0 = one literal, next anchor p + 1.
 // Otherwise bit31 | j << 23 | (len - 3) << 15 | dist - 1: j literals p .. p+j-1, then a
 // match (len, dist) at p + j; next anchor p + j + len.
@@ -761,136 +760,57 @@ __device__ __forceinline__ uint32_t fl_anchor_desc(const uint2* __restrict__ rec
     return 0x80000000u | (j << 23) | ((len - 3) << 15) | dist0;
 }
 
-// One workgroup per chunk: which positions are anchors (visited with no pending match)?
-// Output: desc[c][p] for every position and the anchor bit set marks[c][2048].
-// The chunk is handled in two halves of 32768 positions so that the pointer table is 64 KiB
-// and two workgroups (32 waves) fit a CU; the only state carried across is the next anchor.
-#define FL_PARSE_HALF 32768u
-__global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_lz_parse(const fl_chunk* __restrict__ chunks, fl_params prm,
-                                                                   const uint32_t* __restrict__ rec_all,
-                                                                   uint32_t* __restrict__ desc_all,
-                                                                   uint32_t* __restrict__ marks_all) {
-    __shared__ uint16_t J[FL_PARSE_HALF];
-    __shared__ uint32_t marks[2048];
-    __shared__ uint16_t entry[256];
-    __shared__ uint32_t next_anchor;
-    const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
-    const uint32_t tid = threadIdx.x;
-    if (ck.skip) return;
-    const uint32_t N = ck.in_len;
-    const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
-    uint32_t* desc = desc_all + ck.pos_off;
-    uint32_t* gmarks = marks_all + (ck.pos_off >> 5);
-
-    for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) marks[i] = 0;
-    if (tid < 256) entry[tid] = 0xffff;
-    if (tid == 0) next_anchor = 0;
-    fl_prof_mark(16);
-    for (uint32_t h0 = 0; h0 < N; h0 += FL_PARSE_HALF) {
-        const uint32_t h1 = min(h0 + FL_PARSE_HALF, N);
-        // (a) anchor function for every position, 8 positions per thread per round trip
-        for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
-            uint2 ra[8], rb[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-                ra[u] = p < h1 ? rec2[p] : make_uint2(0u, 0u);
-                rb[u] = (p < h1 && p + 1 < N) ? rec2[p + 1] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-                if (p < h1) {
-                    const uint32_t d = fl_anchor_desc(rec2, p, ra[u], rb[u], prm.good, prm.lazy);
-                    desc[p] = d;
-                    J[p - h0] = (uint16_t)fl_desc_next(d, p);
-                }
-            }
-        }
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(17);
-        // (b) pointer jumping inside 256-position segments: J[p] -> first anchor on p's path that
-        // lies at or beyond the end of p's segment.  Racy reads only ever see a node further along
-        // the same path, so 8 rounds (2^8 = segment length) always suffice.
-        for (int round = 0; round < 8; round++) {
-            for (uint32_t p = h0 + tid; p < h1; p += FL_PARSE_THREADS) {
-                const uint32_t seg_end = min((p | 255u) + 1u, N);
-                const uint32_t j = J[p - h0];
-                if (j < seg_end) J[p - h0] = J[j - h0];
-            }
-            __syncthreads();
-        }
-        if (h0 == 0) fl_prof_mark(18);
-        // (c) first anchor of every segment of this half: at most 128 serial steps
-        if (tid == 0) {
-            uint32_t a = next_anchor;
-            while (a < h1) {
-                entry[a >> 8] = (uint16_t)a;
-                a = J[a - h0];
-            }
-            next_anchor = a;
-        }
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(19);
-        // (d) restore the one-step pointers
-        for (uint32_t base = h0; base < h1; base += FL_PARSE_THREADS * 8) {
-            uint32_t d[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-                d[u] = p < h1 ? desc[p] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t p = base + u * FL_PARSE_THREADS + tid;
-                if (p < h1) J[p - h0] = (uint16_t)fl_desc_next(d[u], p);
-            }
-        }
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(20);
-        // (e) mark the anchors of each segment (one thread per segment, <= 256 steps)
-        if (tid < FL_PARSE_HALF / 256) {
-            const uint32_t seg = (h0 >> 8) + tid;
-            uint32_t a = entry[seg];
-            const uint32_t end = min((seg + 1) << 8, N);
-            while (a < end) {
-                marks[a >> 5] |= 1u << (a & 31);
-                a = J[a - h0];
-            }
-        }
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(21);
-    }
-    for (uint32_t i = tid; i < 2048; i += FL_PARSE_THREADS) gmarks[i] = marks[i];
-}
-
-// ------------------------------------------------------------------ k_lz_emit
-// One workgroup per chunk: turn the anchors into the token list (deflate.zig:213-230), the
-// per-block symbol histograms (block_writer.zig:455-462) and the block boundaries
-// (32768 tokens per block, deflate.zig:227-230, 268-288).  Lane = position: descriptors are
-// read coalesced, literal bytes come from the LDS window, token offsets from wave prefix sums.
+// ------------------------------------------------------------------ token emission helpers
+// (k_lz_tok below; k_st_emit in kernels_stream.h)
 #define FL_EMIT_WAVES 16
 #define FL_EMIT_THREADS (64 * FL_EMIT_WAVES)
-#define FL_EMIT_SPAN (65536u / FL_EMIT_WAVES)  // positions per wave
 
 __device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t off) {
     return (win32[off >> 2] >> (8 * (off & 3))) & 0xff;
 }
 
-__global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_lz_emit(const uint8_t* __restrict__ in,
-                                                              const fl_chunk* __restrict__ chunks, fl_params prm,
-                                                              const uint32_t* __restrict__ desc_all,
-                                                              const uint32_t* __restrict__ marks_all,
-                                                              uint32_t* __restrict__ tokens_all,
-                                                              uint32_t* __restrict__ hist_all,
-                                                              fl_block_plan* __restrict__ plans,
-                                                              uint32_t* __restrict__ ntok_all) {
-    __shared__ uint32_t win32[16384 + 8];
-    __shared__ uint32_t marks[2048];
+// ------------------------------------------------------------------ k_lz_tok
+// k_lz_parse and k_lz_emit in one kernel (the default of the chunk path): the descriptors never
+// leave the registers of the thread that computed them, so the 4-byte-per-position desc array is
+// neither written nor read back (it was read three times), the anchor bits stay in LDS, and the
+// chunk's bytes are staged once, a part at a time, for the literals.
+//
+// The chunk is handled in parts of 8192 positions; wave w owns positions
+// [h0 + 512 w, h0 + 512 (w + 1)) of a part (two 256-position pieces of four 64-position
+// sub-pieces), 8 per lane, and everything except the hand-over of the anchor chain from piece to
+// piece is local to the wave -- four workgroup barriers per part.  Per part:
+//  (a) descriptor and one-step pointer J1 of every position (deflate.zig:154-194, fl_anchor_desc);
+//  (b) pointer jumping: J64[p] = first anchor on p's path beyond p's sub-piece (6 rounds), then
+//      J256[p] = ... beyond p's piece (2 more rounds);
+//  (c) the first anchor of every piece, <= 32 serial steps of one thread over J256;
+//  (d) the first anchor of every sub-piece, <= 4 steps of one lane per piece over J64;
+//  (e) the anchors of every sub-piece, one lane per sub-piece over J1, bits collected in registers;
+//  (f) tokens, histograms and the 32768-token block cut (deflate.zig:213-230, 268-288;
+//      block_writer.zig:444-462) by prefix sums over the anchors.
+#define FL_TOK_THREADS 1024
+#define FL_TOK_PART 8192u
+#define FL_TOK_SPAN (FL_TOK_PART / 16u)  // positions per wave per part
+#define FL_TOK_R (FL_TOK_SPAN / 64u)     // positions per lane per part
+#define FL_TOK_LOOK 256u                 // literals of an anchor may reach this far past its part (j < 256)
+#define FL_TOK_WIN_DW ((FL_TOK_PART + FL_TOK_LOOK) / 4u + 2u)
+
+__global__ __launch_bounds__(FL_TOK_THREADS, 8) void k_lz_tok(const uint8_t* __restrict__ in,
+                                                             const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                             const uint32_t* __restrict__ rec_all,
+                                                             uint32_t* __restrict__ tokens_all,
+                                                             uint32_t* __restrict__ hist_all,
+                                                             fl_block_plan* __restrict__ plans,
+                                                             uint32_t* __restrict__ ntok_all) {
+    __shared__ uint16_t J1[FL_TOK_PART];
+    __shared__ uint16_t J64[FL_TOK_PART];
+    __shared__ uint16_t J256[FL_TOK_PART];
+    __shared__ uint32_t winp[FL_TOK_WIN_DW];
+    __shared__ uint32_t marks[FL_TOK_PART / 32];
+    __shared__ uint16_t entry[FL_TOK_PART / 256];
+    __shared__ uint16_t entry64[FL_TOK_PART / 64];
     __shared__ uint32_t hist[2][320];
-    __shared__ uint32_t wtot[FL_EMIT_WAVES];
-    __shared__ uint32_t v1_sh;
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t next_anchor, v1_sh;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -906,67 +826,169 @@ __global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_lz_emit(const uint8_t* _
     }
     const uint32_t N = ck.in_len;
     const uint8_t* src = in + ck.in_off;
-    const uint32_t* desc = desc_all + ck.pos_off;
-    const uint32_t* gmarks = marks_all + (ck.pos_off >> 5);
+    const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
     uint32_t* tokens = tokens_all + ck.pos_off;
 
-    fl_prof_mark(24);
-    const uint32_t ndw = (N + 3) >> 2;
-    for (uint32_t i = tid; i < 16384 + 8; i += FL_EMIT_THREADS)
-        win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
-    for (uint32_t i = tid; i < 2048; i += FL_EMIT_THREADS) marks[i] = gmarks[i];
-    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS) (&hist[0][0])[i] = 0;
-    if (tid == 0) v1_sh = N;
-    __syncthreads();
-    fl_prof_mark(25);
-    const uint32_t span0 = wave * FL_EMIT_SPAN;
-    // pass 1: tokens per wave
-    uint32_t cnt = 0;
-#pragma unroll 1  // (the compiler would unroll all 16 rounds and spill the descriptors it hoists)
-    for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
-        uint32_t d[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = span0 + (r + u) * 64 + lane;
-            d[u] = p < N ? desc[p] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = span0 + (r + u) * 64 + lane;
-            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
-            cnt += mk ? (d[u] ? ((d[u] >> 23) & 0xff) + 1 : 1) : 0;
-        }
+    for (uint32_t i = tid; i < 640; i += FL_TOK_THREADS) (&hist[0][0])[i] = 0;
+    if (tid == 0) {
+        next_anchor = 0;
+        v1_sh = N;
     }
-    cnt = fl_wave_sum(cnt);
-    if (lane == 0) wtot[wave] = cnt;
-    __syncthreads();
-    fl_prof_mark(26);
-    uint32_t run = 0, total = 0;
-    for (uint32_t w = 0; w < FL_EMIT_WAVES; w++) {
-        if (w < wave) run += wtot[w];
-        total += wtot[w];
-    }
-    // pass 2: emit
-#pragma unroll 1
-    for (uint32_t r = 0; r < FL_EMIT_SPAN / 64; r += 4) {
-        uint32_t d[4];
+    uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
+    fl_prof_mark(16);
+    for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
+        const uint32_t h1 = min(h0 + FL_TOK_PART, N);
+        const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
+        // the records of the wave's positions (in flight while the bytes are staged)
+        uint2 ra[FL_TOK_R];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = span0 + (r + u) * 64 + lane;
-            d[u] = p < N ? desc[p] : 0;
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t p = span0 + r * 64 + lane;
+            ra[r] = p < h1 ? rec2[p] : make_uint2(0u, 0u);
         }
+        // the record of the position after the wave's last one
+        uint2 rx = make_uint2(0u, 0u);
+        if (lane == 63 && span0 + FL_TOK_SPAN < N) rx = rec2[span0 + FL_TOK_SPAN];
+        // the part's bytes (+ lookahead for the literals of its last anchors), zero padded
+        {
+            const uint32_t nb = min(N - h0, FL_TOK_PART + FL_TOK_LOOK);
+            for (uint32_t i = tid; i < FL_TOK_WIN_DW; i += FL_TOK_THREADS)
+                winp[i] = 4 * i < nb ? fl_load_u32_clamped(src + h0, 4 * i, nb) : 0u;
+        }
+        if (h0 == 0) fl_prof_mark(23);
+        if (tid < FL_TOK_PART / 256) entry[tid] = 0xffff;
+        if (lane < FL_TOK_SPAN / 64) entry64[wave * (FL_TOK_SPAN / 64) + lane] = 0xffff;
+        // (a) anchor function of the wave's positions; (b) pointer jumping inside the sub-piece a round
+        // of the wave covers (lane = position): J64 = first anchor on the path beyond the sub-piece.
+        // The pointers stay in registers and travel by ds_bpermute; a lane reads a node further along
+        // its own path, so the rounds end when no pointer moves any more (<= 6: 2^6 positions).
+        uint32_t d[FL_TOK_R];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = span0 + (r + u) * 64 + lane;
-            const bool mk = (marks[p >> 5] >> (p & 31)) & 1;
-            const uint32_t dd = d[u];
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t p = span0 + r * 64 + lane;
+            // record of p + 1: the next lane's, the next round's first lane's, or rx
+            uint2 rb;
+            rb.x = __shfl_down(ra[r].x, 1, 64);
+            rb.y = __shfl_down(ra[r].y, 1, 64);
+            const uint2 nf = ra[r + 1 < (int)FL_TOK_R ? r + 1 : r];
+            const uint32_t fx = r + 1 < (int)FL_TOK_R ? __shfl(nf.x, 0, 64) : rx.x;
+            const uint32_t fy = r + 1 < (int)FL_TOK_R ? __shfl(nf.y, 0, 64) : rx.y;
+            if (lane == 63) {
+                rb.x = fx;
+                rb.y = fy;
+            }
+            uint32_t dd = 0, nx = 0xffffu;
+            if (p < h1) {
+                dd = fl_anchor_desc(rec2, p, ra[r], rb, prm.good, prm.lazy);
+                nx = fl_desc_next(dd, p);
+                J1[p - h0] = (uint16_t)nx;
+            }
+            d[r] = dd;
+            const uint32_t base = span0 + r * 64;
+            const uint32_t seg_end = min(base + 64u, N);
+            while (__any(nx < seg_end)) {
+                const uint32_t o = __shfl(nx, (nx - base) & 63u, 64);
+                if (nx < seg_end) nx = o;
+            }
+            if (p < h1) {
+                J64[p - h0] = (uint16_t)nx;
+                J256[p - h0] = (uint16_t)nx;
+            }
+        }
+        fl_lds_order();
+        if (h0 == 0) fl_prof_mark(17);
+        // J256 = first anchor on the path beyond the 256-position piece: a piece is four sub-pieces,
+        // so two doubling rounds over J64's result always suffice
+        for (int round = 0; round < 2; round++) {
+#pragma unroll
+            for (int r = 0; r < (int)FL_TOK_R; r++) {
+                const uint32_t p = span0 + r * 64 + lane;
+                if (p < h1) {
+                    const uint32_t seg_end = min((p | 255u) + 1u, N);
+                    const uint32_t j = J256[p - h0];
+                    if (j < seg_end) J256[p - h0] = J256[j - h0];
+                }
+            }
+            fl_lds_order();
+        }
+        if (h0 == 0) fl_prof_mark(24);
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(18);
+        // (c) first anchor of every piece of this part: at most 32 serial steps
+        if (tid == 0) {
+            uint32_t a = next_anchor;
+            while (a < h1) {
+                entry[(a - h0) >> 8] = (uint16_t)a;
+                a = J256[a - h0];
+            }
+            next_anchor = a;
+        }
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(19);
+        // (d) first anchor of every sub-piece of the wave's pieces
+        if (lane < FL_TOK_SPAN / 256) {
+            const uint32_t piece = wave * (FL_TOK_SPAN / 256) + lane;
+            uint32_t a = entry[piece];
+            const uint32_t end = min(h0 + ((piece + 1) << 8), N);
+            while (a < end) {
+                entry64[(a - h0) >> 6] = (uint16_t)a;
+                a = J64[a - h0];
+            }
+        }
+        fl_lds_order();
+        // (e) the anchors of the wave's sub-pieces (one lane per sub-piece, bits in registers)
+        if (lane < FL_TOK_SPAN / 64) {
+            const uint32_t sub = wave * (FL_TOK_SPAN / 64) + lane;
+            uint32_t a = entry64[sub];
+            const uint32_t base = h0 + (sub << 6);
+            const uint32_t end = min(base + 64u, N);
+            uint32_t m0 = 0, m1 = 0;
+            while (a < end) {
+                const uint32_t o = a - base;
+                if (o < 32)
+                    m0 |= 1u << o;
+                else
+                    m1 |= 1u << (o - 32);
+                a = J1[a - h0];
+            }
+            marks[2 * sub] = m0;
+            marks[2 * sub + 1] = m1;
+        }
+        fl_lds_order();
+        if (h0 == 0) fl_prof_mark(21);
+        // (f) tokens per wave, then emit
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t q = span0 + r * 64 + lane - h0;
+            const bool mk = (marks[q >> 5] >> (q & 31)) & 1;
+            cnt += mk ? (d[r] ? ((d[r] >> 23) & 0xff) + 1 : 1) : 0;
+        }
+        cnt = fl_wave_sum(cnt);
+        if (lane == 0) wtot[wave] = cnt;
+        __syncthreads();
+        if (h0 == 0) fl_prof_mark(25);
+        uint32_t run = run0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) run += wtot[w];
+            run0 += wtot[w];
+        }
+#pragma unroll 1  // (rolled: the descriptors rotate through d[0])
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t p = span0 + r * 64 + lane;
+            const uint32_t q = p - h0;
+            const bool mk = (marks[q >> 5] >> (q & 31)) & 1;
+            const uint32_t dd = d[0];
+#pragma unroll
+            for (int k = 0; k + 1 < (int)FL_TOK_R; k++) d[k] = d[k + 1];
+            d[FL_TOK_R - 1] = dd;
             const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;  // literals of this anchor
             const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
-            const uint32_t incl = fl_wave_incl_scan(nt, lane);
+            const uint32_t incl = fl_wave_incl_scan_dpp(nt);
             uint32_t idx = run + incl - nt;
-            run += __shfl(incl, 63, 64);
+            run += __builtin_amdgcn_readlane(incl, 63);
             for (uint32_t x = 0; x < nl; x++) {
-                const uint32_t byte = fl_win_byte(win32, p + x);
+                const uint32_t byte = fl_win_byte(winp, q + x);
                 tokens[idx] = FL_TOK_LIT(byte);
                 atomicAdd(&hist[idx >> 15][byte], 1u);
                 if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
@@ -982,14 +1004,16 @@ __global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_lz_emit(const uint8_t* _
                 if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
             }
         }
+        __syncthreads();  // wtot, winp and the pointer tables are reused by the next part
+        if (h0 == 0) fl_prof_mark(22);
     }
-    __syncthreads();
     fl_prof_mark(27);
     // block boundaries (deflate.zig:227-230, 268-288) and histograms
+    const uint32_t total = run0;
     const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
-    uint32_t* h0 = hist_all + (uint64_t)ck.first_block * 320;
-    for (uint32_t i = tid; i < 640; i += FL_EMIT_THREADS)
-        if (i < 320 * nblk) h0[i] = (&hist[0][0])[i];
+    uint32_t* hg = hist_all + (uint64_t)ck.first_block * 320;
+    for (uint32_t i = tid; i < 640; i += FL_TOK_THREADS)
+        if (i < 320 * nblk) hg[i] = (&hist[0][0])[i];
     if (tid == 0) {
         ntok_all[c] = total;
         const uint32_t v1 = v1_sh;

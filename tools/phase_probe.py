@@ -18,9 +18,9 @@ print("n_chunks", len(chunks))
 seg("sort: zero+count1", 0, 1); seg("sort: scan1", 1, 2); seg("sort: scatter1 (LDS)", 2, 3); seg("sort: scan2", 3, 4)
 seg("sort: scatter2 (global)", 4, 5); seg("sort: total", 0, 5)
 seg("match: stage window", 8, 9); seg("match: bucket offsets", 9, 10); seg("match: batches", 10, 11); seg("match: total", 8, 11)
-seg("parse: (a) desc", 16, 17); seg("parse: (b) jump", 17, 18); seg("parse: (c) serial", 18, 19); seg("parse: (d) restore", 19, 20)
-seg("parse: (e) mark", 20, 21); seg("parse: total", 16, 21)
-seg("emit: stage", 24, 25); seg("emit: count", 25, 26); seg("emit: emit", 26, 27); seg("emit: total", 24, 27)
+seg("tok part 0: stage", 16, 23); seg("tok part 0: (a) + sub-piece jumps", 23, 17); seg("tok part 0: piece jumps", 17, 24)
+seg("tok part 0: barrier", 24, 18); seg("tok part 0: (c) serial", 18, 19); seg("tok part 0: (d) + (e)", 19, 21)
+seg("tok part 0: (f) count", 21, 25); seg("tok part 0: (f) emit", 25, 22); seg("tok: all parts", 16, 27)
 if t[32:40].any() and os.environ.get("FL_WALK_PROF"):
     for k, nm in {32: "walk: iterations", 33: "walk: refill rounds", 34: "walk: verify rounds", 35: "walk: walking lanes (sum)",
                   36: "walk: free lanes at refill (sum)", 37: "walk: lanes verified (sum)", 38: "walk: sleeps"}.items():
