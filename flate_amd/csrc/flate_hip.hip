@@ -81,7 +81,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag;
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
@@ -242,6 +242,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     if ((rc = ensure(h, h->fpts, sizeof(uint32_t) * (t.fpts.size() + 1)))) return rc;
     if ((rc = ensure(h, h->zones, sizeof(uint32_t) * (t.zones.size() + 1)))) return rc;
     if ((rc = ensure(h, h->nsorted, sizeof(uint32_t) * tiles_per_launch))) return rc;
+    if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * tiles_per_launch))) return rc;
     if ((rc = ensure(h, h->S, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(h, h->NC, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->rec, npos * 2 * sizeof(uint32_t) + 64))) return rc;
@@ -278,7 +279,8 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         {
             ProfScope ps(h, K_LZ_SORT);
             hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti, dfp,
-                               (uint32_t*)h->nsorted.p, (uint16_t*)h->S.p, prm.dbg);
+                               (uint32_t*)h->nsorted.p, (uint16_t*)h->S.p,
+                               (prm.dbg & (2 | 64 | 2048 | 8192)) ? (uint32_t*)nullptr : (uint32_t*)h->cflag.p, prm.dbg);
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
@@ -288,11 +290,12 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             else if (!(prm.dbg & (2 | 64)))
                 hipLaunchKernelGGL((k_lz_match<true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p);
+                                   (uint32_t*)h->rec.p,
+                                   (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p);
             else if (prm.dbg & 2)
                 hipLaunchKernelGGL((k_lz_match<true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p);
+                                   (uint32_t*)h->rec.p, (const uint32_t*)nullptr);
             else
                 launch_match2<true>(st, nt, prm.mode, d_in, dch, dti, dfp, (const uint32_t*)h->nsorted.p, prm,
                                     (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
@@ -426,6 +429,7 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc) {
     if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
+    if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nc))) return rc;
     return FLATE_HIP_OK;
 }
 
@@ -498,7 +502,8 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 ProfScope ps(h, K_LZ_SORT);
                 hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
                                    (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint16_t*)h->S.p, prm.dbg);
+                                   (uint16_t*)h->S.p,
+                                   (prm.dbg & (2 | 64 | 2048 | 8192)) ? (uint32_t*)nullptr : (uint32_t*)h->cflag.p, prm.dbg);
             }
             {
                 ProfScope ps(h, K_LZ_MATCH);
@@ -509,11 +514,13 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 else if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
                     hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p,
+                                       (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p);
                 else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
                     hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p);
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p,
+                                       (const uint32_t*)nullptr);
                 else
                     launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
                                          (uint32_t*)h->rec.p);
@@ -590,7 +597,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
                                                               const fl_tile* __restrict__ tiles,
                                                               const uint32_t* __restrict__ fpts,
                                                               uint32_t* __restrict__ n_sorted,
-                                                              uint16_t* __restrict__ S, uint32_t dbg) {
+                                                              uint16_t* __restrict__ S, uint32_t* __restrict__ cflag,
+                                                              uint32_t dbg) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
@@ -183,7 +184,27 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     };
     __shared__ uint32_t n_hashed;
     if (tid == 0) n_hashed = 0;
+    // A window of one repeated byte (a run of zeros, say) needs no sort: k_lz_match writes its records
+    // directly (every position matches its predecessor over the full length).  It is one iff every
+    // 4-byte word equals the first one.
+    const uint32_t word0 = M ? fl_load_u32_unaligned(src) : 0u;
+    bool same = cflag != nullptr && M >= 64 && !(STREAM && ck.n_flush);
 
+    // (looked for before the counting pass -- whose LDS atomics would all hit one counter -- whenever the
+    // first words of every wave's slice already agree)
+    if (__syncthreads_and(!same || slice0 + lane >= M || fl_load_u32_unaligned(src + slice0 + lane) == word0) && same) {
+        for (uint32_t p = tid; p < M; p += FL_SORT_THREADS) same = same && fl_load_u32_unaligned(src + p) == word0;
+        if (STREAM)  // the lookahead of the last targets (k_lz_match stages 288 bytes past the 65536 positions)
+            for (uint32_t q = 65536u + tid; q < min(N, 65536u + 288u); q += FL_SORT_THREADS)
+                same = same && src[q] == (uint8_t)word0;
+        if (__syncthreads_and(same)) {
+            if (tid == 0) {
+                cflag[c] = 1u;
+                if (STREAM) n_sorted[c] = M;
+            }
+            return;
+        }
+    }
     fl_prof_mark(0);
     for (uint32_t i = tid; i < FL_SORT_WAVES * 256; i += FL_SORT_THREADS) (&cnt1[0][0])[i] = 0;
     for (uint32_t i = tid; i < FL_SORT_WAVES * 128; i += FL_SORT_THREADS) (&cnt2[0][0])[i] = 0;
@@ -211,6 +232,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     __syncthreads();
     const uint32_t Ms = STREAM ? n_hashed : M;  // entries of the sorted array
     if (STREAM && tid == 0) n_sorted[c] = Ms;
+    if (cflag != nullptr && tid == 0) cflag[c] = 0u;
     fl_prof_mark(1);
     fl_scan_counters<256, 4>(cnt1, wsum, tid);
     fl_prof_mark(2);
@@ -369,7 +391,8 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                                                                   const uint32_t* __restrict__ n_sorted, fl_params prm,
                                                                   const uint16_t* __restrict__ S,
                                                                   uint32_t* __restrict__ NQ,
-                                                                  uint32_t* __restrict__ rec_all) {
+                                                                  uint32_t* __restrict__ rec_all,
+                                                                  const uint32_t* __restrict__ cflag) {
     constexpr uint32_t WIN_DW = STREAM ? FL_WIN_DW_STREAM : FL_WIN_DW_CHUNK;
     __shared__ uint32_t win32[WIN_DW];
     __shared__ uint2 tW[FL_MATCH_WAVES][FL_TILE];
@@ -396,13 +419,26 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     const uint32_t chain = prm.chain, quarter = prm.chain >> 2, nice = prm.nice;
 
     fl_prof_mark(8);
+    // positions without a hash entry never match (Lookup.zig:24)
+    // (with flush points in the stream the host has cleared all records beforehand)
+    for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
+    if (cflag != nullptr && cflag[c]) {
+        // The window is one repeated byte (k_lz_sort saw it and sorted nothing).  The nearest chain
+        // candidate of p is p - 1, it matches over the whole lookahead, and a match that long ends the
+        // walk (deflate.zig:254-258): every position's record is (maxlen, distance 1), for both chain
+        // budgets -- unless p - 1 is the chain's null (position 0, deflate.zig:248) or went with a slide.
+        for (uint32_t p = tgt0 + tid; p < Mpos; p += FL_MATCH_THREADS) {
+            uint32_t lov = 1u;
+            if (STREAM && p >= zone) lov = FL_MAX_DIST + 1u;
+            const uint32_t r = (p >= 1u && p - 1u >= lov) ? (min(N - p, FL_MAX_MATCH) << 16) : 0u;
+            rec2[p] = make_uint2(r, r);
+        }
+        return;
+    }
     // stage the window in LDS (zero padded)
     const uint32_t ndw = (min(N, WIN_DW * 4u) + 3) >> 2;
     for (uint32_t i = tid; i < WIN_DW; i += FL_MATCH_THREADS)
         win32[i] = i < ndw ? fl_load_u32_clamped(src, 4 * i, N) : 0u;
-    // positions without a hash entry never match (Lookup.zig:24)
-    // (with flush points in the stream the host has cleared all records beforehand)
-    for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
     __syncthreads();
     fl_prof_mark(9);
 

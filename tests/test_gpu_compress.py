@@ -30,6 +30,11 @@ def _rng_cases():
         "zeros262": bytes(262),
         "zeros263": bytes(263),
         "zeros65535": bytes(65535),
+        "ff1000": b"\xff" * 1000,              # one repeated byte: answered without a sort (k_lz_match)
+        "a66": b"a" * 66,
+        "zeros_then_x": bytes(65534) + b"x",  # ... and almost: the ordinary path
+        "x_then_zeros": b"x" + bytes(65534),
+        "zeros_x_zeros": bytes(40000) + b"x" + bytes(25534),
         "rfc": golden("rfc1951.txt"),
         "text64k": synth.text(synth.SEED_TEXT, 65535).tobytes(),
         "text_odd": synth.text(synth.SEED_TEXT + 1, 40001).tobytes(),

@@ -27,6 +27,13 @@ def _cases():
         "zeros65537": bytes(65537),
         "zeros98304": bytes(98304),
         "zeros200k": bytes(200000),
+        # one repeated byte: windows that k_lz_sort recognises and k_lz_match answers directly, and the
+        # windows around the place where the run ends (inside the tile, in its 288-byte lookahead, after it)
+        "ff150k": b"\xff" * 150000,
+        "zeros_then_text": bytes(65536 + 100) + text[:50000],
+        "zeros_then_x_in_lookahead": bytes(65536 + 287) + b"x" + bytes(40000),
+        "zeros_then_x_after_lookahead": bytes(65536 + 288) + b"x" + bytes(70000),
+        "text_then_zeros": text[:40000] + bytes(200000),
         "text65536": text[:65536],
         "text_zone": text[:ZONE + 40],
         "text98303": text[:98303],
