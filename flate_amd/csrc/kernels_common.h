@@ -19,11 +19,6 @@ __device__ __forceinline__ void fl_prof_mark(uint32_t slot) {
 __device__ __forceinline__ uint32_t fl_lane() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
-__device__ __forceinline__ uint32_t fl_wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
 __device__ __forceinline__ uint32_t fl_wave_xor(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v ^= __shfl_xor(v, d, 64);
@@ -37,16 +32,8 @@ __device__ __forceinline__ uint32_t fl_wave_max(uint32_t v) {
     }
     return v;
 }
-// inclusive prefix sum across the 64 lanes
-__device__ __forceinline__ uint32_t fl_wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
-    return v;
-}
-// the same on the cross-lane data path (DPP row shifts and row broadcasts: no LDS round trips)
+// inclusive prefix sum across the 64 lanes, on the cross-lane data path (DPP row shifts and row
+// broadcasts: no LDS round trips)
 __device__ __forceinline__ uint32_t fl_wave_incl_scan_dpp(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
@@ -55,6 +42,13 @@ __device__ __forceinline__ uint32_t fl_wave_incl_scan_dpp(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return v;
+}
+__device__ __forceinline__ uint32_t fl_wave_incl_scan(uint32_t v, uint32_t lane) {
+    (void)lane;
+    return fl_wave_incl_scan_dpp(v);
+}
+__device__ __forceinline__ uint32_t fl_wave_sum(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)fl_wave_incl_scan_dpp(v), 63);
 }
 // make this wave's LDS writes visible to its own later reads (cross-lane through LDS)
 __device__ __forceinline__ void fl_wave_lds_sync() {
