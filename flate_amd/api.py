@@ -18,9 +18,12 @@ Scope of this round: one-shot streams of any length.  At levels 4..9
 input longer than 65535 bytes is compressed as ONE stream by the whole-stream path
 (SURVEY.md 8f-2), byte-identical to the reference's sliding-window compressor.
 Compressor.flush (deflate.zig:335-337; 474-478 for the huffman-only / store-only
-compressors) is a sync flush that keeps the LZ history: the object re-runs the stream so far with its flush points on the GPU and
-hands the writer only the new bytes (the output of a prefix of the calls is a prefix
-of the output).
+compressors) is a sync flush that keeps the LZ history.  It is incremental: the object
+keeps only the tail of what was written that the reference's window, slide schedule and
+pending block can still depend on (from a 32 KiB-aligned position at least 96 KiB before
+the previous flush), compresses that tail with its flush points on the GPU and hands the
+writer the bytes that follow what the previous flush produced; the container checksum is
+folded piece by piece.
 """
 import enum
 import io

@@ -10,7 +10,7 @@ run() {  # name, bench args...
   rm -rf /tmp/prof_$name
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p --output-format csv -- python $R/bench.py "$@" > $R/gpurun_out/${TAG}_${name}_bench.json 2> /tmp/prof_$name.err
   f=$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)
-  { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py $*"; grep -E '^"?Name|k_' "$f" | head -40; } > $R/gpurun_out/${TAG}_${name}_kernel_stats.csv
+  { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py $*"; grep -E '^"?Name|^"?(void )?k_[a-z_0-9]+[<(]' "$f" | head -40; } > $R/gpurun_out/${TAG}_${name}_kernel_stats.csv
   tail -1 $R/gpurun_out/${TAG}_${name}_bench.json | cut -c1-400
 }
 run config2 --steps 5 --warmup 2 --no-cpu-baseline --no-extras

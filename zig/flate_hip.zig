@@ -6,8 +6,8 @@
 //! the Zig 0.12-era std the reference itself targets.  The same façade in C++
 //! (flate_amd/host/flate.hpp) and Python (flate_amd/api.py) is compiled / run and tested.
 //! Deviation from the reference: the reference keeps all state inline and needs no allocator;
-//! this façade buffers whole streams in `std.heap.page_allocator` memory, because the GPU
-//! entry points are one-shot (the sync flush re-runs the stream so far, see DESIGN.md 1).
+//! this façade buffers in `std.heap.page_allocator` memory what the GPU entry points need at once
+//! (a one-shot stream, or the retained tail of a stream between sync flushes, see DESIGN.md 1).
 const std = @import("std");
 
 // ---- include/flate_hip.h ----
