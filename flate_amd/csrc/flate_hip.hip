@@ -85,6 +85,9 @@ struct flate_hip_ctx {
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
+    // host-buffer calls with pinned memory: copy streams beside the compute stream, events between them
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> xfer_events;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
     uint32_t dbg_first_chunk = 0;
@@ -205,6 +208,31 @@ size_t pass_chunk_limit() {
     const char* e = getenv("FLATE_HIP_MAX_PASS_CHUNKS");
     if (e && atoi(e) > 0) return (size_t)atoi(e);
     return 32768;
+}
+
+// host-buffer calls whose buffers are pinned run in sub-batches of this many chunks, so that the H2D copy of
+// sub-batch k + 1 and the D2H copy of k - 1 overlap the kernels of k
+size_t host_pass_chunk_limit() {
+    const char* e = getenv("FLATE_HIP_HOST_PASS_CHUNKS");
+    if (e && atoi(e) > 0) return (size_t)atoi(e);
+    return 1024;
+}
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain pageable memory: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+int xfer_event(flate_hip_ctx* h, size_t k, hipEvent_t* ev) {
+    while (h->xfer_events.size() <= k) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return FLATE_HIP_E_ALLOC;
+        h->xfer_events.push_back(e);
+    }
+    *ev = h->xfer_events[k];
+    return FLATE_HIP_OK;
 }
 
 // whole-stream passes: uncompressed bytes per pass (about 30 bytes of scratch per input byte)
@@ -603,6 +631,9 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->xfer_events) (void)hipEventDestroy(e);
+    if (h->s_in) (void)hipStreamDestroy(h->s_in);
+    if (h->s_out) (void)hipStreamDestroy(h->s_out);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return FLATE_HIP_OK;
@@ -705,12 +736,20 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     uint64_t* d_outlen = out_len;
     int32_t* d_status = status;
     uint64_t in_shift = 0, out_shift = 0;  // subtracted from offsets when staging host buffers
+    bool pin_in = false, pin_out = false;
     if (memkind == FLATE_HIP_MEM_HOST) {
         if ((rc = ensure(h, h->st_in, (in_hi - in_lo) + 16))) return rc;
         if ((rc = ensure(h, h->st_out, (out_hi - out_lo) + 16))) return rc;
         if ((rc = ensure(h, h->st_outlen, sizeof(uint64_t) * n_chunks))) return rc;
         if ((rc = ensure(h, h->st_status, sizeof(int32_t) * n_chunks))) return rc;
-        if (in_hi > in_lo)
+        // Pinned host buffers (hipHostMalloc / hipHostRegister, torch pin_memory): the copies are real DMA
+        // and run on their own streams, a sub-batch at a time (below).  Pageable: one staged copy each way.
+        pin_in = !fs && is_pinned_host(in + in_lo);
+        pin_out = !fs && is_pinned_host(out + out_lo);
+        if ((pin_in && !h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) ||
+            (pin_out && !h->s_out && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess))
+            return FLATE_HIP_E_ALLOC;
+        if (in_hi > in_lo && !pin_in)
             HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
         d_in = (const uint8_t*)h->st_in.p;
         d_out = (uint8_t*)h->st_out.p;
@@ -752,8 +791,9 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
 
     // A pass is a run of consecutive chunks of one kind: at levels 4..9 inputs of up to 65535 bytes
     // take the chunk path (kernels_lz.h), longer ones the whole-stream path (kernels_stream.h).
-    const size_t pass_limit = pass_chunk_limit();
+    const size_t pass_limit = (pin_in || pin_out) ? std::min(pass_chunk_limit(), host_pass_chunk_limit()) : pass_chunk_limit();
     const uint64_t stream_pass_bytes = stream_pass_byte_limit();
+    if (pin_out) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
     uint32_t nc = 0;
     size_t pass_count = 0;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
@@ -767,6 +807,14 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         if (pl && stream) return FLATE_HIP_E_UNSUPPORTED;  // (whole-stream passes build more tables per call)
         const size_t pass_index = pass_count++;
+        hipEvent_t ev_in = nullptr;
+        if (pin_in) {  // this sub-batch's input: in flight while the previous sub-batch is computed
+            const uint64_t a = hin[c0], b = hin[c0 + nc];
+            if ((rc = xfer_event(h, 2 * pass_index, &ev_in))) return rc;
+            if (b > a)
+                HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
+            HIP_OK(h, hipEventRecord(ev_in, h->s_in));
+        }
         if (pl && pl->ready) {
             // planned batch: the tables of this pass are on the device already
             const flate_hip_plan::Pass& pp = pl->passes[pass_index];
@@ -834,6 +882,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         // the host vectors must outlive the async copies
         HIP_OK(h, hipStreamSynchronize(st));
+        if (ev_in) HIP_OK(h, hipStreamWaitEvent(st, ev_in, 0));
         if (planning) {
             // keep this pass's tables in the plan; size the workspace now so that planned calls never allocate
             flate_hip_plan::Pass pp;
@@ -868,13 +917,25 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             if ((rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
         }
         HIP_OK(h, hipGetLastError());
+        if (pin_out) {  // this sub-batch's output slots go home while the next sub-batch is computed
+            hipEvent_t ev_out;
+            if ((rc = xfer_event(h, 2 * pass_index + 1, &ev_out))) return rc;
+            HIP_OK(h, hipEventRecord(ev_out, st));
+            HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
+            const uint64_t a = hout[c0], b = hout[c0 + nc];
+            if (b > a)
+                HIP_OK(h, hipMemcpyAsync(out + a, d_out + (a - out_shift), b - a, hipMemcpyDeviceToHost, h->s_out));
+        }
     }
 
     if (memkind == FLATE_HIP_MEM_HOST) {
         HIP_OK(h, hipMemcpyAsync(out_len, d_outlen, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_chunks, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipStreamSynchronize(st));
-        if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len))) return rc;
+        if (pin_out)
+            HIP_OK(h, hipStreamSynchronize(h->s_out));
+        else if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len)))
+            return rc;
     } else if (h->sync) {
         HIP_OK(h, hipStreamSynchronize(st));
     }

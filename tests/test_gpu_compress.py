@@ -474,3 +474,41 @@ def test_planned_batches_only_enqueue():
         with pytest.raises(Exception):
             eng.plan_compress(np.array([0, 70000], dtype=np.uint64), np.array([0, 80000], dtype=np.uint64), O.RAW, 6)
     eng.close()
+
+
+def test_pinned_host_buffers_take_the_overlapped_path():
+    """MEM_HOST with pinned buffers runs in sub-batches (H2D / kernels / D2H on three streams): every stream
+    equals what the pageable call produces, chunk sizes ragged, more chunks than one sub-batch holds."""
+    import torch
+    from flate_amd import _capi, synth
+    eng = engine()
+    L = _capi.lib()
+    rng = np.random.default_rng(77)
+    text = synth.text(synth.SEED_TEXT + 3, 40 << 20)
+    sizes = rng.integers(0, 20000, 2600)
+    sizes[::97] = 65535
+    sizes[5] = 0
+    off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+    np.cumsum(sizes, out=off[1:].view(np.int64))
+    n = len(sizes)
+    data = text[: int(off[-1])]
+    for container, mode in ((O.GZIP, 6), (O.RAW, 1), (O.ZLIB, 4)):
+        caps = np.array([(eng.compress_bound(int(x), container, mode) + 7) & ~7 for x in sizes], dtype=np.uint64)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        res = []
+        for pinned in (False, True):
+            mk = (lambda k, dt: torch.zeros(k, dtype=dt).pin_memory()) if pinned else (lambda k, dt: torch.zeros(k, dtype=dt))
+            h_in = mk(len(data) + 8, torch.uint8)
+            h_in[: len(data)] = torch.from_numpy(data)
+            h_out = mk(int(out_off[-1]) + 8, torch.uint8)
+            out_len = np.zeros(n, dtype=np.uint64)
+            status = np.zeros(n, dtype=np.int32)
+            rc = L.flate_hip_compress_batch(eng._h, h_in.data_ptr(), off.ctypes.data, n, container, mode, h_out.data_ptr(),
+                                            out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data, _capi.MEM_HOST)
+            assert rc == 0 and not status.any()
+            o = h_out.numpy()
+            res.append([o[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)])
+        assert res[0] == res[1]
+        for i in (0, 5, 97, n - 1):
+            assert res[1][i] == O.compress(data[int(off[i]): int(off[i + 1])].tobytes(), container, mode)
