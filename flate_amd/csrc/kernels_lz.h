@@ -533,7 +533,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const uint32_t p = nx_p;
         const bool active = i < M && (!STREAM || p >= tgt0);
-        uint32_t n = active ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only)
+        uint32_t n = (active && !(prm.dbg & 8)) ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only; 8: timing experiment)
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248),
         // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
         uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
