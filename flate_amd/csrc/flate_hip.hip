@@ -316,10 +316,16 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                 hipLaunchKernelGGL(k_lz_match3<true>, dim3(nt), dim3(FL_M3_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
             else if (!(prm.dbg & (2 | 64)))
-                hipLaunchKernelGGL((k_lz_match<true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
-                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p,
-                                   (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p);
+            {
+                const uint32_t* cf = (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p;
+                hipLaunchKernelGGL((k_lz_match<true, true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti,
+                                   dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p, cf);
+                if (cf)  // the tiles k_lz_sort marked runny
+                    hipLaunchKernelGGL((k_lz_match<true, true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                       dti, dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p,
+                                       (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
+            }
             else if (prm.dbg & 2)
                 hipLaunchKernelGGL((k_lz_match<true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
                                    (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
@@ -540,10 +546,17 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
                                        (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
                 else if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
-                    hipLaunchKernelGGL((k_lz_match<false, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                {
+                    const uint32_t* cf = (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p;
+                    hipLaunchKernelGGL((k_lz_match<false, true, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p,
-                                       (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p);
+                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
+                    if (cf)  // the chunks k_lz_sort marked runny
+                        hipLaunchKernelGGL((k_lz_match<false, true, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in,
+                                           dch, (const fl_tile*)nullptr, (const uint32_t*)nullptr,
+                                           (const uint32_t*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                           (uint32_t*)h->rec.p, cf);
+                }
                 else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
                     hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
                                        (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,

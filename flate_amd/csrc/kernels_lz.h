@@ -232,7 +232,18 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     __syncthreads();
     const uint32_t Ms = STREAM ? n_hashed : M;  // entries of the sorted array
     if (STREAM && tid == 0) n_sorted[c] = Ms;
-    if (cflag != nullptr && tid == 0) cflag[c] = 0u;
+    // "runny" windows (one low hash digit holds an eighth of the positions: runs, padding, repeated
+    // records) go to the RJ variant of k_lz_match
+    {
+        bool big = false;
+        if (tid < 256) {
+            uint32_t t = 0;
+            for (uint32_t w = 0; w < FL_SORT_WAVES; w++) t += cnt1[w][tid];
+            big = t >= max(Ms >> 3, 128u);
+        }
+        const int runny = __syncthreads_or(big && !(dbg & 65536));
+        if (cflag != nullptr && tid == 0) cflag[c] = runny ? 2u : 0u;
+    }
     fl_prof_mark(1);
     fl_scan_counters<256, 4>(cnt1, wsum, tid);
     fl_prof_mark(2);
@@ -330,7 +341,28 @@ __device__ __forceinline__ void fl_lds_load8(const uint32_t* win32, uint32_t off
     w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
 }
 
-// exact common prefix of the window at p and q, known to be >= 8, capped at maxlen
+// exact common prefix of the window at p and q, known to be >= len0, capped at maxlen
+__device__ __forceinline__ uint32_t fl_extend_len(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t len0,
+                                                  uint32_t maxlen) {
+    uint32_t len = len0;
+    while (len < maxlen) {
+        uint32_t a0, a1, b0, b1;
+        fl_lds_load8(win32, p + len, a0, a1);
+        fl_lds_load8(win32, q + len, b0, b1);
+        const uint32_t y0 = a0 ^ b0, y1 = a1 ^ b1;
+        if (y0) {
+            len += (uint32_t)__builtin_ctz(y0) >> 3;
+            break;
+        }
+        if (y1) {
+            len += 4 + ((uint32_t)__builtin_ctz(y1) >> 3);
+            break;
+        }
+        len += 8;
+    }
+    return min(len, maxlen);
+}
+// ... known to be >= 8
 __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t maxlen) {
     uint32_t len = 8;
     while (len < maxlen) {
@@ -383,7 +415,11 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 // position bound, a packed score "equal bytes, then nearest", a max, and one bit "agrees in all 8
 // prefix bytes"); only the tile's winner meets the lane's key, at the end of the tile.  Same
 // result: the key is a maximum.
-template <bool STREAM, bool BF>
+// RJ: the variant for windows k_lz_sort has marked "runny" (cflag 2: one hash digit holds an eighth of
+// the positions -- runs, padding, repeated records).  It adds the byte filter for groups of candidates
+// and the wave-wide compare described at flush_deep_rj below; plain windows run the plain variant,
+// whose code these additions would slow by 10 % (measured on the benchmark text: 26.0 -> 28.9 ms).
+template <bool STREAM, bool BF, bool RJ = false>
 __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t* __restrict__ in,
                                                                   const fl_chunk* __restrict__ chunks,
                                                                   const fl_tile* __restrict__ tiles,
@@ -403,6 +439,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     const uint32_t tgt0 = STREAM ? tiles[c].tgt0 : 0u;
     const fl_chunk ck = chunks[STREAM ? tiles[c].chunk : c];
     if (ck.skip) return;
+    if (((cflag != nullptr && cflag[c] == 2u) ? true : false) != RJ) return;  // the other variant's window
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t zone = STREAM ? tiles[c].zone : 65536u;
     const uint32_t N = ck.in_len - w0;
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
     // positions without a hash entry never match (Lookup.zig:24)
     // (with flush points in the stream the host has cleared all records beforehand)
     for (uint32_t p = Mpos + tid; p < min(N, 65536u); p += FL_MATCH_THREADS) rec2[p] = make_uint2(0u, 0u);
-    if (cflag != nullptr && cflag[c]) {
+    if (cflag != nullptr && cflag[c] == 1u) {
         // The window is one repeated byte (k_lz_sort saw it and sorted nothing).  The nearest chain
         // candidate of p is p - 1, it matches over the whole lookahead, and a match that long ends the
         // walk (deflate.zig:254-258): every position's record is (maxlen, distance 1), for both chain
@@ -601,7 +638,103 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         const uint32_t lenmask = maxlen >= 8 ? 0x80808080u : (0x00808080u >> (8 * (7 - maxlen)));
         uint32_t bb = 0;     // best score of the current tile: equal-byte flags | 0x40 | 32 - candidate number
         uint32_t kdone = 0;  // candidates of the current tile scored so far; dmask bit b = candidate kdone - b
-        auto flush_deep_bf = [&]() {
+        // Runs and repeated records (every candidate agrees in 8 bytes, nearly every lane of the wave already
+        // holds a match of >= 8): such a group of four candidates is filtered instead of scored -- a
+        // candidate can only beat a match of `best` bytes if its byte number `best` agrees
+        // (SlidingWindow.zig:91-93), one byte load per candidate.  What passes goes into dmask like an
+        // 8-byte candidate, but its prefix has not been looked at: fcand remembers which candidates of the
+        // tile were filtered, and those candidates are compared from their first byte.
+        bool runny = false;    // the wave has been served early once in this batch (uniform)
+        uint32_t fcand = 0;    // bit t - 1: candidate t of the current tile was filtered, not scored (uniform)
+        auto flush_deep_rj = [&]() {
+            // an 8-byte candidate of a lane that can match at most 8 bytes has nothing to add to its score
+            // (a filtered one has no score yet: bit b of dmask = candidate kdone - b)
+            if (maxlen <= 8) dmask &= (fcand && kdone) ? (__brev(fcand) >> (32u - kdone)) : 0u;
+            if (prm.dbg & 4) dmask = 0;  // (4: timing experiment, wrong output)
+            for (;;) {
+                const uint64_t act = __ballot(dmask != 0);
+                if (!act) break;
+                if (__popcll(act) <= 2 && __any(__popc(dmask) >= 3) && !(prm.dbg & 32768)) {
+                    // One or two lanes left, with several candidates (the start of a run walking back through
+                    // the end of the previous one: every candidate a byte longer than the last): the whole wave
+                    // compares one pair at a time, lane l the bytes 4 l .. 4 l + 3 -- the common prefix
+                    // in one step however long it is, instead of 8 bytes per trip on one lane.
+                    uint64_t rem = act;
+                    while (rem) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(rem);
+                        rem &= rem - 1;
+                        uint32_t q_l = 0, take_l = 0;
+                        if (lane == l) {
+                            const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
+                            dmask &= ~(1u << b);
+                            q_l = ts[FL_KB + lane - (kdone - b)];
+                            take_l = maxlen > (key >> 16) ? 1u : 0u;
+                        }
+                        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)l);
+                        const uint32_t Q = (uint32_t)__builtin_amdgcn_readlane((int)q_l, (int)l);
+                        const uint32_t ML = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)l);
+                        if (!__builtin_amdgcn_readlane((int)take_l, (int)l)) continue;
+                        const uint32_t off = 4u * lane;
+                        uint32_t x = 0;
+                        if (off < ML) x = fl_lds_load4(win32, P + off) ^ fl_lds_load4(win32, Q + off);
+                        const uint64_t diff = __ballot(x != 0);
+                        uint32_t lcp;
+                        if (diff) {
+                            const uint32_t fl_ = (uint32_t)__builtin_ctzll(diff);
+                            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl_);
+                            lcp = 4u * fl_ + ((uint32_t)__builtin_ctz(xf) >> 3);
+                        } else if (ML > 256u) {  // bytes 256, 257 (FL_MAX_MATCH = 258)
+                            const uint32_t xt = fl_lds_load4(win32, P + 256u) ^ fl_lds_load4(win32, Q + 256u);
+                            lcp = 256u + (xt ? ((uint32_t)__builtin_ctz(xt) >> 3) : 4u);
+                        } else {
+                            lcp = ML;
+                        }
+                        lcp = min(lcp, ML);
+                        if (lane == l) {
+                            const uint32_t kc = (lcp << 16) | (q_l + cp);
+                            if (lcp >= FL_MIN_MATCH && kc > key) {  // deflate.zig:254-261
+                                key = kc;
+                                pb = fl_lds_load4(win32, p + lcp - 3);
+                                if (lcp >= maxlen || lcp >= nice) {  // nothing longer possible / stop looking
+                                    n = 0;
+                                    lov = 0x7fffffffu;
+                                    dmask = 0;
+                                }
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if (dmask) {
+                    const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
+                    dmask &= ~(1u << b);
+                    const uint32_t t = kdone - b;
+                    const uint32_t q = ts[FL_KB + lane - t];
+                    const uint32_t best = key >> 16;
+                    // SlidingWindow.zig:91-98: a candidate that does not extend the best match is
+                    // dropped on one compare
+                    bool take = maxlen > best;
+                    if (take && best >= 8) take = fl_lds_load4(win32, q + best - 3) == pb;
+                    // (a filtered candidate's prefix has not been looked at: compare from the first byte;
+                    // fewer than 4 equal bytes -- another 4-gram of the bucket, or another bucket -- is no match)
+                    const bool filtered = (fcand >> (t - 1u)) & 1u;
+                    if (take) {
+                        const uint32_t le = fl_extend_len(win32, p, q, filtered ? 0u : 8u, maxlen);
+                        const uint32_t kc = (le << 16) | (q + cp);
+                        if (le >= FL_MIN_MATCH && kc > key) {  // deflate.zig:254-261
+                            key = kc;
+                            pb = fl_lds_load4(win32, p + le - 3);
+                            if (le >= maxlen || le >= nice) {  // nothing longer possible / stop looking
+                                n = 0;
+                                lov = 0x7fffffffu;
+                                dmask = 0;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        auto flush_deep_plain = [&]() {
             if (maxlen <= 8 || (prm.dbg & 4)) dmask = 0;  // (4: timing experiment, wrong output)
             while (__any(dmask != 0)) {
                 if (dmask) {
@@ -629,6 +762,12 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 }
             }
         };
+        auto flush_deep_bf = [&]() {
+            if (RJ)
+                flush_deep_rj();
+            else
+                flush_deep_plain();
+        };
         // the tile's winner meets the key, then the 8-byte candidates meet the window
         auto tile_end_bf = [&]() {
             if (__any(bb != 0)) {
@@ -653,6 +792,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         for (uint32_t kb = 0; kb < chain; kb += FL_KB) {
             if (!__any(n > kb)) break;
             kdone = 0;
+            fcand = 0;
             // tile = sorted entries [i0 - kb - FL_KB, i0 - kb + 64) with their first 8 bytes
             fl_lds_order();
             {
@@ -690,6 +830,25 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 if (!__any(n >= kb + kk0)) break;
                 tsp -= 4;
                 twp -= 4;
+                if (RJ && BF && runny && !(prm.dbg & 16384) &&
+                    __popcll(__ballot(n >= kb + kk0 && key < (8u << 16))) <= 8) {
+                    // (nearly) every lane that still walks holds a match of >= 8 bytes: filter (see above; the
+                    // few lanes with a shorter match filter on their byte number `best` just the same)
+                    const uint32_t bo = min(key >> 16, maxlen - 1u);
+                    const uint8_t* win8 = (const uint8_t*)win32;
+                    const uint32_t pbyte = win8[p + bo];
+                    fcand |= 0xfu << (kk0 - 1u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t q = tsp[3 - u];
+                        // (a lane whose walk has ended has lov = 0x7fffffff)
+                        const uint32_t s = (q >= lov && win8[q + bo] == pbyte) ? 0x80000000u : 0u;
+                        dmask = __builtin_amdgcn_alignbit(dmask, s, 31);
+                    }
+                    kdone = kk0 + 3;
+                    if ((kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) tile_end_bf();
+                    continue;
+                }
                 if (BF) {
                     // (the compiler turns the conditions into branches that skip the remaining loads of a
                     // candidate whose first four bytes differ; measured faster than forcing them straight)
@@ -708,7 +867,10 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     kdone = kk0 + 3;
                     // When most lanes are waiting for the window anyway (runs, long repeats), one round
                     // serves them all: do it now; a match of `nice` bytes then ends the walk early.
-                    if ((kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) tile_end_bf();  // (every 8 candidates)
+                    if ((kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) {  // (every 8 candidates)
+                        tile_end_bf();
+                        if (RJ) runny = true;
+                    }
                     continue;
                 }
 #pragma unroll

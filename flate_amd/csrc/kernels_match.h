@@ -64,23 +64,7 @@ struct fl_m2_wave {
 // exact common prefix of the window at p and q, known to be >= len0, capped at maxlen
 __device__ __forceinline__ uint32_t fl_extend_from(const uint32_t* win32, uint32_t p, uint32_t q, uint32_t len0,
                                                    uint32_t maxlen) {
-    uint32_t len = len0;
-    while (len < maxlen) {
-        uint32_t a0, a1, b0, b1;
-        fl_lds_load8(win32, p + len, a0, a1);
-        fl_lds_load8(win32, q + len, b0, b1);
-        const uint32_t y0 = a0 ^ b0, y1 = a1 ^ b1;
-        if (y0) {
-            len += (uint32_t)__builtin_ctz(y0) >> 3;
-            break;
-        }
-        if (y1) {
-            len += 4 + ((uint32_t)__builtin_ctz(y1) >> 3);
-            break;
-        }
-        len += 8;
-    }
-    return min(len, maxlen);
+    return fl_extend_len(win32, p, q, len0, maxlen);
 }
 
 // the walk of one lane (= one sorted entry)
