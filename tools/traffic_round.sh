@@ -14,15 +14,17 @@ python $R/tools/pmc_summary.py /tmp/tw /tmp/tw.json
 python - "$R/gpurun_out/${TAG}_hbm_traffic_1gib.json" <<'PY'
 import json, sys
 f = json.load(open('/tmp/tf.json')); w = json.load(open('/tmp/tw.json'))
-def per_launch(d, k, c):
-    return int(d[k]["counters"][c] / max(d[k]["dispatches"], 1) * 1024) if k in d and c in d[k].get("counters", {}) else None
+def per_step(d, k, c):  # the command runs ONE step: everything the kernel's launches of that step moved
+    return int(d[k]["counters"][c] * 1024) if k in d and c in d[k].get("counters", {}) else 0
 ks = {}
 for k in sorted(set(f) | set(w)):
-    name = k.split("<")[0]
-    ks[name] = {"fetch_bytes": per_launch(f, k, "FETCH_SIZE"), "write_bytes": per_launch(w, k, "WRITE_SIZE")}
+    name = k.split("<")[0]  # (template instantiations of one kernel -- k_lz_match plain / runny windows -- add up)
+    e = ks.setdefault(name, {"fetch_bytes": 0, "write_bytes": 0})
+    e["fetch_bytes"] += per_step(f, k, "FETCH_SIZE")
+    e["write_bytes"] += per_step(w, k, "WRITE_SIZE")
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes of `python bench.py --steps 1 --warmup 0 "
                "--no-cpu-baseline --no-extras --no-verify` (1 GiB text, level 6, 16385 chunks, plus the round-trip inflate). "
-               "Per launch, counter units of 1 KiB converted to bytes. gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+               "Per bench step (all launches of a kernel in that step added up), counter units of 1 KiB converted to bytes. gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
                "under-reports wide coalesced reads by 2x; these kernels mix narrow gathers and wide loads, so the read "
                "figure is a lower bound between 1x and 2x. Algorithmic bytes of the compress path: n_in + n_out = 1.50e9.",
        "workload": "text", "bytes_per_gpu": 1073741824, "mode": 6, "kernels": ks}
