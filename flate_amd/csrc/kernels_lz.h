@@ -232,14 +232,14 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
     __syncthreads();
     const uint32_t Ms = STREAM ? n_hashed : M;  // entries of the sorted array
     if (STREAM && tid == 0) n_sorted[c] = Ms;
-    // "runny" windows (one low hash digit holds an eighth of the positions: runs, padding, repeated
-    // records) go to the RJ variant of k_lz_match
+    // "runny" windows (one low hash digit holds a sixteenth of the positions: runs, padding, repeated
+    // records, short periods) go to the RJ variant of k_lz_match
     {
         bool big = false;
         if (tid < 256) {
             uint32_t t = 0;
             for (uint32_t w = 0; w < FL_SORT_WAVES; w++) t += cnt1[w][tid];
-            big = t >= max(Ms >> 3, 128u);
+            big = t >= max(Ms >> 4, 128u);
         }
         const int runny = __syncthreads_or(big && !(dbg & 65536));
         if (cflag != nullptr && tid == 0) cflag[c] = runny ? 2u : 0u;
@@ -415,8 +415,8 @@ __device__ __forceinline__ uint32_t fl_extend_match(const uint32_t* win32, uint3
 // position bound, a packed score "equal bytes, then nearest", a max, and one bit "agrees in all 8
 // prefix bytes"); only the tile's winner meets the lane's key, at the end of the tile.  Same
 // result: the key is a maximum.
-// RJ: the variant for windows k_lz_sort has marked "runny" (cflag 2: one hash digit holds an eighth of
-// the positions -- runs, padding, repeated records).  It adds the byte filter for groups of candidates
+// RJ: the variant for windows k_lz_sort has marked "runny" (cflag 2: one hash digit holds a sixteenth of
+// the positions -- runs, padding, repeated records, short periods).  It adds the byte filter for groups of candidates
 // and the wave-wide compare described at flush_deep_rj below; plain windows run the plain variant,
 // whose code these additions would slow by 10 % (measured on the benchmark text: 26.0 -> 28.9 ms).
 template <bool STREAM, bool BF, bool RJ = false>
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     kdone = kk0 + 3;
                     // When most lanes are waiting for the window anyway (runs, long repeats), one round
                     // serves them all: do it now; a match of `nice` bytes then ends the walk early.
-                    if ((kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) {  // (every 8 candidates)
+                    if ((RJ || (prm.dbg & 131072)) && (kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) {  // (every 8 candidates)
                         tile_end_bf();
                         if (RJ) runny = true;
                     }
