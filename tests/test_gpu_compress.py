@@ -512,3 +512,58 @@ def test_pinned_host_buffers_take_the_overlapped_path():
         assert res[0] == res[1]
         for i in (0, 5, 97, n - 1):
             assert res[1][i] == O.compress(data[int(off[i]): int(off[i + 1])].tobytes(), container, mode)
+
+
+def test_runny_windows_take_their_variant_and_match_the_oracle():
+    """Windows with runs, padding, short periods and repeated records (k_lz_sort marks them, k_lz_match<.., RJ>
+    filters groups of candidates on one byte and serves lone lanes with the whole wave): tokens == oracle at
+    every level, chunk path and whole-stream path."""
+    from flate_amd import synth
+    eng = engine()
+    rng = np.random.default_rng(4321)
+
+    def sparse(n, every, lo=0, hi=256):
+        z = np.zeros(n, dtype=np.uint8)
+        k = max(1, n // every)
+        z[rng.integers(0, n, k)] = rng.integers(lo, hi, k, dtype=np.uint8)
+        return z.tobytes()
+
+    def records(n):
+        rec = bytearray(rng.integers(0, 256, 48, dtype=np.uint8).tobytes())
+        out = bytearray()
+        i = 0
+        while len(out) < n:
+            r = bytearray(rec)
+            r[0:4] = int(i).to_bytes(4, "little")
+            r[20 + int(rng.integers(0, 8))] = int(rng.integers(0, 256))
+            out += r
+            i += 1
+        return bytes(out[:n])
+
+    text = synth.text(synth.SEED_TEXT + 17, 70000).tobytes()
+    cases = {
+        "sparse97": sparse(65535, 97), "sparse9": sparse(50000, 9), "sparse400": sparse(65535, 400),
+        "sparse_two_values": sparse(65535, 30, 1, 3),
+        "ab": (b"ab" * 33000)[:65535], "abc": (b"abc" * 22000)[:65535], "period5": (b"hello" * 13200)[:65535],
+        "period255": (bytes(range(255)) * 300)[:65535], "period300": (rng.integers(0, 256, 300, dtype=np.uint8).tobytes() * 230)[:65535],
+        "records48": records(65535),
+        "runs_of_runs": b"".join(bytes([int(v)]) * int(l) for v, l in zip(rng.integers(0, 4, 3000), rng.integers(1, 70, 3000)))[:65535],
+        "text_then_zeros_then_text": text[:20000] + bytes(25000) + text[20000:40535],
+        "tar_like": synth.tar_like(synth.SEED_TAR, 1 << 20)[300000:365535].tobytes(),
+    }
+    names = list(cases)
+    for level in (4, 5, 6, 7, 8, 9):
+        outs, st = eng.compress_many([cases[n] for n in names], O.RAW, level)
+        assert st == [0] * len(names)
+        for i, n in enumerate(names):
+            want = O.tokenize(cases[n], level)
+            got = eng.debug_tokens(i)
+            assert len(got) == len(want) and not (got != want).any(), (n, level)
+            assert outs[i] == O.compress(cases[n], O.RAW, level), (n, level)
+    # the same kinds of data as ONE stream each (tiles of the whole-stream path)
+    long_cases = [sparse(300000, 97), (b"abcdefg" * 40000), records(200000), bytes(70000) + sparse(150000, 50) + text]
+    for level in (4, 6, 9):
+        outs, st = eng.compress_many(long_cases, O.GZIP, level)
+        assert st == [0] * len(long_cases)
+        for d, o in zip(long_cases, outs):
+            assert o == O.compress(d, O.GZIP, level), level
