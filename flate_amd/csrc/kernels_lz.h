@@ -16,14 +16,15 @@
 //               position are its predecessors in its bucket, nearest first.
 //   k_lz_match  for EVERY position, the longest-match record the reference's findMatch
 //               would return, for the full chain budget and for chain >> 2
-//               (deflate.zig:241-245); window staged in LDS.
+//               (deflate.zig:241-245); window staged in LDS.  Two instantiations per path:
+//               plain windows, and windows the sort marks runny (runs, padding, records).
 //   k_lz_tok    the lazy-matching automaton (deflate.zig:154-205) as a function
 //               "anchor -> next anchor", resolved with pointer jumping instead of a
 //               serial walk; then the token list, per-block histograms and the block
 //               boundaries (32768 tokens, deflate.zig:227-230) by prefix sums over the anchors.
 //
-// Bounds: k_lz_match is bound by vector-ALU issue, the others by latency and by the traffic
-// of the per-position scratch arrays in HBM; no MFMA.
+// Bounds: k_lz_match and k_lz_tok are bound by vector-ALU issue, k_lz_sort by the CU's memory pipe
+// (one scattered gather and one scattered store per element) and issue; no MFMA.
 #pragma once
 #include "kernels_common.h"
 
@@ -968,7 +969,7 @@ __device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t 
 }
 
 // ------------------------------------------------------------------ k_lz_tok
-// k_lz_parse and k_lz_emit in one kernel (the default of the chunk path): the descriptors never
+// Parse and emit of the chunk path in one kernel (they were two until round 2): the descriptors never
 // leave the registers of the thread that computed them, so the 4-byte-per-position desc array is
 // neither written nor read back (it was read three times), the anchor bits stay in LDS, and the
 // chunk's bytes are staged once, a part at a time, for the literals.

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t fl_slides_before(uint32_t v, const uint32_t*
 }
 
 // ------------------------------------------------------------------ k_st_parse1
-// One workgroup per segment.  desc[] for every position (as k_lz_parse phase a), the pointer
+// One workgroup per segment.  desc[] for every position (as k_lz_tok phase a), the pointer
 // table jumped inside 256-position runs (phase b) saved to jmp[], and the exit map
 // exitmap[seg][e] = first anchor >= segment end on the path that enters at offset max(e, lo).
 __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse1(const fl_chunk* __restrict__ chunks,
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_st_stitch_c(const fl_piece* __restrict__
 }
 
 // ------------------------------------------------------------------ k_st_parse2
-// One workgroup per segment: anchors of the segment (k_lz_parse phases c-e) from its entry
+// One workgroup per segment: anchors of the segment (as k_lz_tok phases c-e) from its entry
 // anchor, and the number of tokens they emit.  marks_all was cleared by the host: segments of
 // neighbouring pieces may share a word.
 __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chunk* __restrict__ chunks,
