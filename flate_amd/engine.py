@@ -100,11 +100,25 @@ class Engine:
         return int(self._L.flate_hip_checksum_combine(container, a, b, len_b))
 
     def decompress_many(self, streams, container=0, flags=0, caps=None):
-        """streams: sequence of bytes-like.  caps: output capacity per stream (default: generous guess).
+        """streams: sequence of bytes-like.  caps: output capacity per stream.  Default: for gzip the ISIZE
+        field of the stream's last 8 bytes (container.zig:92-96) plus slack, and whatever then reports
+        OutputTooSmall (more members behind the first, a damaged footer) is decoded again with the worst
+        case of 1100 output bytes per input byte; raw / zlib streams get the worst case at once.
         Returns (list of bytes, list of status codes, list of consumed input bytes)."""
         n = len(streams)
         if n == 0:
             return [], [], []
+        if caps is None and container == 1:  # gzip
+            worst = [max(1 << 16, len(c) * 1100 + 1024) for c in streams]
+            guess = [min(w, int.from_bytes(bytes(c[-4:]), "little") + 64) if len(c) >= 18 else w
+                     for c, w in zip(streams, worst)]
+            res, st, cons = self.decompress_many(streams, container, flags, guess)
+            redo = [i for i in range(n) if st[i] == 100 and guess[i] < worst[i]]  # FLATE_HIP_ST_OUTPUT_TOO_SMALL
+            if redo:
+                r2, s2, c2 = self.decompress_many([streams[i] for i in redo], container, flags, [worst[i] for i in redo])
+                for k, i in enumerate(redo):
+                    res[i], st[i], cons[i] = r2[k], s2[k], c2[k]
+            return res, st, cons
         lens = np.array([len(c) for c in streams], dtype=np.uint64)
         in_off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(lens, out=in_off[1:])
