@@ -660,49 +660,52 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     // the end of the previous one: every candidate a byte longer than the last): the whole wave
                     // compares one pair at a time, lane l the bytes 4 l .. 4 l + 3 -- the common prefix
                     // in one step however long it is, instead of 8 bytes per trip on one lane.
-                    uint64_t rem = act;
-                    while (rem) {
+                    for (uint64_t rem = act; rem; rem &= rem - 1) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(rem);
-                        rem &= rem - 1;
-                        uint32_t q_l = 0, take_l = 0;
-                        if (lane == l) {
-                            const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
-                            dmask &= ~(1u << b);
-                            q_l = ts[FL_KB + lane - (kdone - b)];
-                            take_l = maxlen > (key >> 16) ? 1u : 0u;
-                        }
                         const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)l);
-                        const uint32_t Q = (uint32_t)__builtin_amdgcn_readlane((int)q_l, (int)l);
                         const uint32_t ML = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)l);
-                        if (!__builtin_amdgcn_readlane((int)take_l, (int)l)) continue;
                         const uint32_t off = 4u * lane;
-                        uint32_t x = 0;
-                        if (off < ML) x = fl_lds_load4(win32, P + off) ^ fl_lds_load4(win32, Q + off);
-                        const uint64_t diff = __ballot(x != 0);
-                        uint32_t lcp;
-                        if (diff) {
-                            const uint32_t fl_ = (uint32_t)__builtin_ctzll(diff);
-                            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl_);
-                            lcp = 4u * fl_ + ((uint32_t)__builtin_ctz(xf) >> 3);
-                        } else if (ML > 256u) {  // bytes 256, 257 (FL_MAX_MATCH = 258)
-                            const uint32_t xt = fl_lds_load4(win32, P + 256u) ^ fl_lds_load4(win32, Q + 256u);
-                            lcp = 256u + (xt ? ((uint32_t)__builtin_ctz(xt) >> 3) : 4u);
-                        } else {
-                            lcp = ML;
-                        }
-                        lcp = min(lcp, ML);
-                        if (lane == l) {
-                            const uint32_t kc = (lcp << 16) | (q_l + cp);
-                            if (lcp >= FL_MIN_MATCH && kc > key) {  // deflate.zig:254-261
-                                key = kc;
-                                pb = fl_lds_load4(win32, p + lcp - 3);
-                                if (lcp >= maxlen || lcp >= nice) {  // nothing longer possible / stop looking
-                                    n = 0;
-                                    lov = 0x7fffffffu;
-                                    dmask = 0;
+                        const uint32_t pw = off < ML ? fl_lds_load4(win32, P + off) : 0u;  // p's bytes: once per lane served
+                        for (;;) {  // all of this lane's candidates before the next lane is served
+                            uint32_t q_l = ~0u;
+                            if (lane == l) {
+                                if (maxlen <= (key >> 16)) dmask = 0;  // nothing can beat the match it holds
+                                if (dmask) {
+                                    const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
+                                    dmask &= ~(1u << b);
+                                    q_l = ts[FL_KB + lane - (kdone - b)];
+                                }
+                            }
+                            const uint32_t Q = (uint32_t)__builtin_amdgcn_readlane((int)q_l, (int)l);
+                            if (Q == ~0u) break;
+                            uint32_t x = 0;
+                            if (off < ML) x = pw ^ fl_lds_load4(win32, Q + off);
+                            const uint64_t diff = __ballot(x != 0);
+                            uint32_t lcp;
+                            if (diff) {
+                                const uint32_t fl_ = (uint32_t)__builtin_ctzll(diff);
+                                const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl_);
+                                lcp = 4u * fl_ + ((uint32_t)__builtin_ctz(xf) >> 3);
+                            } else if (ML > 256u) {  // bytes 256, 257 (FL_MAX_MATCH = 258)
+                                const uint32_t xt = fl_lds_load4(win32, P + 256u) ^ fl_lds_load4(win32, Q + 256u);
+                                lcp = 256u + (xt ? ((uint32_t)__builtin_ctz(xt) >> 3) : 4u);
+                            } else {
+                                lcp = ML;
+                            }
+                            lcp = min(lcp, ML);
+                            if (lane == l) {
+                                const uint32_t kc = (lcp << 16) | (q_l + cp);
+                                if (lcp >= FL_MIN_MATCH && kc > key) {  // deflate.zig:254-261
+                                    key = kc;
+                                    if (lcp >= maxlen || lcp >= nice) {  // nothing longer possible / stop looking
+                                        n = 0;
+                                        lov = 0x7fffffffu;
+                                        dmask = 0;
+                                    }
                                 }
                             }
                         }
+                        if (lane == l && (key >> 16) >= 8u) pb = fl_lds_load4(win32, p + (key >> 16) - 3);
                     }
                     continue;
                 }
