@@ -1008,13 +1008,22 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     int32_t* d_status = status;
     uint64_t* d_consumed = consumed;
     uint64_t in_shift = 0, out_shift = 0;
+    bool pin_io = false;
     if (memkind == FLATE_HIP_MEM_HOST) {
         if ((rc = ensure(h, h->st_in, (in_hi - in_lo) + 16))) return rc;
         if ((rc = ensure(h, h->st_out, (out_hi - out_lo) + 16))) return rc;
         if ((rc = ensure(h, h->st_outlen, sizeof(uint64_t) * n_chunks))) return rc;
         if ((rc = ensure(h, h->st_status, sizeof(int32_t) * n_chunks))) return rc;
         if ((rc = ensure(h, h->st_consumed, sizeof(uint64_t) * n_chunks))) return rc;
-        if (in_hi > in_lo)
+        // Pinned host buffers whose output slots are not much larger than what goes in (a caller who knows
+        // the sizes): sub-batches with the copies on their own streams, as in compress_impl.  Otherwise one
+        // staged copy in, and only the produced bytes come back (copy_out_host).
+        pin_io = is_pinned_host(in + in_lo) && is_pinned_host(out + out_lo) &&
+                 (out_hi - out_lo) <= 64 * (in_hi - in_lo) + (1ull << 20) && n_chunks > 4 * host_pass_chunk_limit();
+        if (pin_io && ((!h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) ||
+                       (!h->s_out && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess)))
+            return FLATE_HIP_E_ALLOC;
+        if (in_hi > in_lo && !pin_io)
             HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
         d_in = (const uint8_t*)h->st_in.p;
         d_out = (uint8_t*)h->st_out.p;
@@ -1042,34 +1051,68 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     HIP_OK(h, hipStreamSynchronize(st));
     // Long streams of a batch that has few of them: a workgroup per stream (kernels_inflate_par.h).  It marks
     // what it does not finish (short streams, anything irregular) FL_PAR_REDO, and k_inflate takes those.
-    const int32_t* redo_only = nullptr;
+    bool use_par = false;
+    uint32_t par_min_bytes = 0;
     {
         const char* e = getenv("FLATE_HIP_INFLATE_PAR");  // 0: never; else the minimum stream size in bytes
         const uint32_t min_bytes = e ? (uint32_t)atoi(e) : 32768u;
         uint32_t n_big = 0;
         for (uint32_t i = 0; i < n_chunks; i++)  // long input, or an output slot that says the output is long
             n_big += (chunks[i].in_len >= min_bytes || chunks[i].out_cap >= 16ull * min_bytes) ? 1u : 0u;
-        if (min_bytes && n_big && n_big <= 2048u && !(flags & 1)) {
-            ProfScope ps(h, K_INFLATE_PAR);
-            hipLaunchKernelGGL(k_inflate_par, dim3(n_chunks), dim3(FP_THREADS), 0, st, d_in, (const fl_chunk*)h->chunks.p,
-                               container, flags, min_bytes, h->crc, d_out, d_outlen, d_status, d_consumed);
-            redo_only = d_status;
-        }
+        use_par = min_bytes && n_big && n_big <= 2048u && !(flags & 1);
+        par_min_bytes = min_bytes;
     }
-    {
-        ProfScope ps(h, K_INFLATE);
-        // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
-        // many streams: the small ring keeps 13 per CU in flight
-        const char* e = getenv("FLATE_HIP_INFLATE_RING");
-        const bool large = e ? atoi(e) >= (int)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // measured crossover
-        if (large)
-            hipLaunchKernelGGL(k_inflate<FL_INF_RING_LARGE>, dim3(n_chunks), dim3(64), 0, st, d_in,
-                               (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
-                               d_consumed, redo_only);
-        else
-            hipLaunchKernelGGL(k_inflate<FL_INF_RING_SMALL>, dim3(n_chunks), dim3(64), 0, st, d_in,
-                               (const fl_chunk*)h->chunks.p, container, flags, h->crc, d_out, d_outlen, d_status,
-                               d_consumed, redo_only);
+    // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
+    // many streams: the small ring keeps 13 per CU in flight
+    const char* ering = getenv("FLATE_HIP_INFLATE_RING");
+    const bool large = ering ? atoi(ering) >= (int)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // measured crossover
+    if (pin_io) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
+    // (a wave per stream: a sub-batch must still fill the chip -- 13 streams per CU -- or the kernel's latency per
+    // stream, not the copies, decides; measured: sub-batches of 1024 streams are slower than no overlap at all)
+    const uint32_t sub = pin_io ? 4u * (uint32_t)host_pass_chunk_limit() : n_chunks;
+    size_t pass_index = 0;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += sub, pass_index++) {
+        const uint32_t nc = std::min(sub, n_chunks - c0);
+        if (pin_io) {  // this sub-batch's input: in flight while the previous sub-batch is decoded
+            hipEvent_t ev_in;
+            if ((rc = xfer_event(h, 2 * pass_index, &ev_in))) return rc;
+            const uint64_t a = hin[c0], b = hin[c0 + nc];
+            if (b > a)
+                HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
+            HIP_OK(h, hipEventRecord(ev_in, h->s_in));
+            HIP_OK(h, hipStreamWaitEvent(st, ev_in, 0));
+        }
+        const fl_chunk* dch = (const fl_chunk*)h->chunks.p + c0;
+        // Long streams of a batch that has few of them: a workgroup per stream (kernels_inflate_par.h).  It marks
+        // what it does not finish (short streams, anything irregular) FL_PAR_REDO, and k_inflate takes those.
+        const int32_t* redo_only = nullptr;
+        if (use_par) {
+            ProfScope ps(h, K_INFLATE_PAR);
+            hipLaunchKernelGGL(k_inflate_par, dim3(nc), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, par_min_bytes,
+                               h->crc, d_out, d_outlen + c0, d_status + c0, d_consumed ? d_consumed + c0 : nullptr);
+            redo_only = d_status + c0;
+        }
+        {
+            ProfScope ps(h, K_INFLATE);
+            if (large)
+                hipLaunchKernelGGL(k_inflate<FL_INF_RING_LARGE>, dim3(nc), dim3(64), 0, st, d_in, dch, container, flags,
+                                   h->crc, d_out, d_outlen + c0, d_status + c0,
+                                   d_consumed ? d_consumed + c0 : nullptr, redo_only);
+            else
+                hipLaunchKernelGGL(k_inflate<FL_INF_RING_SMALL>, dim3(nc), dim3(64), 0, st, d_in, dch, container, flags,
+                                   h->crc, d_out, d_outlen + c0, d_status + c0,
+                                   d_consumed ? d_consumed + c0 : nullptr, redo_only);
+        }
+        HIP_OK(h, hipGetLastError());
+        if (pin_io) {  // this sub-batch's output slots go home while the next sub-batch is decoded
+            hipEvent_t ev_out;
+            if ((rc = xfer_event(h, 2 * pass_index + 1, &ev_out))) return rc;
+            HIP_OK(h, hipEventRecord(ev_out, st));
+            HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
+            const uint64_t a = hout[c0], b = hout[c0 + nc];
+            if (b > a)
+                HIP_OK(h, hipMemcpyAsync(out + a, d_out + (a - out_shift), b - a, hipMemcpyDeviceToHost, h->s_out));
+        }
     }
     HIP_OK(h, hipGetLastError());
     if (memkind == FLATE_HIP_MEM_HOST) {
@@ -1078,7 +1121,10 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         if (consumed)
             HIP_OK(h, hipMemcpyAsync(consumed, d_consumed, sizeof(uint64_t) * n_chunks, hipMemcpyDeviceToHost, st));
         HIP_OK(h, hipStreamSynchronize(st));
-        if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len))) return rc;
+        if (pin_io)
+            HIP_OK(h, hipStreamSynchronize(h->s_out));
+        else if ((rc = copy_out_host(h, d_out, d_outlen, n_chunks, hout, out_shift, out, out_len)))
+            return rc;
     } else if (h->sync) {
         HIP_OK(h, hipStreamSynchronize(st));
     }

@@ -512,6 +512,26 @@ def test_pinned_host_buffers_take_the_overlapped_path():
         assert res[0] == res[1]
         for i in (0, 5, 97, n - 1):
             assert res[1][i] == O.compress(data[int(off[i]): int(off[i + 1])].tobytes(), container, mode)
+        # and back: the streams packed back to back in pinned memory, outputs into pinned slots of the original sizes
+        lens = np.array([len(x) for x in res[1]], dtype=np.int64)
+        c_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(lens, out=c_off[1:].view(np.int64))
+        p_in = torch.zeros(int(c_off[-1]) + 8, dtype=torch.uint8).pin_memory()
+        p_in[: int(c_off[-1])] = torch.from_numpy(np.frombuffer(b"".join(res[1]), dtype=np.uint8).copy())
+        p_out = torch.zeros(len(data) + 8, dtype=torch.uint8).pin_memory()
+        dlen = np.zeros(n, dtype=np.uint64)
+        status = np.ones(n, dtype=np.int32)
+        cons = np.zeros(n, dtype=np.uint64)
+        os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = "256"  # (inflate overlaps in sub-batches of 4 x this many streams)
+        try:
+            rc = L.flate_hip_decompress_batch(eng._h, p_in.data_ptr(), c_off.ctypes.data, n, container, 0,
+                                              p_out.data_ptr(), off.ctypes.data, dlen.ctypes.data, status.ctypes.data,
+                                              cons.ctypes.data, _capi.MEM_HOST)
+        finally:
+            del os.environ["FLATE_HIP_HOST_PASS_CHUNKS"]
+        assert rc == 0 and not status.any()
+        assert np.array_equal(dlen.astype(np.int64), sizes) and np.array_equal(cons.astype(np.int64), lens)
+        assert np.array_equal(p_out.numpy()[: len(data)], data)
 
 
 def test_runny_windows_take_their_variant_and_match_the_oracle():
