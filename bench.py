@@ -293,9 +293,18 @@ def run_compress(args, torch, dist, eng, world, rank, device):
     n_in = job.n_in
     gather = None
     if dist is not None and not args.no_gather:
-        gather = sharded.OutputGather(world, rank, device, int(job.out_off_np[-1]), engine=eng)
         job.step()
-        gather.calibrate(job.out, job.out_off, job.out_len)  # one host sync, outside the timed region
+        for algo in (None, "all_gather"):  # grouped send/recv first; one padded all-gather if the backend refuses it
+            try:
+                gather = sharded.OutputGather(world, rank, device, int(job.out_off_np[-1]), engine=eng, algo=algo)
+                gather.calibrate(job.out, job.out_off, job.out_len)  # one host sync, outside the timed region
+                gather.run(job.out, job.out_off, job.out_len)
+                torch.cuda.synchronize()
+                break
+            except Exception as e:  # noqa: BLE001 -- reported, and the other exchange form is tried
+                sys.stderr.write("rank %d: output gather (%s) failed: %r\n" % (rank, algo or "p2p", e))
+                if algo == "all_gather":
+                    raise
 
     def step():
         job.step()
