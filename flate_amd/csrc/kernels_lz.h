@@ -1069,16 +1069,13 @@ __global__ __launch_bounds__(FL_TOK_THREADS, 8) void k_lz_tok(const uint8_t* __r
         for (int r = 0; r < (int)FL_TOK_R; r++) {
             const uint32_t p = span0 + r * 64 + lane;
             // record of p + 1: the next lane's, the next round's first lane's, or rx
-            uint2 rb;
-            rb.x = __shfl_down(ra[r].x, 1, 64);
-            rb.y = __shfl_down(ra[r].y, 1, 64);
+            // (DPP wave_shl:1 -- lane i reads lane i + 1; lane 63 keeps `old`: the value that follows the wave)
             const uint2 nf = ra[r + 1 < (int)FL_TOK_R ? r + 1 : r];
-            const uint32_t fx = r + 1 < (int)FL_TOK_R ? __shfl(nf.x, 0, 64) : rx.x;
-            const uint32_t fy = r + 1 < (int)FL_TOK_R ? __shfl(nf.y, 0, 64) : rx.y;
-            if (lane == 63) {
-                rb.x = fx;
-                rb.y = fy;
-            }
+            const uint32_t fx = r + 1 < (int)FL_TOK_R ? (uint32_t)__builtin_amdgcn_readfirstlane((int)nf.x) : rx.x;
+            const uint32_t fy = r + 1 < (int)FL_TOK_R ? (uint32_t)__builtin_amdgcn_readfirstlane((int)nf.y) : rx.y;
+            uint2 rb;
+            rb.x = (uint32_t)__builtin_amdgcn_update_dpp((int)fx, (int)ra[r].x, 0x130, 0xf, 0xf, false);
+            rb.y = (uint32_t)__builtin_amdgcn_update_dpp((int)fy, (int)ra[r].y, 0x130, 0xf, 0xf, false);
             uint32_t dd = 0, nx = 0xffffu;
             if (p < h1) {
                 dd = fl_anchor_desc(rec2, p, ra[r], rb, prm.good, prm.lazy);
