@@ -527,9 +527,9 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 const uint32_t i = slice0 + (r + u) * 64 + lane;
                 const bool valid = i < M;
                 const uint32_t h = valid ? fl_hash_le(fl_lds_load4(win32, sp[u])) : 0xffffffffu;
-                uint32_t hp = __shfl_up(h, 1, 64);
-                if (lane == 0) hp = hlast;
-                hlast = __shfl(h, 63, 64);
+                // (DPP wave_shr:1 -- lane i reads lane i - 1; lane 0 keeps `old`: the previous round's last hash)
+                const uint32_t hp = (uint32_t)__builtin_amdgcn_update_dpp((int)hlast, (int)h, 0x138, 0xf, 0xf, false);
+                hlast = (uint32_t)__builtin_amdgcn_readlane((int)h, 63);
                 // bucket start (encoded index + 1) at or before this lane: the highest start
                 // flag among lanes <= lane, else the one carried in from earlier rounds
                 const uint64_t starts = __ballot(valid && (i == 0 || h != hp));
