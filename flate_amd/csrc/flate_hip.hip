@@ -19,9 +19,7 @@
 #include "kernels_inflate.h"
 #include "kernels_inflate_par.h"
 #include "kernels_lz.h"
-#include "kernels_match.h"
-#include "kernels_match3.h"
-#include "kernels_chain.h"
+#include "kernels_parse.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -34,7 +32,8 @@ enum KernelId {
     K_LZ_SORT,
     K_LZ_MATCH,
     K_LZ_CHAIN,
-    K_LZ_WALK,
+    K_LZ_PARSE,
+    K_LZ_EMIT,
     K_LZ_TOK,
     K_ST_PARSE,
     K_ST_EMIT,
@@ -47,7 +46,7 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_chain", "k_lz_walk",
+                                           "k_lz_chain", "k_lz_parse", "k_lz_emit",
                                            "k_lz_tok", "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_gather"};
 
@@ -242,18 +241,6 @@ uint64_t stream_pass_byte_limit() {
     return 4096ull << 20;
 }
 
-// second-generation match finder: units of 4 candidates at level 4 (chain >> 2 = 4), else 8
-template <bool STREAM>
-void launch_match2(hipStream_t st, uint32_t n, int mode, const uint8_t* d_in, const fl_chunk* dch, const fl_tile* dti,
-                   const uint32_t* dfp, const uint32_t* nsorted, const fl_params& prm, const uint16_t* S, uint32_t* rec) {
-    if (mode == 4)
-        hipLaunchKernelGGL((k_lz_match2<STREAM, 4>), dim3(n), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp, nsorted,
-                           prm, S, rec);
-    else
-        hipLaunchKernelGGL((k_lz_match2<STREAM, 8>), dim3(n), dim3(FL_M2_THREADS), 0, st, d_in, dch, dti, dfp, nsorted,
-                           prm, S, rec);
-}
-
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
 // histograms and the block table for the shared back end.
 int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
@@ -308,31 +295,18 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             ProfScope ps(h, K_LZ_SORT);
             hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti, dfp,
                                (uint32_t*)h->nsorted.p, (uint16_t*)h->S.p,
-                               (prm.dbg & (2 | 64 | 2048 | 8192)) ? (uint32_t*)nullptr : (uint32_t*)h->cflag.p, prm.dbg);
+                               (uint32_t*)h->cflag.p, prm.dbg);
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
-            if (prm.chain <= FL_M3_BACK && (prm.dbg & 2048))  // rolling-buffer experiment (kernels_match3.h)
-                hipLaunchKernelGGL(k_lz_match3<true>, dim3(nt), dim3(FL_M3_THREADS), 0, st, d_in, dch, dti, dfp,
-                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
-            else if (!(prm.dbg & (2 | 64)))
-            {
-                const uint32_t* cf = (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p;
-                hipLaunchKernelGGL((k_lz_match<true, true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti,
-                                   dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p, cf);
-                if (cf)  // the tiles k_lz_sort marked runny
-                    hipLaunchKernelGGL((k_lz_match<true, true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                       dti, dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p,
-                                       (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
-            }
-            else if (prm.dbg & 2)
-                hipLaunchKernelGGL((k_lz_match<true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti, dfp,
-                                   (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p, (const uint32_t*)nullptr);
-            else
-                launch_match2<true>(st, nt, prm.mode, d_in, dch, dti, dfp, (const uint32_t*)h->nsorted.p, prm,
-                                    (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
+            const uint32_t* cf = (const uint32_t*)h->cflag.p;
+            hipLaunchKernelGGL((k_lz_match<true, true, false>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch, dti,
+                               dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                               (uint32_t*)h->rec.p, cf);
+            // the tiles k_lz_sort marked runny
+            hipLaunchKernelGGL((k_lz_match<true, true, true>), dim3(nt), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                               dti, dfp, (const uint32_t*)h->nsorted.p, prm, (const uint16_t*)h->S.p,
+                               (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
         }
     }
     if (nseg) {
@@ -458,9 +432,9 @@ int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind
 int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc) {
     int rc;
     const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
-    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;      // chain links
+    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
+    if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
     if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nc))) return rc;
@@ -519,58 +493,20 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     }
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc))) return rc;
-        if (prm.dbg & 128) {
-            // FLATE_HIP_DBG=128: hash chains walked by lanes (kernels_chain.h, an experiment that lost:
-            // DESIGN.md 4c); the chain array lives in the S buffer
-            {
-                ProfScope ps(h, K_LZ_CHAIN);
-                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p);
-            }
-            {
-                ProfScope ps(h, K_LZ_WALK);
-                hipLaunchKernelGGL(k_lz_walk, dim3(nc), dim3(FL_WALK_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
-            }
-        } else {
-            {
-                ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint16_t*)h->S.p,
-                                   (prm.dbg & (2 | 64 | 2048 | 8192)) ? (uint32_t*)nullptr : (uint32_t*)h->cflag.p, prm.dbg);
-            }
-            {
-                ProfScope ps(h, K_LZ_MATCH);
-                if (prm.chain <= FL_M3_BACK && (prm.dbg & 2048))  // rolling-buffer experiment (kernels_match3.h)
-                    hipLaunchKernelGGL(k_lz_match3<false>, dim3(nc), dim3(FL_M3_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->rec.p);
-                else if (!(prm.dbg & (2 | 64)))  // first-generation match finder, block scoring (the default)
-                {
-                    const uint32_t* cf = (prm.dbg & 8192) ? (const uint32_t*)nullptr : (const uint32_t*)h->cflag.p;
-                    hipLaunchKernelGGL((k_lz_match<false, true, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
-                    if (cf)  // the chunks k_lz_sort marked runny
-                        hipLaunchKernelGGL((k_lz_match<false, true, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in,
-                                           dch, (const fl_tile*)nullptr, (const uint32_t*)nullptr,
-                                           (const uint32_t*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                           (uint32_t*)h->rec.p, cf);
-                }
-                else if (prm.dbg & 2)  // first-generation match finder (A/B timing only)
-                    hipLaunchKernelGGL((k_lz_match<false, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                       (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                       (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p,
-                                       (const uint32_t*)nullptr);
-                else
-                    launch_match2<false>(st, nc, mode, d_in, dch, nullptr, nullptr, nullptr, prm, (const uint16_t*)h->S.p,
-                                         (uint32_t*)h->rec.p);
-            }
+        {
+            ProfScope ps(h, K_LZ_CHAIN);
+            hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p);
         }
         {
-            ProfScope ps(h, K_LZ_TOK);
-            hipLaunchKernelGGL(k_lz_tok, dim3(nc), dim3(FL_TOK_THREADS), 0, st, d_in, dch, prm,
-                               (const uint32_t*)h->rec.p, (uint32_t*)h->tokens.p, dhist, dpl, (uint32_t*)h->ntok.p);
+            ProfScope ps(h, K_LZ_PARSE);
+            hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
+                               (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_EMIT);
+            hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
+                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
+                               dpl, (uint32_t*)h->ntok.p);
         }
         h->dbg_pass_chunks = nc;
         h->dbg_first_chunk = c0;

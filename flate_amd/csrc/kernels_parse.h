@@ -1,0 +1,566 @@
+// kernels_parse.h -- the LZ77 tokenizer of the chunk path (levels 4..9, inputs of at most 65535 bytes),
+// round 3: demand driven.  The reference calls findMatch only where its lazy-matching automaton
+// actually goes (0.42 calls per byte of text, deflate.zig:154-205) and rejects most candidates on
+// one compare (SlidingWindow.zig:91-98); the round-2 kernels computed two records for EVERY position
+// (2 calls per byte, no reject).  Here the automaton itself runs on the GPU:
+//
+//   k_lz_chain  hash chains (Lookup.zig:23-51): prev[p] = nearest earlier position with the same
+//               hash, 0 = none.  They do not depend on the parse (every position is inserted exactly
+//               once, in ascending order: deflate.zig:207-211, 236), so one wave per chunk inserts
+//               64 consecutive positions per step into a head table in LDS.
+//   k_lz_parse  one workgroup per chunk, one LANE per 64-byte (or 32-byte) segment of the input.
+//               Phase 0: every lane runs the reference's automaton from the start of its segment as
+//               if that were a position visited with no pending match ("anchor") -- findMatch walks
+//               the chain in LDS exactly as deflate.zig:233-266 does, candidate after candidate, with
+//               the reference's early reject.  A parse started at an arbitrary position falls in step
+//               with the true parse within a few bytes (measured: 6 bytes on average, never more than
+//               128 on the benchmark text), because both are at an anchor whenever a token of each
+//               ends at the same position.  Stitch rounds: the true path is followed from segment to
+//               segment by pointer jumping over the lanes' exits; a segment the path enters at a
+//               position its lane did not visit is parsed again from there until it meets the lane's
+//               own anchors (or leaves the segment).  Rounds repeat until every segment on the path
+//               has been resolved for the entry it really gets -- at that point nothing is
+//               speculative any more: the marked anchors are exactly the reference's.
+//               Output: one descriptor per anchor (what it emits) and the bitmap of true anchors.
+//   k_lz_emit   tokens, per-block histograms and the 32768-token block cut (deflate.zig:213-230,
+//               268-288; block_writer.zig:444-462) by prefix sums over the anchors.
+//
+// LDS holds, per sub-pass, the window bytes and the chain links of every position a call of the
+// sub-pass can touch: targets [0, 49152) need positions [0, 49152 + 256 + 266), targets [49152, 65536)
+// need [16320, 65536) -- 3 bytes per position, 145 KiB, one workgroup per CU.
+//
+// Bounds: k_lz_parse is bound by vector-ALU issue and LDS latency (pointer chasing), k_lz_chain by
+// LDS latency of one wave; no MFMA (byte compares and pointer hops).
+#pragma once
+#include "kernels_common.h"
+#include "kernels_lz.h"
+
+// ------------------------------------------------------------------ k_lz_chain
+// One wave per chunk; LDS = the head table (64 KiB) + a 2 x 1 KiB staging buffer for the input.
+#define FL_CHAIN_STG_DW 264  // 1024 bytes + 16 (alignment shift) + 4 (hash of the last position) rounded up
+
+__global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
+                                                 uint16_t* __restrict__ prev_all) {
+    __shared__ uint16_t head[32768];
+    __shared__ uint32_t stg[2][FL_CHAIN_STG_DW];
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t N = ck.in_len;
+    const uint32_t Mpos = N >= 4 ? N - 3 : 0u;  // positions with 4 bytes left (Lookup.zig:24)
+    if (Mpos == 0) return;
+    const uint8_t* src = in + ck.in_off;
+    uint16_t* pv = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
+    const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
+    const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
+    {
+        uint4* h4 = (uint4*)head;
+        for (uint32_t i = lane; i < 4096; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs: granules
+    // 64 b .. 64 b + 65 (sh + 1023 + 3 < 1056 = 66 granules); lane l loads granule 64 b + l, lanes 0..1 two more
+    auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {
+        const uint32_t ga = 64 * b + lane, gb = 64 * b + 64 + lane;
+        g0 = ga < n_gran ? src16[ga] : make_uint4(0, 0, 0, 0);
+        g1 = (lane < 2 && gb < n_gran) ? src16[gb] : make_uint4(0, 0, 0, 0);
+    };
+    const uint32_t n_blocks = (Mpos + 1023) >> 10;
+    uint4 ga0, ga1, gb0, gb1;  // two blocks in flight
+    load_block(0, ga0, ga1);
+    if (n_blocks > 1) load_block(1, gb0, gb1);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint32_t* sb = stg[b & 1];
+        ((uint4*)sb)[lane] = ga0;
+        if (lane < 2) ((uint4*)sb)[64 + lane] = ga1;
+        ga0 = gb0;
+        ga1 = gb1;
+        if (b + 2 < n_blocks) load_block(b + 2, gb0, gb1);
+        fl_lds_order();
+#pragma unroll 4
+        for (uint32_t s = 0; s < 16; s++) {
+            const uint32_t p = (b << 10) + (s << 6) + lane;
+            const bool valid = p < Mpos;
+            const uint32_t off = (s << 6) + lane + sh;
+            const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
+            const uint32_t h = fl_hash_le(v);
+            uint32_t old = 0, chk = p;
+            if (valid) old = head[h];
+            fl_lds_order();
+            if (valid) head[h] = (uint16_t)p;
+            fl_lds_order();
+            if (valid) chk = head[h];
+            // lanes of this step that share a hash: whichever store won, the others see it
+            uint64_t dup = __ballot(chk != p);
+            while (dup) {
+                const uint32_t l0 = (uint32_t)__builtin_ctzll(dup);
+                const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)l0);
+                const uint64_t grp = __ballot(valid && h == hk);  // ascending lanes = ascending positions
+                const uint64_t below = grp & ((1ull << lane) - 1ull);
+                if (valid && h == hk) {
+                    if (below) old = (b << 10) + (s << 6) + 63u - (uint32_t)__builtin_clzll(below);
+                    if ((grp >> lane) == 1ull) head[h] = (uint16_t)p;  // the last one stays in the table
+                }
+                dup &= ~grp;
+            }
+            fl_lds_order();
+            if (valid) pv[p] = (uint16_t)old;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
+        }
+        fl_lds_order();
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_parse
+#define PZ_THREADS 768
+#define PZ_WAVES (PZ_THREADS / 64)
+#define PZ_TA 49152u     // targets of sub-pass A: [0, PZ_TA); sub-pass B: [PZ_TA, 65536)
+#define PZ_MARGIN 64u    // sub-pass B keeps this many positions more than the farthest candidate, so that relative position 0 is never one
+#define PZ_LOOK 256u     // the lazy calls of a sub-pass's last anchor go at most this far past its targets (lazy <= 258)
+#define PZ_PRV_N (PZ_TA + PZ_LOOK)                             // chain links per sub-pass (A: 49408, B: 49216)
+#define PZ_WIN_DW ((PZ_TA + PZ_LOOK + FL_MAX_MATCH + 30u) / 4u)  // window bytes per sub-pass, zero padded (A: 49680, B: 49232)
+#define PZ_NONE 0xffffu
+#define PZ_NOHIT 0xffffffffu
+#define PZ_DESC_LIT 0x40000000u  // descriptor of an anchor that emits one literal
+#define PZ_BURST 16              // chain steps between two visits of the slow block, at most
+#define PZ_NEED 16               // ... fewer when this many lanes wait for the slow block
+#define PZ_SEG_A 64u
+#define PZ_SEG_B 32u
+
+__device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off) {
+    const uint32_t* w = win32 + (off >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], off);
+}
+
+__global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __restrict__ in,
+                                                           const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                           const uint16_t* __restrict__ prev_all,
+                                                           uint32_t* __restrict__ desc_all,
+                                                           uint32_t* __restrict__ true_all) {
+    __shared__ uint32_t win32[PZ_WIN_DW];
+    __shared__ uint16_t prv[PZ_PRV_N];
+    __shared__ uint16_t tExg[PZ_THREADS];     // exit the path is assumed to take out of a segment
+    __shared__ uint16_t tNxt[2][PZ_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
+    __shared__ uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
+    __shared__ uint16_t tMark[PZ_THREADS];    // segment is on the path
+    __shared__ uint32_t sh_next_entry;
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = ck.in_len;
+    const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
+    const uint8_t* src = in + ck.in_off;
+    const uint16_t* pvg = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    uint32_t* descg = desc_all + ck.pos_off;
+    uint32_t* trueg = true_all + (ck.pos_off >> 5);
+    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+
+    for (uint32_t sub = 0; sub < 2; sub++) {
+        const uint32_t t0 = sub ? PZ_TA : 0u;
+        if (t0 >= N) break;
+        const uint32_t end = min(N, sub ? 65536u : PZ_TA);  // targets [t0, end)
+        const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
+        const uint32_t S = sub ? PZ_SEG_B : PZ_SEG_A;
+        const uint32_t lgS = sub ? 5u : 6u;
+        const uint32_t nseg = (end - t0 + S - 1) >> lgS;
+        const uint32_t Nr = N - r0;            // end of the input
+        const uint32_t endr = end - r0, t0r = t0 - r0;
+        if (sub) __syncthreads();  // the previous sub-pass is done with the LDS tables
+        // ---- stage window bytes and chain links
+        {
+            const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
+            for (uint32_t i = tid; i < PZ_WIN_DW; i += PZ_THREADS)
+                win32[i] = 4 * i < Nr ? fl_load_u32_clamped(src + r0, 4 * i, Nr) : 0u;
+            // two links per thread and step; relative to r0, 0 = none (also everything below r0)
+            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);  // r0 is even
+            uint32_t* prv2 = (uint32_t*)prv;
+            const uint32_t r0r0 = r0 | (r0 << 16);
+            for (uint32_t i = tid; i < PZ_PRV_N / 2; i += PZ_THREADS) {
+                const uint32_t pa = 2 * i + r0;  // absolute position of the low half
+                uint32_t v = 0;
+                if (2 * i < nb_pos) v = pv2[i];
+                if (pa >= Mpos) v &= 0xffff0000u;  // positions without a hash entry have no link (never written)
+                if (pa + 1 >= Mpos) v &= 0x0000ffffu;
+                // saturating 16-bit subtract of r0 from both halves
+                uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
+                lo16 = lo16 > r0 ? lo16 - r0 : 0u;
+                hi16 = hi16 > r0 ? hi16 - r0 : 0u;
+                (void)r0r0;
+                prv2[i] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const uint32_t y0 = sub ? sh_next_entry : 0u;  // the sub-pass is entered at this anchor (relative)
+        const uint32_t m = tid;                         // this lane's segment
+        const uint32_t seg0 = t0r + (m << lgS);
+        const uint32_t seg_end = min(seg0 + S, endr);
+        if (y0 >= endr) {  // the path jumps over the whole sub-pass
+            if (m < nseg) {
+                if (S == 64) {
+                    trueg[(seg0 + r0) >> 5] = 0u;
+                    if (seg0 + 32 < endr) trueg[((seg0 + r0) >> 5) + 1] = 0u;
+                } else {
+                    trueg[(seg0 + r0) >> 5] = 0u;
+                }
+            }
+            if (tid == 0) sh_next_entry = y0;
+            continue;
+        }
+        const uint32_t me = (y0 - t0r) >> lgS;
+        // per-segment state of the stitch
+        uint64_t A = 0, F = 0;        // anchors of the lane's own parse; of the parse from the entry
+        uint32_t X = seg_end;         // exit of the lane's own parse
+        uint32_t res_entry = PZ_NONE, res_exit = 0, Z = PZ_NONE;
+        bool marked = false;
+
+        for (uint32_t round = 0;; round++) {
+            // ---- what this lane parses in this round
+            uint32_t a = 0, stop_end = 0;
+            uint64_t stopmask = 0;
+            bool work = false;
+            uint32_t y_in = PZ_NONE;
+            if (round == 0) {
+                work = m < nseg && seg_end > y0;
+                a = (m == me) ? y0 : seg0;
+                stop_end = seg_end;
+            } else {
+                // the path, assuming every segment not resolved yet leaves through its own exit
+                if (m < nseg) {
+                    const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
+                    tExg[m] = (uint16_t)ex;
+                    tNxt[0][m] = (uint16_t)(ex >= endr ? nseg : ((ex - t0r) >> lgS));
+                    tMark[m] = m == me ? 1 : 0;
+                    tEnt[m] = m == me ? (uint16_t)y0 : (uint16_t)PZ_NONE;
+                }
+                __syncthreads();
+                uint32_t cur = 0;
+                for (uint32_t step = 0; (1u << step) < nseg; step++) {
+                    if (m < nseg) {
+                        const uint32_t n = tNxt[cur][m];
+                        if (n < nseg) {
+                            if (tMark[m]) tMark[n] = 1;
+                            tNxt[cur ^ 1][m] = tNxt[cur][n];
+                        } else {
+                            tNxt[cur ^ 1][m] = (uint16_t)nseg;
+                        }
+                    }
+                    __syncthreads();
+                    cur ^= 1;
+                }
+                marked = m < nseg && tMark[m] != 0;
+                uint32_t n0 = nseg;
+                if (marked) {
+                    const uint32_t ex = tExg[m];
+                    n0 = ex >= endr ? nseg : ((ex - t0r) >> lgS);
+                    if (n0 < nseg)
+                        tEnt[n0] = (uint16_t)ex;
+                    else
+                        sh_next_entry = ex;  // (relative to this sub-pass's r0; converted below)
+                }
+                __syncthreads();
+                if (marked) y_in = tEnt[m];
+                work = marked && y_in != res_entry;
+                if (!__syncthreads_or(work ? 1 : 0)) break;
+                a = y_in;
+                stop_end = seg_end;
+                stopmask = A;
+            }
+            // ---- the automaton (deflate.zig:154-205) from anchor a until the parse leaves the segment
+            // or (stitch rounds) steps on an anchor of the lane's own parse
+            uint64_t amask = 0;
+            bool done = !work || a >= stop_end || ((stopmask >> ((a - seg0) & 63u)) & 1ull);
+            uint32_t j = 0, plen = 0, pdist = 0;
+            uint32_t p = 0, q = 0, cnt = 0, lo = 1, best = 0, bdist = 0, maxlen = 0, off = 0, pref = 0;
+            uint32_t qh = PZ_NOHIT;
+#define PZ_START_CALL(PP, LL, BUDGET)                                          \
+    do {                                                                       \
+        p = (PP);                                                              \
+        best = (LL);                                                           \
+        bdist = 0;                                                             \
+        maxlen = min(Nr - p, (uint32_t)FL_MAX_MATCH);                          \
+        q = prv[p];                                                            \
+        lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
+        cnt = maxlen > best ? (BUDGET) : 0u;                                   \
+        off = best ? best - 3u : 0u;                                           \
+        pref = pz_lds4(win32, p + off);                                        \
+    } while (0)
+            if (!done) PZ_START_CALL(a, 0u, chain);
+            for (;;) {
+                // ---- fast steps: one chain candidate per step (deflate.zig:248-263), rejected on the four bytes
+                // that end at offset `best` (SlidingWindow.zig:91-98 tests one of them)
+#pragma unroll 1
+                for (int b = 0; b < PZ_BURST; b++) {
+                    const bool walk = !done && qh == PZ_NOHIT && q >= lo && cnt != 0;
+                    const uint64_t mw = __ballot(walk);
+                    const uint64_t need = __ballot(!done && !walk);
+                    if (mw == 0 || __popcll(need) >= PZ_NEED) break;
+                    if (walk) {
+                        const uint32_t w = pz_lds4(win32, q + off);
+                        const uint32_t nq = prv[q];
+                        if (w == pref) qh = q;
+                        q = nq;
+                        cnt--;
+                    }
+                }
+                // ---- slow block
+                if (!done) {
+                    if (qh != PZ_NOHIT) {
+                        // the candidate agrees where it must: its exact common prefix with p
+                        uint32_t l = 0;
+                        for (;;) {
+                            uint32_t a0, a1, b0, b1;
+                            fl_lds_load8(win32, p + l, a0, a1);
+                            fl_lds_load8(win32, qh + l, b0, b1);
+                            const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+                            if (x0) {
+                                l += (uint32_t)__builtin_ctz(x0) >> 3;
+                                break;
+                            }
+                            if (x1) {
+                                l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+                                break;
+                            }
+                            l += 8;
+                            if (l >= maxlen) break;
+                        }
+                        l = min(l, maxlen);
+                        if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
+                            best = l;
+                            bdist = p - qh;
+                            if (l >= nice || l >= maxlen) {
+                                cnt = 0;  // good enough / nothing longer possible
+                            } else {
+                                off = l - 3u;
+                                pref = pz_lds4(win32, p + off);
+                            }
+                        }
+                        qh = PZ_NOHIT;
+                    }
+                    // the call has ended: the automaton's next move (a run of literals in one go)
+#pragma unroll 1
+                    for (int it = 0; it < 8 && !done && !(q >= lo && cnt != 0); it++) {
+                        bool emit;
+                        if (bdist) {  // a match, longer than the pending one if there is one
+                            if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
+                            plen = best;
+                            pdist = bdist;
+                            emit = plen >= lazy;  // deflate.zig:171-173
+                        } else {
+                            emit = true;  // the pending match goes out (deflate.zig:182-184), or a literal
+                        }
+                        if (emit) {
+                            uint32_t desc = PZ_DESC_LIT, next = a + 1;
+                            if (plen) {
+                                desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
+                                next = a + j + plen;
+                            }
+                            descg[a + r0] = desc;
+                            amask |= 1ull << (a - seg0);
+                            a = next;
+                            j = 0;
+                            plen = 0;
+                            if (a >= stop_end || ((stopmask >> ((a - seg0) & 63u)) & 1ull))
+                                done = true;
+                            else
+                                PZ_START_CALL(a, 0u, chain);
+                        } else {
+                            // keep the match, look one position further (deflate.zig:174-178), in a quarter
+                            // of the chain if the match is good enough (deflate.zig:241-245)
+                            const uint32_t budget = plen >= good ? (chain >> 2) : chain;
+                            PZ_START_CALL(a + j + 1u, plen, budget);
+                        }
+                    }
+                }
+                if (__ballot(!done) == 0) break;
+            }
+#undef PZ_START_CALL
+            // ---- results of the round
+            if (round == 0) {
+                if (work) {
+                    A = amask;
+                    X = a;
+                    if (m == me) {  // the entry segment's own parse is the true one
+                        res_entry = y0;
+                        res_exit = a;
+                        Z = y0;
+                    }
+                }
+            } else if (work) {
+                F = amask;
+                res_entry = y_in;
+                if (a < seg_end) {  // met the lane's own parse at a
+                    Z = a;
+                    res_exit = X;
+                } else {
+                    Z = PZ_NONE;
+                    res_exit = a;
+                }
+            }
+        }
+        // ---- the true anchors of this sub-pass
+        if (m < nseg) {
+            uint64_t T = 0;
+            if (marked) {
+                T = F;
+                if (Z != PZ_NONE) T |= A & (~0ull << (Z - seg0));
+            }
+            if (S == 64) {
+                trueg[(seg0 + r0) >> 5] = (uint32_t)T;
+                if (seg0 + 32 < endr) trueg[((seg0 + r0) >> 5) + 1] = (uint32_t)(T >> 32);
+            } else {
+                trueg[(seg0 + r0) >> 5] = (uint32_t)T;
+            }
+        }
+        __syncthreads();
+        // the next sub-pass counts from its own r0
+        if (tid == 0 && sub == 0) sh_next_entry = sh_next_entry - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_emit
+// Tokens of a chunk from its true anchors.  The chunk is handled in parts of 8192 positions; wave w
+// owns positions [h0 + 512 w, h0 + 512 (w + 1)) of a part, 8 per lane; token offsets by DPP prefix
+// sums, literals from the staged part, per-block histograms (LDS atomics), block cut at 32768
+// tokens incl. the input slice a stored block would copy (deflate.zig:268-288: `rp` at the moment
+// the 32768th token is added).
+#define FL_EMITZ_THREADS 1024
+
+__global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* __restrict__ in,
+                                                                 const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                 const uint32_t* __restrict__ desc_all,
+                                                                 const uint32_t* __restrict__ true_all,
+                                                                 uint32_t* __restrict__ tokens_all,
+                                                                 uint32_t* __restrict__ hist_all,
+                                                                 fl_block_plan* __restrict__ plans,
+                                                                 uint32_t* __restrict__ ntok_all) {
+    __shared__ uint32_t winp[FL_TOK_WIN_DW];
+    __shared__ uint32_t hist[2][320];
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t v1_sh;
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fl_block_plan* plan0 = &plans[ck.first_block];
+    fl_block_plan* plan1 = &plans[ck.first_block + 1];
+    if (ck.skip) {
+        if (tid == 0) {
+            plan0->valid = 0;
+            plan1->valid = 0;
+            ntok_all[c] = 0;
+        }
+        return;
+    }
+    const uint32_t N = ck.in_len;
+    const uint8_t* src = in + ck.in_off;
+    const uint32_t* descg = desc_all + ck.pos_off;
+    const uint32_t* trueg = true_all + (ck.pos_off >> 5);
+    uint32_t* tokens = tokens_all + ck.pos_off;
+
+    for (uint32_t i = tid; i < 640; i += FL_EMITZ_THREADS) (&hist[0][0])[i] = 0;
+    if (tid == 0) v1_sh = N;
+    uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
+    for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
+        const uint32_t h1 = min(h0 + FL_TOK_PART, N);
+        const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
+        // the wave's 512 anchor bits (16 words), its descriptors
+        uint32_t tw = 0;
+        if (lane < 16 && span0 + 32 * lane < h1) tw = trueg[(span0 >> 5) + lane];
+        // d[r]: 0 = no anchor, PZ_DESC_LIT = one literal, else j literals and a match
+        uint32_t d[FL_TOK_R];
+#pragma unroll
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t p = span0 + r * 64 + lane;
+            const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r);
+            const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r + 1);
+            const uint64_t m64 = (uint64_t)wlo | ((uint64_t)whi << 32);
+            uint32_t dd = 0;
+            if (p < h1 && ((m64 >> lane) & 1ull)) dd = descg[p];
+            d[r] = dd;
+        }
+        // the part's bytes (+ lookahead for the literals of its last anchors), zero padded
+        {
+            const uint32_t nb = min(N - h0, FL_TOK_PART + FL_TOK_LOOK);
+            for (uint32_t i = tid; i < FL_TOK_WIN_DW; i += FL_EMITZ_THREADS)
+                winp[i] = 4 * i < nb ? fl_load_u32_clamped(src + h0, 4 * i, nb) : 0u;
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < (int)FL_TOK_R; r++) cnt += d[r] ? ((d[r] & PZ_DESC_LIT) ? 1u : ((d[r] >> 23) & 0xff) + 1u) : 0u;
+        cnt = fl_wave_sum(cnt);
+        if (lane == 0) wtot[wave] = cnt;
+        __syncthreads();
+        uint32_t run = run0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) run += wtot[w];
+            run0 += wtot[w];
+        }
+#pragma unroll 1  // (rolled: the descriptors rotate through d[0])
+        for (int r = 0; r < (int)FL_TOK_R; r++) {
+            const uint32_t p = span0 + r * 64 + lane;
+            const uint32_t q = p - h0;
+            const uint32_t d0r = d[0];
+#pragma unroll
+            for (int k = 0; k + 1 < (int)FL_TOK_R; k++) d[k] = d[k + 1];
+            d[FL_TOK_R - 1] = d0r;
+            const bool mk = d0r != 0;
+            const uint32_t dd = (d0r & PZ_DESC_LIT) ? 0u : d0r;
+            const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;  // literals of this anchor
+            const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
+            const uint32_t incl = fl_wave_incl_scan_dpp(nt);
+            uint32_t idx = run + incl - nt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+            for (uint32_t x = 0; x < nl; x++) {
+                const uint32_t byte = fl_win_byte(winp, q + x);
+                tokens[idx] = FL_TOK_LIT(byte);
+                atomicAdd(&hist[idx >> 15][byte], 1u);
+                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
+                idx++;
+            }
+            if (mk && dd) {
+                const uint32_t ll = (dd >> 15) & 0xff, d0 = dd & 0x7fff;
+                tokens[idx] = (1u << 23) | (ll << 15) | d0;
+                atomicAdd(&hist[idx >> 15][257 + fl_len_index(ll)], 1u);
+                atomicAdd(&hist[idx >> 15][286 + fl_dist_code(d0)], 1u);
+                // a match of at least `lazy` goes out at its own visit, a shorter one at the next
+                // (deflate.zig:171-173 vs 182-184); rp at that moment decides the Q1 input slice
+                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+            }
+        }
+        __syncthreads();  // wtot and winp are reused by the next part
+    }
+    // block boundaries (deflate.zig:227-230, 268-288) and histograms
+    const uint32_t total = run0;
+    const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
+    uint32_t* hg = hist_all + (uint64_t)ck.first_block * 320;
+    for (uint32_t i = tid; i < 640; i += FL_EMITZ_THREADS)
+        if (i < 320 * nblk) hg[i] = (&hist[0][0])[i];
+    if (tid == 0) {
+        ntok_all[c] = total;
+        const uint32_t v1 = v1_sh;
+        plan0->no_input = 0;
+        plan1->no_input = 0;
+        if (nblk == 1) {
+            plan0->valid = 1;
+            plan0->tok_start = 0;
+            plan0->tok_count = total;
+            plan0->in_start = 0;
+            plan0->in_len = N;
+            plan0->final_block = 1;
+            plan1->valid = 0;
+        } else {
+            plan0->valid = 1;
+            plan0->tok_start = 0;
+            plan0->tok_count = FL_MAX_TOKENS;
+            plan0->in_start = 0;
+            plan0->in_len = v1;
+            plan0->final_block = 0;
+            plan1->valid = 1;
+            plan1->tok_start = FL_MAX_TOKENS;
+            plan1->tok_count = total - FL_MAX_TOKENS;
+            plan1->in_start = v1;
+            plan1->in_len = N - v1;
+            plan1->final_block = 1;
+        }
+    }
+}

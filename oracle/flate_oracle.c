@@ -938,6 +938,12 @@ static uint16_t df_add_match(fo_deflate* d, uint32_t m) { /* deflate.zig:220-225
     d->has_prev_match = 0;
     return (uint16_t)(FO_TOK_LENLIT(m) + 3);
 }
+#ifdef FO_STATS /* tools/lz_stats.c: counters of the reference walk, never built into the oracle library */
+unsigned long long fo_stat_calls[3], fo_stat_cands[3], fo_stat_hist[3][14], fo_stat_lenhist[260], fo_stat_cmp8;
+#define FO_STAT(x) x
+#else
+#define FO_STAT(x)
+#endif
 /* deflate.zig:233-266 */
 static int df_find_match(fo_deflate* d, uint16_t pos, const uint8_t* lh, size_t lh_len,
                          uint16_t min_len, uint32_t* match_out) {
@@ -946,19 +952,26 @@ static int df_find_match(fo_deflate* d, uint16_t pos, const uint8_t* lh, size_t 
     int found = 0;
     size_t chain = d->level.chain;
     if (len >= d->level.good) chain >>= 2;
+    FO_STAT(int kind = min_len == 0 ? 0 : (min_len >= d->level.good ? 2 : 1); unsigned nc = 0; fo_stat_calls[kind]++;)
     while (prev_pos > 0 && chain > 0) {
         uint16_t distance = (uint16_t)(pos - prev_pos);
         if (distance > 32768) break;
+        FO_STAT(nc++;)
         uint16_t new_len = win_match_raw(d->win.buffer, d->win.wp, prev_pos, pos, len);
+        FO_STAT(if (new_len >= 8) fo_stat_cmp8++;)
         if (new_len > len) {
             *match_out = FO_TOK_MATCH(distance, new_len);
             found = 1;
-            if (new_len >= d->level.nice) return 1;
+            if (new_len >= d->level.nice) {
+                FO_STAT(fo_stat_cands[kind] += nc; { int b = 0; while ((1u << b) <= nc && b < 13) b++; fo_stat_hist[kind][b]++; })
+                return 1;
+            }
             len = new_len;
         }
         prev_pos = d->lookup.chain[prev_pos];
         chain--;
     }
+    FO_STAT(fo_stat_cands[kind] += nc; { int b = 0; while ((1u << b) <= nc && b < 13) b++; fo_stat_hist[kind][b]++; })
     return found;
 }
 /* deflate.zig:154-205 */
