@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflate_hip.so")
+# (FLATE_HIP_LIB: another build of the same library, e.g. one with tuning counters -- tools/ only)
+LIB_PATH = os.environ.get("FLATE_HIP_LIB") or os.path.join(_HERE, "lib", "libflate_hip.so")
 
 RAW, GZIP, ZLIB = 0, 1, 2
 MODE_STORE, MODE_HUFFMAN = 0, 1

@@ -36,12 +36,27 @@
 #include "kernels_lz.h"
 
 // ------------------------------------------------------------------ k_lz_chain
-// One wave per chunk; LDS = the head table (64 KiB) + a 2 x 1 KiB staging buffer for the input.
+// One wave per chunk; LDS = the head table (32768 x 16 bit = 64 KiB) + a 2 x 1 KiB staging buffer.
+// "Exchange head[h] with p" is one LDS instruction per 64 positions: DS_MSKOR_RTN_B32 (D = (D & ~mask) | value,
+// returns the old word) on the 32-bit word that holds two 16-bit heads.  Lanes that hit the same word in
+// one instruction are served in lane order and one wave's DS instructions in program order (measured:
+// tools/ubench/ub2.hip, profiles/r03_ubench.txt), which is the order of the reference's insertions, so the
+// value a lane gets back IS its chain link -- also for positions of one step that share a hash.  The
+// kernel does not rely on it: a lane that was overtaken receives a position above its own, and any such
+// lane makes the wave redo the chunk one position at a time.
 #define FL_CHAIN_STG_DW 264  // 1024 bytes + 16 (alignment shift) + 4 (hash of the last position) rounded up
+
+typedef __attribute__((address_space(3))) uint32_t fl_lds_u32;
+__device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_t mask, uint32_t value) {
+    uint32_t old;
+    fl_lds_u32* a = (fl_lds_u32*)lds_word;  // (the 32-bit LDS address)
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(old) : "v"(a), "v"(mask), "v"(value) : "memory");
+    return old;
+}
 
 __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
                                                  uint16_t* __restrict__ prev_all) {
-    __shared__ uint16_t head[32768];
+    __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
     __shared__ uint32_t stg[2][FL_CHAIN_STG_DW];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
@@ -56,7 +71,7 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
     const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
     {
-        uint4* h4 = (uint4*)head;
+        uint4* h4 = (uint4*)head32;
         for (uint32_t i = lane; i < 4096; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
     }
     // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs: granules
@@ -70,6 +85,7 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
     uint4 ga0, ga1, gb0, gb1;  // two blocks in flight
     load_block(0, ga0, ga1);
     if (n_blocks > 1) load_block(1, gb0, gb1);
+    bool overtaken = false;
     for (uint32_t b = 0; b < n_blocks; b++) {
         uint32_t* sb = stg[b & 1];
         ((uint4*)sb)[lane] = ga0;
@@ -78,41 +94,66 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
         ga1 = gb1;
         if (b + 2 < n_blocks) load_block(b + 2, gb0, gb1);
         fl_lds_order();
-#pragma unroll 4
+        // 16 steps of 64 positions: all exchanges are issued before the first result is looked at
+        uint32_t old[16];
+        uint32_t odd = 0;  // bit s: the hash of step s is odd (its head is the upper half of the word)
+#pragma unroll
         for (uint32_t s = 0; s < 16; s++) {
             const uint32_t p = (b << 10) + (s << 6) + lane;
-            const bool valid = p < Mpos;
             const uint32_t off = (s << 6) + lane + sh;
             const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
             const uint32_t h = fl_hash_le(v);
-            uint32_t old = 0, chk = p;
-            if (valid) old = head[h];
-            fl_lds_order();
-            if (valid) head[h] = (uint16_t)p;
-            fl_lds_order();
-            if (valid) chk = head[h];
-            // lanes of this step that share a hash: whichever store won, the others see it
-            uint64_t dup = __ballot(chk != p);
-            while (dup) {
-                const uint32_t l0 = (uint32_t)__builtin_ctzll(dup);
-                const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)l0);
-                const uint64_t grp = __ballot(valid && h == hk);  // ascending lanes = ascending positions
-                const uint64_t below = grp & ((1ull << lane) - 1ull);
-                if (valid && h == hk) {
-                    if (below) old = (b << 10) + (s << 6) + 63u - (uint32_t)__builtin_clzll(below);
-                    if ((grp >> lane) == 1ull) head[h] = (uint16_t)p;  // the last one stays in the table
-                }
-                dup &= ~grp;
+            const uint32_t hs = (h & 1u) << 4;
+            odd |= (h & 1u) << s;
+            // (no branch around the instruction: the compiler must not look at a result before the wait below)
+            const bool valid = p < Mpos;
+            uint32_t* word = &head32[valid ? (h >> 1) : 16384u + lane];
+            old[s] = fl_lds_mskor_rtn(word, valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+        }
+        // the results exist from here on (listed as operands so that no use of them is scheduled above the wait)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]),
+                       "+v"(old[7]), "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]), "+v"(old[12]),
+                       "+v"(old[13]), "+v"(old[14]), "+v"(old[15])
+                     :
+                     : "memory");
+        // the links: the half of the returned word this position's hash selects
+#pragma unroll
+        for (uint32_t s = 0; s < 16; s++) {
+            const uint32_t p = (b << 10) + (s << 6) + lane;
+            if (p < Mpos) {
+                const uint32_t o = ((odd >> s) & 1u) ? (old[s] >> 16) : (old[s] & 0xffffu);
+                overtaken = overtaken || o > p;
+                pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
             }
-            fl_lds_order();
-            if (valid) pv[p] = (uint16_t)old;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
         }
         fl_lds_order();
+    }
+#ifdef FL_CHAIN_FORCE_SLOW
+    overtaken = true;  // (test builds: exercise the fallback)
+#endif
+#ifdef FL_CHAIN_NO_FALLBACK
+    overtaken = false;  // (test builds: the fast path alone, tools/ubench/chain_test.hip)
+#endif
+    if (__any(overtaken)) {
+        // never seen on gfx950: one position at a time, by one lane (Lookup.zig:35-40 as written)
+        uint16_t* head16 = (uint16_t*)head32;
+        for (uint32_t i = lane; i < 16384; i += 64) head32[i] = 0;
+        fl_lds_order();
+        if (lane == 0) {
+            for (uint32_t p = 0; p < Mpos; p++) {
+                const uint32_t h = fl_hash_le(fl_load_u32_clamped(src, p, N));
+                pv[p] = head16[h];
+                head16[h] = (uint16_t)p;
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------ k_lz_parse
-#define PZ_THREADS 768
+#ifndef PZ_THREADS
+#define PZ_THREADS 1024
+#endif
 #define PZ_WAVES (PZ_THREADS / 64)
 #define PZ_TA 49152u     // targets of sub-pass A: [0, PZ_TA); sub-pass B: [PZ_TA, 65536)
 #define PZ_MARGIN 64u    // sub-pass B keeps this many positions more than the farthest candidate, so that relative position 0 is never one
@@ -122,23 +163,41 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
 #define PZ_NONE 0xffffu
 #define PZ_NOHIT 0xffffffffu
 #define PZ_DESC_LIT 0x40000000u  // descriptor of an anchor that emits one literal
+#ifndef PZ_BURST
 #define PZ_BURST 16              // chain steps between two visits of the slow block, at most
-#define PZ_NEED 16               // ... fewer when this many lanes wait for the slow block
-#define PZ_SEG_A 64u
+#endif
+#ifndef PZ_NEED
+#define PZ_NEED 48               // ... fewer when this many lanes wait for the slow block
+#endif
+#ifndef PZ_UNROLL
+#define PZ_UNROLL 8               // chain steps between two looks at the other lanes
+#endif
+#ifndef PZ_TRANS_ITERS
+#define PZ_TRANS_ITERS 1         // automaton moves per lane and slow block (runs of literals)
+#endif
+#define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
 #define PZ_SEG_B 32u
+
+// tuning counters (compiled in with -DPZ_PROF; read with tools/parse_probe.py): per wave, summed over the grid
+#ifdef PZ_PROF
+#define PZ_CNT(var, v) (var) += (v)
+#else
+#define PZ_CNT(var, v)
+#endif
 
 __device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off) {
     const uint32_t* w = win32 + (off >> 2);
     return __builtin_amdgcn_alignbyte(w[1], w[0], off);
 }
 
-__global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const uint8_t* __restrict__ in,
                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                            const uint16_t* __restrict__ prev_all,
                                                            uint32_t* __restrict__ desc_all,
                                                            uint32_t* __restrict__ true_all) {
     __shared__ uint32_t win32[PZ_WIN_DW];
     __shared__ uint16_t prv[PZ_PRV_N];
+    __shared__ uint16_t tX[PZ_THREADS];       // exit of a lane's own parse, as soon as it is known
     __shared__ uint16_t tExg[PZ_THREADS];     // exit the path is assumed to take out of a segment
     __shared__ uint16_t tNxt[2][PZ_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
     __shared__ uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
@@ -155,6 +214,10 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
     uint32_t* descg = desc_all + ck.pos_off;
     uint32_t* trueg = true_all + (ck.pos_off >> 5);
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+#ifdef PZ_PROF
+    uint32_t c_fast = 0, c_walk = 0, c_slow = 0, c_meas = 0, c_measl = 0, c_trans = 0, c_transl = 0, c_rounds = 0, c_loops = 0;
+    uint64_t c_t0 = __builtin_readcyclecounter(), c_tspec = 0, c_tstitch = 0, c_tfast = 0, c_tmeas = 0, c_ttrans = 0;
+#endif
 
     for (uint32_t sub = 0; sub < 2; sub++) {
         const uint32_t t0 = sub ? PZ_TA : 0u;
@@ -162,8 +225,10 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
         const uint32_t end = min(N, sub ? 65536u : PZ_TA);  // targets [t0, end)
         const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
         const uint32_t S = sub ? PZ_SEG_B : PZ_SEG_A;
-        const uint32_t lgS = sub ? 5u : 6u;
-        const uint32_t nseg = (end - t0 + S - 1) >> lgS;
+        // segment of a relative target position x - t0r (< 65536): a shift, or a multiplication by 1 / 48
+        // (43691 / 2^21 = 1 / 47.99997: exact for arguments below 2^16)
+#define PZ_SEG_OF(D) (sub ? ((D) >> 5) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))
+        const uint32_t nseg = PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
         if (sub) __syncthreads();  // the previous sub-pass is done with the LDS tables
@@ -193,43 +258,46 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
         __syncthreads();
         const uint32_t y0 = sub ? sh_next_entry : 0u;  // the sub-pass is entered at this anchor (relative)
         const uint32_t m = tid;                         // this lane's segment
-        const uint32_t seg0 = t0r + (m << lgS);
+        const uint32_t seg0 = t0r + m * S;
         const uint32_t seg_end = min(seg0 + S, endr);
-        if (y0 >= endr) {  // the path jumps over the whole sub-pass
-            if (m < nseg) {
-                if (S == 64) {
-                    trueg[(seg0 + r0) >> 5] = 0u;
-                    if (seg0 + 32 < endr) trueg[((seg0 + r0) >> 5) + 1] = 0u;
-                } else {
-                    trueg[(seg0 + r0) >> 5] = 0u;
-                }
-            }
+        if (y0 >= endr) {  // the path jumps over the whole sub-pass: no anchors (the bitmap is zero already)
             if (tid == 0) sh_next_entry = y0;
             continue;
         }
-        const uint32_t me = (y0 - t0r) >> lgS;
+        const uint32_t me = PZ_SEG_OF(y0 - t0r);
         // per-segment state of the stitch
         uint64_t A = 0, F = 0;        // anchors of the lane's own parse; of the parse from the entry
         uint32_t X = seg_end;         // exit of the lane's own parse
         uint32_t res_entry = PZ_NONE, res_exit = 0, Z = PZ_NONE;
         bool marked = false;
+        if (m < PZ_THREADS) tX[m] = (uint16_t)PZ_NONE;
+        __syncthreads();
 
+        // Lane states.  Round 0: SPEC (the lane's own parse from the start of its segment), then WAIT until the
+        // lane before has published its exit, then FIX (the parse from that exit, if it lands in this segment
+        // on a position the own parse did not visit: almost always where the true path enters), then DONE.
+        // Later rounds: FIX from the entry the stitch has found, for the few segments where that guess was wrong.
+        enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
         for (uint32_t round = 0;; round++) {
-            // ---- what this lane parses in this round
-            uint32_t a = 0, stop_end = 0;
+            PZ_CNT(c_rounds, 1);
+#ifdef PZ_PROF
+            const uint64_t c_tr0 = __builtin_readcyclecounter();
+#endif
+            uint32_t st = ST_DONE;
+            uint32_t a = 0;
             uint64_t stopmask = 0;
-            bool work = false;
             uint32_t y_in = PZ_NONE;
             if (round == 0) {
-                work = m < nseg && seg_end > y0;
-                a = (m == me) ? y0 : seg0;
-                stop_end = seg_end;
+                if (m < nseg && seg_end > y0) {
+                    st = ST_SPEC;
+                    a = (m == me) ? y0 : seg0;
+                }
             } else {
                 // the path, assuming every segment not resolved yet leaves through its own exit
                 if (m < nseg) {
                     const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
                     tExg[m] = (uint16_t)ex;
-                    tNxt[0][m] = (uint16_t)(ex >= endr ? nseg : ((ex - t0r) >> lgS));
+                    tNxt[0][m] = (uint16_t)(ex >= endr ? nseg : PZ_SEG_OF(ex - t0r));
                     tMark[m] = m == me ? 1 : 0;
                     tEnt[m] = m == me ? (uint16_t)y0 : (uint16_t)PZ_NONE;
                 }
@@ -249,10 +317,9 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                     cur ^= 1;
                 }
                 marked = m < nseg && tMark[m] != 0;
-                uint32_t n0 = nseg;
                 if (marked) {
                     const uint32_t ex = tExg[m];
-                    n0 = ex >= endr ? nseg : ((ex - t0r) >> lgS);
+                    const uint32_t n0 = ex >= endr ? nseg : PZ_SEG_OF(ex - t0r);
                     if (n0 < nseg)
                         tEnt[n0] = (uint16_t)ex;
                     else
@@ -260,19 +327,20 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                 }
                 __syncthreads();
                 if (marked) y_in = tEnt[m];
-                work = marked && y_in != res_entry;
+                const bool work = marked && y_in != res_entry;
                 if (!__syncthreads_or(work ? 1 : 0)) break;
-                a = y_in;
-                stop_end = seg_end;
-                stopmask = A;
+                if (work) {
+                    st = ST_FIX;
+                    a = y_in;
+                    stopmask = A;
+                }
             }
-            // ---- the automaton (deflate.zig:154-205) from anchor a until the parse leaves the segment
-            // or (stitch rounds) steps on an anchor of the lane's own parse
+            // ---- the automaton (deflate.zig:154-205)
             uint64_t amask = 0;
-            bool done = !work || a >= stop_end || ((stopmask >> ((a - seg0) & 63u)) & 1ull);
             uint32_t j = 0, plen = 0, pdist = 0;
-            uint32_t p = 0, q = 0, cnt = 0, lo = 1, best = 0, bdist = 0, maxlen = 0, off = 0, pref = 0;
+            uint32_t p = 0, q = 0, cnt = 0, crem = 0, lo = 1, best = 0, bdist = 0, maxlen = 0, off = 0, pref = 0;
             uint32_t qh = PZ_NOHIT;
+            // cnt = candidates the current call may still look at, 0 when the lane is not walking a chain
 #define PZ_START_CALL(PP, LL, BUDGET)                                          \
     do {                                                                       \
         p = (PP);                                                              \
@@ -281,34 +349,65 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
         maxlen = min(Nr - p, (uint32_t)FL_MAX_MATCH);                          \
         q = prv[p];                                                            \
         lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
-        cnt = maxlen > best ? (BUDGET) : 0u;                                   \
+        cnt = (maxlen > best && q >= lo) ? (BUDGET) : 0u;                      \
         off = best ? best - 3u : 0u;                                           \
         pref = pz_lds4(win32, p + off);                                        \
     } while (0)
-            if (!done) PZ_START_CALL(a, 0u, chain);
+            // a parse that starts on a position where it has to stop already (FIX only)
+            if (st == ST_FIX && ((stopmask >> ((a - seg0) & 63u)) & 1ull)) {
+                F = 0;
+                res_entry = y_in;
+                Z = a;
+                res_exit = X;
+                st = ST_DONE;
+            }
+            if (st != ST_DONE) PZ_START_CALL(a, 0u, chain);
             for (;;) {
+                PZ_CNT(c_loops, 1);
+#ifdef PZ_PROF
+                const uint64_t c_ta = __builtin_readcyclecounter();
+#endif
+                const uint64_t alive = __ballot(st != ST_DONE);
+                if (alive == 0) break;
+                const uint64_t waiting = __ballot(st == ST_WAIT);
+                if (waiting == alive) __builtin_amdgcn_s_sleep(8);  // nothing to do but wait for another wave
+                const uint64_t serve = alive & ~waiting;              // (a waiting lane is polled when the others are served)
                 // ---- fast steps: one chain candidate per step (deflate.zig:248-263), rejected on the four bytes
                 // that end at offset `best` (SlidingWindow.zig:91-98 tests one of them)
 #pragma unroll 1
-                for (int b = 0; b < PZ_BURST; b++) {
-                    const bool walk = !done && qh == PZ_NOHIT && q >= lo && cnt != 0;
-                    const uint64_t mw = __ballot(walk);
-                    const uint64_t need = __ballot(!done && !walk);
-                    if (mw == 0 || __popcll(need) >= PZ_NEED) break;
-                    if (walk) {
-                        const uint32_t w = pz_lds4(win32, q + off);
-                        const uint32_t nq = prv[q];
-                        if (w == pref) qh = q;
-                        q = nq;
-                        cnt--;
+                for (int b = 0; b < PZ_BURST; b += PZ_UNROLL) {
+                    const uint64_t mw = __ballot(cnt != 0);
+                    if (mw == 0 || __popcll(serve & ~mw) >= PZ_NEED) break;
+                    PZ_CNT(c_fast, 1);
+                    PZ_CNT(c_walk, __popcll(mw));
+#pragma unroll
+                    for (int u = 0; u < PZ_UNROLL; u++) {
+                        if (cnt != 0) {
+                            const uint32_t w = pz_lds4(win32, q + off);
+                            const uint32_t nq = prv[q];
+                            const bool hit = w == pref;
+                            if (hit) {
+                                qh = q;
+                                crem = cnt - 1u;
+                            }
+                            q = nq;
+                            cnt = (hit || nq < lo) ? 0u : cnt - 1u;
+                        }
                     }
                 }
-                // ---- slow block
-                if (!done) {
+                // ---- slow block: lanes that are not walking
+#ifdef PZ_PROF
+                const uint64_t c_tb = __builtin_readcyclecounter();
+                c_tfast += c_tb - c_ta;
+#endif
+                PZ_CNT(c_slow, 1);
+                PZ_CNT(c_measl, __popcll(__ballot(st != ST_DONE && qh != PZ_NOHIT)));
+                if (st != ST_DONE && cnt == 0) {
                     if (qh != PZ_NOHIT) {
                         // the candidate agrees where it must: its exact common prefix with p
                         uint32_t l = 0;
                         for (;;) {
+                            PZ_CNT(c_meas, 1);
                             uint32_t a0, a1, b0, b1;
                             fl_lds_load8(win32, p + l, a0, a1);
                             fl_lds_load8(win32, qh + l, b0, b1);
@@ -325,11 +424,12 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                             if (l >= maxlen) break;
                         }
                         l = min(l, maxlen);
+                        cnt = q >= lo ? crem : 0u;            // the walk goes on behind the candidate ...
                         if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
                             best = l;
                             bdist = p - qh;
                             if (l >= nice || l >= maxlen) {
-                                cnt = 0;  // good enough / nothing longer possible
+                                cnt = 0;  // ... unless the match is good enough / nothing longer is possible
                             } else {
                                 off = l - 3u;
                                 pref = pz_lds4(win32, p + off);
@@ -337,9 +437,35 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                         }
                         qh = PZ_NOHIT;
                     }
-                    // the call has ended: the automaton's next move (a run of literals in one go)
+#ifdef PZ_PROF
+                    c_tmeas += __builtin_readcyclecounter() - c_tb;
+#endif
 #pragma unroll 1
-                    for (int it = 0; it < 8 && !done && !(q >= lo && cnt != 0); it++) {
+                    for (int it = 0; it < PZ_TRANS_ITERS && st != ST_DONE && cnt == 0; it++) {
+                        PZ_CNT(c_trans, 1);
+                        if (st == ST_WAIT) {
+                            // the lane before has finished its own parse: where does that leave this segment?
+                            const uint32_t v = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (v == PZ_NONE) break;
+                            st = ST_DONE;
+                            if (v >= seg0 && v < seg_end) {
+                                y_in = v;
+                                if ((A >> (v - seg0)) & 1ull) {  // on an anchor of the own parse
+                                    F = 0;
+                                    res_entry = v;
+                                    Z = v;
+                                    res_exit = X;
+                                } else {
+                                    st = ST_FIX;
+                                    a = v;
+                                    stopmask = A;
+                                    amask = 0;
+                                    PZ_START_CALL(a, 0u, chain);
+                                }
+                            }
+                            continue;
+                        }
+                        // the call has ended: the automaton's next move
                         bool emit;
                         if (bdist) {  // a match, longer than the pending one if there is one
                             if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
@@ -360,10 +486,32 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                             a = next;
                             j = 0;
                             plen = 0;
-                            if (a >= stop_end || ((stopmask >> ((a - seg0) & 63u)) & 1ull))
-                                done = true;
-                            else
+                            const bool meet = a < seg_end && ((stopmask >> ((a - seg0) & 63u)) & 1ull);
+                            if (a >= seg_end || meet) {
+                                // the parse leaves the segment or steps on an anchor of the lane's own parse
+                                if (st == ST_SPEC) {
+                                    A = amask;
+                                    X = a;
+                                    __hip_atomic_store(&tX[m], (uint16_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    amask = 0;
+                                    if (m == me) {  // the entry segment's own parse is the true one
+                                        res_entry = y0;
+                                        res_exit = a;
+                                        Z = y0;
+                                        st = ST_DONE;
+                                    } else {
+                                        st = ST_WAIT;
+                                    }
+                                } else {
+                                    F = amask;
+                                    res_entry = y_in;
+                                    Z = meet ? a : PZ_NONE;
+                                    res_exit = meet ? X : a;
+                                    st = ST_DONE;
+                                }
+                            } else {
                                 PZ_START_CALL(a, 0u, chain);
+                            }
                         } else {
                             // keep the match, look one position further (deflate.zig:174-178), in a quarter
                             // of the chain if the match is good enough (deflate.zig:241-245)
@@ -372,31 +520,14 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                         }
                     }
                 }
-                if (__ballot(!done) == 0) break;
+#ifdef PZ_PROF
+                c_ttrans += __builtin_readcyclecounter() - c_tb;
+#endif
             }
 #undef PZ_START_CALL
-            // ---- results of the round
-            if (round == 0) {
-                if (work) {
-                    A = amask;
-                    X = a;
-                    if (m == me) {  // the entry segment's own parse is the true one
-                        res_entry = y0;
-                        res_exit = a;
-                        Z = y0;
-                    }
-                }
-            } else if (work) {
-                F = amask;
-                res_entry = y_in;
-                if (a < seg_end) {  // met the lane's own parse at a
-                    Z = a;
-                    res_exit = X;
-                } else {
-                    Z = PZ_NONE;
-                    res_exit = a;
-                }
-            }
+#ifdef PZ_PROF
+            if (round == 0) c_tspec += __builtin_readcyclecounter() - c_tr0; else c_tstitch += __builtin_readcyclecounter() - c_tr0;
+#endif
         }
         // ---- the true anchors of this sub-pass
         if (m < nseg) {
@@ -405,17 +536,39 @@ __global__ __launch_bounds__(PZ_THREADS, 3) void k_lz_parse(const uint8_t* __res
                 T = F;
                 if (Z != PZ_NONE) T |= A & (~0ull << (Z - seg0));
             }
-            if (S == 64) {
-                trueg[(seg0 + r0) >> 5] = (uint32_t)T;
-                if (seg0 + 32 < endr) trueg[((seg0 + r0) >> 5) + 1] = (uint32_t)(T >> 32);
-            } else {
-                trueg[(seg0 + r0) >> 5] = (uint32_t)T;
-            }
+            // (OR into the bitmap the host has cleared: a segment need not start on a word boundary)
+            const uint32_t pa = seg0 + r0, sh = pa & 31u;
+            const uint64_t lo64 = T << sh;
+            const uint32_t w0 = (uint32_t)lo64, w1 = (uint32_t)(lo64 >> 32), w2 = sh ? (uint32_t)(T >> (64u - sh)) : 0u;
+            if (w0) atomicOr(&trueg[pa >> 5], w0);
+            if (w1) atomicOr(&trueg[(pa >> 5) + 1], w1);
+            if (w2) atomicOr(&trueg[(pa >> 5) + 2], w2);
         }
         __syncthreads();
         // the next sub-pass counts from its own r0
         if (tid == 0 && sub == 0) sh_next_entry = sh_next_entry - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);
     }
+#ifdef PZ_PROF
+    if ((tid & 63) == 0) {
+        // (c_meas / c_trans are per-lane counters of lane 0's view: only the wave-uniform ones are exact)
+        atomicAdd((unsigned long long*)&g_fl_prof[40], (unsigned long long)c_fast);
+        atomicAdd((unsigned long long*)&g_fl_prof[41], (unsigned long long)c_walk);
+        atomicAdd((unsigned long long*)&g_fl_prof[42], (unsigned long long)c_slow);
+        atomicAdd((unsigned long long*)&g_fl_prof[43], (unsigned long long)c_measl);
+        atomicAdd((unsigned long long*)&g_fl_prof[44], (unsigned long long)c_loops);
+        atomicAdd((unsigned long long*)&g_fl_prof[45], (unsigned long long)c_rounds);
+        atomicAdd((unsigned long long*)&g_fl_prof[46], (unsigned long long)c_tspec);
+        atomicAdd((unsigned long long*)&g_fl_prof[47], (unsigned long long)c_tstitch);
+        atomicAdd((unsigned long long*)&g_fl_prof[48], (unsigned long long)(__builtin_readcyclecounter() - c_t0));
+        atomicAdd((unsigned long long*)&g_fl_prof[49], 1ull);
+        atomicAdd((unsigned long long*)&g_fl_prof[50], (unsigned long long)c_tfast);
+        atomicAdd((unsigned long long*)&g_fl_prof[51], (unsigned long long)c_tmeas);
+        atomicAdd((unsigned long long*)&g_fl_prof[52], (unsigned long long)c_ttrans);
+        atomicAdd((unsigned long long*)&g_fl_prof[53], (unsigned long long)c_meas);
+        atomicAdd((unsigned long long*)&g_fl_prof[54], (unsigned long long)c_trans);
+    }
+    (void)c_meas; (void)c_trans; (void)c_transl;
+#endif
 }
 
 // ------------------------------------------------------------------ k_lz_emit

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Counters of k_lz_parse (library built with EXTRA=-DPZ_PROF): wave-level loop statistics per 64 KiB chunk.
+usage: FLATE_HIP_LIB=flate_amd/lib/libflate_hip_prof.so python tools/parse_probe.py [n_chunks] [level] [workload]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from flate_amd import Engine, synth
+
+n_chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+kind = sys.argv[3] if len(sys.argv) > 3 else "text"
+eng = Engine(0)
+nbytes = 65535 * n_chunks
+if kind == "text":
+    data = synth.text(synth.SEED_TEXT, nbytes)
+elif kind == "tar":
+    data = synth.tar_like(synth.SEED_TAR, nbytes)
+else:
+    data = synth.silesia_like(synth.SEED_SILESIA, nbytes)
+data = data.tobytes()
+chunks = [data[i:i + 65535] for i in range(0, len(data), 65535)]
+t0 = eng.phase_cycles().astype(np.int64)
+outs, st = eng.compress_many(chunks, 0, level)
+t = eng.phase_cycles().astype(np.int64) - t0
+nw = max(int(t[49]), 1)
+nc = len(chunks)
+print("chunks %d, waves %d" % (nc, nw))
+print("per chunk: fast steps %.0f (walking lanes %.1f of 64), slow blocks %.0f (lanes measured %.1f per block), outer loops %.0f, rounds %.2f"
+      % (t[40] / nc, t[41] / max(t[40], 1), t[42] / nc, t[43] / max(t[42], 1), t[44] / nc, t[45] / nw))
+print("per wave cycles: total %.0f, speculative phase %.0f, stitch rounds %.0f" % (t[48] / nw, t[46] / nw, t[47] / nw))
+print("cycles per fast step+share of slow: %.1f" % (t[46] / max(t[40], 1)))
+print("per wave cycles: fast loop %.0f, slow block %.0f (of which measure part, lanes that measure only: %.0f)" % (t[50] / nw, t[52] / nw, t[51] / nw))
+print("lane 0 of each wave: measure iterations %.1f, transitions %.1f per wave" % (t[53] / nw, t[54] / nw))
