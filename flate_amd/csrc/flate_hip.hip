@@ -295,7 +295,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             ProfScope ps(h, K_LZ_SORT);
             hipLaunchKernelGGL(k_lz_sort<true>, dim3(nt), dim3(FL_SORT_THREADS), 0, st, d_in, dch, dti, dfp,
                                (uint32_t*)h->nsorted.p, (uint16_t*)h->S.p,
-                               (uint32_t*)h->cflag.p, prm.dbg);
+                               (uint32_t*)h->cflag.p);
         }
         {
             ProfScope ps(h, K_LZ_MATCH);
@@ -429,12 +429,17 @@ int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind
 
 
 // workspace of a chunk-path pass of nc chunks (levels 4..9)
-int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc) {
+int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
     int rc;
     const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
-    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;      // chain links
-    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
-    if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
+    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;      // chain links / sorted positions
+    if (chain >= FL_BULK_MIN_CHAIN) {
+        if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
+    } else {
+        if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
+        if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
+    }
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
     if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nc))) return rc;
@@ -492,22 +497,53 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
         hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, dcks);
     }
     if (mode >= 4) {
-        if ((rc = ensure_lz_workspace(h, nc))) return rc;
-        {
-            ProfScope ps(h, K_LZ_CHAIN);
-            hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p);
-        }
-        HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // k_lz_parse ORs the anchors in
-        {
-            ProfScope ps(h, K_LZ_PARSE);
-            hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
-                               (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
-        }
-        {
-            ProfScope ps(h, K_LZ_EMIT);
-            hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
-                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
-                               dpl, (uint32_t*)h->ntok.p);
+        if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
+        if (prm.chain >= FL_BULK_MIN_CHAIN) {
+            // levels 8 and 9 (chains of 1024 / 4096 candidates): the match finder that evaluates every position in
+            // hash order, 64 positions of a bucket at a time (kernels_lz.h) -- a lane walking 4096 links on its
+            // own, as the demand-driven parse below would, keeps its whole workgroup waiting
+            {
+                ProfScope ps(h, K_LZ_SORT);
+                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                   (uint16_t*)h->S.p, (uint32_t*)h->cflag.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_MATCH);
+                const uint32_t* cf = (const uint32_t*)h->cflag.p;
+                hipLaunchKernelGGL((k_lz_match<false, true, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
+                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
+                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
+                // the chunks k_lz_sort marked runny
+                hipLaunchKernelGGL((k_lz_match<false, true, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in,
+                                   dch, (const fl_tile*)nullptr, (const uint32_t*)nullptr,
+                                   (const uint32_t*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
+                                   (uint32_t*)h->rec.p, cf);
+            }
+            {
+                ProfScope ps(h, K_LZ_TOK);
+                hipLaunchKernelGGL(k_lz_tok, dim3(nc), dim3(FL_TOK_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint32_t*)h->rec.p, (uint32_t*)h->tokens.p, dhist, dpl, (uint32_t*)h->ntok.p);
+            }
+        } else {
+            // levels 4..7: hash chains, the reference's automaton per segment, tokens (kernels_parse.h)
+            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // k_lz_parse ORs the anchors in
+            {
+                ProfScope ps(h, K_LZ_CHAIN);
+                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p,
+                                   (uint32_t*)h->cflag.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_PARSE);
+                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_EMIT);
+                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
+                                   dpl, (uint32_t*)h->ntok.p);
+            }
         }
         h->dbg_pass_chunks = nc;
         h->dbg_first_chunk = c0;
@@ -664,7 +700,6 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
     prm.container = container;
     prm.mode = mode;
-    prm.dbg = getenv("FLATE_HIP_DBG") ? (uint32_t)atoi(getenv("FLATE_HIP_DBG")) : 0u;
     hipStream_t st = h->stream;
 
     std::vector<uint64_t> hin_, hout_;
@@ -839,12 +874,15 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             pp.nc = nc;
             pp.nb = nb;
             if (hipMalloc(&pp.chunks, sizeof(fl_chunk) * nc) != hipSuccess ||
-                hipMalloc(&pp.blk_chunk, sizeof(uint32_t) * std::max(nb, 1u)) != hipSuccess)
+                hipMalloc(&pp.blk_chunk, sizeof(uint32_t) * std::max(nb, 1u)) != hipSuccess) {
+                if (pp.chunks) (void)hipFree(pp.chunks);
+                if (pp.blk_chunk) (void)hipFree(pp.blk_chunk);
                 return FLATE_HIP_E_ALLOC;
+            }
+            pl->passes.push_back(pp);  // the plan owns the tables from here on (flate_hip_plan_destroy frees them)
             HIP_OK(h, hipMemcpy(pp.chunks, h->chunks.p, sizeof(fl_chunk) * nc, hipMemcpyDeviceToDevice));
             HIP_OK(h, hipMemcpy(pp.blk_chunk, h->blk_chunk.p, sizeof(uint32_t) * nb, hipMemcpyDeviceToDevice));
-            pl->passes.push_back(pp);
-            if (mode >= 4 && (rc = ensure_lz_workspace(h, nc))) return rc;
+            if (mode >= 4 && (rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
             continue;
         }
 

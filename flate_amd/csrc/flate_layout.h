@@ -73,7 +73,7 @@ struct fl_params {
     int32_t mode;       // 0 store, 1 huffman, 4..9
     // level args (deflate.zig:41-52)
     uint32_t good, lazy, nice, chain;
-    uint32_t dbg;     // tuning experiments only (FLATE_HIP_DBG), 0 in production
+    uint32_t pad0_;
     uint32_t stream;  // non-zero: whole-stream pass (kernels_stream.h)
     uint32_t plan_dynamic_only;  // debug seam only: plan token blocks as BlockWriter.dynamicBlock does
 };

@@ -158,8 +158,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
                                                               const fl_tile* __restrict__ tiles,
                                                               const uint32_t* __restrict__ fpts,
                                                               uint32_t* __restrict__ n_sorted,
-                                                              uint16_t* __restrict__ S, uint32_t* __restrict__ cflag,
-                                                              uint32_t dbg) {
+                                                              uint16_t* __restrict__ S, uint32_t* __restrict__ cflag) {
     __shared__ uint16_t tmp[65536];
     __shared__ uint32_t cnt1[FL_SORT_WAVES][256];
     __shared__ uint32_t cnt2[FL_SORT_WAVES][128];
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             for (uint32_t w = 0; w < FL_SORT_WAVES; w++) t += cnt1[w][tid];
             big = t >= max(Ms >> 4, 128u);
         }
-        const int runny = __syncthreads_or(big && !(dbg & 65536));
+        const int runny = __syncthreads_or(big);
         if (cflag != nullptr && tid == 0) cflag[c] = runny ? 2u : 0u;
     }
     fl_prof_mark(1);
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t e = slice0 + (r + 4 + u) * 64 + lane;
             const bool okn = r + 4 < FL_SORT_SLICE / 64 && e < Ms;
             ppn[u] = okn ? tmp[e] : 0;
-            a0n[u] = okn ? ((dbg & 1024) ? ppn[u] * 0x01010101u : fl_gather_u32(src, ppn[u], N)) : 0;
+            a0n[u] = okn ? fl_gather_u32(src, ppn[u], N) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
             const uint32_t d = fl_hash_le(a0[u]) >> 8;
             const uint64_t peers = fl_match_any<7>(d, __ballot(valid));
             const uint32_t rank = __popcll(peers & lt_mask), np = __popcll(peers);
-            if (valid) So[(dbg & 512) ? e : cnt2[wave][d] + rank] = (uint16_t)pp[u];
+            if (valid) So[cnt2[wave][d] + rank] = (uint16_t)pp[u];
             fl_lds_order();
             if (valid && rank == np - 1) cnt2[wave][d] += np;
             fl_lds_order();
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
         const uint32_t i0 = batch << 6, i = i0 + lane;
         const uint32_t p = nx_p;
         const bool active = i < M && (!STREAM || p >= tgt0);
-        uint32_t n = (active && !(prm.dbg & 8)) ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only; 8: timing experiment)
+        uint32_t n = active ? (nx_nq & 0xffff) : 0;  // candidates left to look at (loop bound only)
         // valid candidates: q >= 1 (position 0 is the chain's null, deflate.zig:248),
         // p - q <= 32768 (deflate.zig:250-251) and not beyond candidate n
         uint32_t lov = max(max(p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u, 1u), nx_nq >> 16);
@@ -651,11 +650,10 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
             // an 8-byte candidate of a lane that can match at most 8 bytes has nothing to add to its score
             // (a filtered one has no score yet: bit b of dmask = candidate kdone - b)
             if (maxlen <= 8) dmask &= (fcand && kdone) ? (__brev(fcand) >> (32u - kdone)) : 0u;
-            if (prm.dbg & 4) dmask = 0;  // (4: timing experiment, wrong output)
             for (;;) {
                 const uint64_t act = __ballot(dmask != 0);
                 if (!act) break;
-                if (__popcll(act) <= 2 && __any(__popc(dmask) >= 3) && !(prm.dbg & 32768)) {
+                if (__popcll(act) <= 2 && __any(__popc(dmask) >= 3)) {
                     // One or two lanes left, with several candidates (the start of a run walking back through
                     // the end of the previous one: every candidate a byte longer than the last): the whole wave
                     // compares one pair at a time, lane l the bytes 4 l .. 4 l + 3 -- the common prefix
@@ -739,7 +737,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
             }
         };
         auto flush_deep_plain = [&]() {
-            if (maxlen <= 8 || (prm.dbg & 4)) dmask = 0;  // (4: timing experiment, wrong output)
+            if (maxlen <= 8) dmask = 0;
             while (__any(dmask != 0)) {
                 if (dmask) {
                     const uint32_t b = 31u - (uint32_t)__builtin_clz(dmask);  // nearest first
@@ -834,7 +832,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                 if (!__any(n >= kb + kk0)) break;
                 tsp -= 4;
                 twp -= 4;
-                if (RJ && BF && runny && !(prm.dbg & 16384) &&
+                if (RJ && BF && runny &&
                     __popcll(__ballot(n >= kb + kk0 && key < (8u << 16))) <= 8) {
                     // (nearly) every lane that still walks holds a match of >= 8 bytes: filter (see above; the
                     // few lanes with a shorter match filter on their byte number `best` just the same)
@@ -871,7 +869,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
                     kdone = kk0 + 3;
                     // When most lanes are waiting for the window anyway (runs, long repeats), one round
                     // serves them all: do it now; a match of `nice` bytes then ends the walk early.
-                    if ((RJ || (prm.dbg & 131072)) && (kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) {  // (every 8 candidates)
+                    if (RJ && (kk0 & 7u) == 5u && __popcll(__ballot(dmask != 0)) >= 40) {  // (every 8 candidates)
                         tile_end_bf();
                         if (RJ) runny = true;
                     }
@@ -919,7 +917,7 @@ __global__ __launch_bounds__(FL_MATCH_THREADS, 8) void k_lz_match(const uint8_t*
             // key -> record: len << 16 | dist - 1, dist = 65535 - low half
             const uint32_t rf = (key >> 16) ? ((key & 0xffff0000u) | (0xfffeu - (key & 0xffffu))) : 0u;
             const uint32_t rq = (qkey >> 16) ? ((qkey & 0xffff0000u) | (0xfffeu - (qkey & 0xffffu))) : 0u;
-            rec2[(prm.dbg & 1) ? (i & 1023u) : p] = make_uint2(rf, rq);
+            rec2[p] = make_uint2(rf, rq);
         }
     }
     fl_prof_mark(11);

@@ -54,8 +54,11 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
     return old;
 }
 
+// Levels whose chain budget reaches this value keep the match finder of kernels_lz.h (flate_hip.hip).
+#define FL_BULK_MIN_CHAIN 1024u
+
 __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
-                                                 uint16_t* __restrict__ prev_all) {
+                                                 uint16_t* __restrict__ prev_all, uint32_t* __restrict__ cflag) {
     __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
     __shared__ uint32_t stg[2][FL_CHAIN_STG_DW];
     const uint32_t c = blockIdx.x;
@@ -64,12 +67,44 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
     const uint32_t lane = threadIdx.x;
     const uint32_t N = ck.in_len;
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;  // positions with 4 bytes left (Lookup.zig:24)
+    if (lane == 0) cflag[c] = 0u;
     if (Mpos == 0) return;
     const uint8_t* src = in + ck.in_off;
     uint16_t* pv = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
     const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
     const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
+    // A chunk of ONE repeated byte (a run of zeros, say) needs no chains: k_lz_parse writes its anchors directly
+    // (every position matches its predecessor over the whole lookahead).  Looked for granule by granule; the
+    // scan of an ordinary chunk ends in its first step.
+    if (N >= 64) {
+        const uint32_t b0 = src[0] * 0x01010101u;
+        bool same = true;
+        for (uint32_t g0 = 0; g0 < n_gran; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            if (g < n_gran) {
+                uint4 v = src16[g];
+                // bytes of the granule outside the chunk do not count
+                const int32_t first = (int32_t)(16 * g) - (int32_t)sh;  // chunk offset of the granule's byte 0
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) {
+                        const int32_t o = first + 4 * k + bb;
+                        if (o >= 0 && o < (int32_t)N) m |= 0xffu << (8 * bb);
+                    }
+                    same = same && ((w[k] ^ b0) & m) == 0;
+                }
+            }
+            if (__any(!same)) break;
+        }
+        if (!__any(!same)) {
+            if (lane == 0) cflag[c] = 1u;
+            return;
+        }
+    }
     {
         uint4* h4 = (uint4*)head32;
         for (uint32_t i = lane; i < 4096; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
@@ -193,6 +228,7 @@ __device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off)
 __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const uint8_t* __restrict__ in,
                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                            const uint16_t* __restrict__ prev_all,
+                                                           const uint32_t* __restrict__ cflag,
                                                            uint32_t* __restrict__ desc_all,
                                                            uint32_t* __restrict__ true_all) {
     __shared__ uint32_t win32[PZ_WIN_DW];
@@ -214,9 +250,42 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     uint32_t* descg = desc_all + ck.pos_off;
     uint32_t* trueg = true_all + (ck.pos_off >> 5);
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    if (cflag[c] == 1u) {
+        // The chunk is one repeated byte (k_lz_chain saw it and built no chains).  Positions 0 and 1 are
+        // literals (the only candidate of position 1 is position 0, the chain's null: deflate.zig:248); from
+        // position 2 on the nearest candidate is the position before, it matches over the whole lookahead,
+        // and a match that long ends the walk at every level (deflate.zig:254-258): anchors 2, 260, 518, ...
+        // each emit (min(258, N - a), distance 1); what is left behind the last match (< 4 bytes: no hash
+        // entry, Lookup.zig:24) goes out as literals.  A last match shorter than `lazy` waits for the next
+        // position, whose match is one byte shorter, and goes out unchanged (deflate.zig:182-184).
+        for (uint32_t k = tid; 2 + FL_MAX_MATCH * k < N || k < 1; k += PZ_THREADS) {
+            if (k == 0) {
+                uint32_t w = 0;
+                for (uint32_t p = 0; p < min(N, 2u); p++) {
+                    descg[p] = PZ_DESC_LIT;
+                    w |= 1u << p;
+                }
+                if (w) atomicOr(&trueg[0], w);
+            }
+            const uint32_t a = 2 + FL_MAX_MATCH * k;
+            if (a >= N) continue;
+            if (N - a >= FL_MIN_MATCH) {
+                const uint32_t len = min(N - a, (uint32_t)FL_MAX_MATCH);
+                descg[a] = 0x80000000u | ((len - 3u) << 15);  // j = 0, distance 1
+                atomicOr(&trueg[a >> 5], 1u << (a & 31u));
+                // (the next anchor is a + len: the next step's, or the end of the chunk)
+            } else {
+                for (uint32_t p = a; p < N; p++) {
+                    descg[p] = PZ_DESC_LIT;
+                    atomicOr(&trueg[p >> 5], 1u << (p & 31u));
+                }
+            }
+        }
+        return;
+    }
 #ifdef PZ_PROF
     uint32_t c_fast = 0, c_walk = 0, c_slow = 0, c_meas = 0, c_measl = 0, c_trans = 0, c_transl = 0, c_rounds = 0, c_loops = 0;
-    uint64_t c_t0 = __builtin_readcyclecounter(), c_tspec = 0, c_tstitch = 0, c_tfast = 0, c_tmeas = 0, c_ttrans = 0;
+    uint64_t c_t0 = __builtin_readcyclecounter(), c_tspec = 0, c_tstitch = 0, c_tfast = 0, c_tmeas = 0, c_ttrans = 0, c_tstage = 0, c_tjump = 0;
 #endif
 
     for (uint32_t sub = 0; sub < 2; sub++) {
@@ -232,30 +301,61 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
         if (sub) __syncthreads();  // the previous sub-pass is done with the LDS tables
-        // ---- stage window bytes and chain links
+        // ---- stage window bytes and chain links (loads in batches: one round of memory latency per batch)
+#ifdef PZ_PROF
+        const uint64_t c_ts0 = __builtin_readcyclecounter();
+#endif
         {
+            const uint32_t ash = (uint32_t)((uintptr_t)(src + r0) & 3);
+            const uint32_t* a32 = (const uint32_t*)(src + r0 - ash);
+            const uint32_t ndw = (Nr + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
+            constexpr uint32_t WB = 7;                 // 2 batches cover PZ_WIN_DW / PZ_THREADS dwords per thread
+            for (uint32_t base = 0; base < PZ_WIN_DW; base += WB * PZ_THREADS) {
+                uint32_t lo[WB], hi[WB];
+#pragma unroll
+                for (uint32_t u = 0; u < WB; u++) {
+                    const uint32_t i = base + u * PZ_THREADS + tid;
+                    lo[u] = i < ndw ? a32[i] : 0u;
+                    hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < WB; u++) {
+                    const uint32_t i = base + u * PZ_THREADS + tid;
+                    uint32_t v = __builtin_amdgcn_alignbyte(hi[u], lo[u], ash);
+                    if (4 * i + 4 > Nr) v = 4 * i < Nr ? (v & ((1u << (8 * (Nr - 4 * i))) - 1u)) : 0u;  // zero padding
+                    if (i < PZ_WIN_DW) win32[i] = v;
+                }
+            }
+            // two links per dword; relative to r0, 0 = none (also everything below r0)
             const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
-            for (uint32_t i = tid; i < PZ_WIN_DW; i += PZ_THREADS)
-                win32[i] = 4 * i < Nr ? fl_load_u32_clamped(src + r0, 4 * i, Nr) : 0u;
-            // two links per thread and step; relative to r0, 0 = none (also everything below r0)
-            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);  // r0 is even
+            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);    // r0 is even
             uint32_t* prv2 = (uint32_t*)prv;
-            const uint32_t r0r0 = r0 | (r0 << 16);
-            for (uint32_t i = tid; i < PZ_PRV_N / 2; i += PZ_THREADS) {
-                const uint32_t pa = 2 * i + r0;  // absolute position of the low half
-                uint32_t v = 0;
-                if (2 * i < nb_pos) v = pv2[i];
-                if (pa >= Mpos) v &= 0xffff0000u;  // positions without a hash entry have no link (never written)
-                if (pa + 1 >= Mpos) v &= 0x0000ffffu;
-                // saturating 16-bit subtract of r0 from both halves
-                uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
-                lo16 = lo16 > r0 ? lo16 - r0 : 0u;
-                hi16 = hi16 > r0 ? hi16 - r0 : 0u;
-                (void)r0r0;
-                prv2[i] = lo16 | (hi16 << 16);
+            constexpr uint32_t PB = 8;
+            for (uint32_t base = 0; base < PZ_PRV_N / 2; base += PB * PZ_THREADS) {
+                uint32_t lv[PB];
+#pragma unroll
+                for (uint32_t u = 0; u < PB; u++) {
+                    const uint32_t i = base + u * PZ_THREADS + tid;
+                    lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < PB; u++) {
+                    const uint32_t i = base + u * PZ_THREADS + tid;
+                    const uint32_t pa = 2 * i + r0;  // absolute position of the low half
+                    uint32_t v = lv[u];
+                    if (pa >= Mpos) v &= 0xffff0000u;  // positions without a hash entry have no link (never written)
+                    if (pa + 1 >= Mpos) v &= 0x0000ffffu;
+                    uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
+                    lo16 = lo16 > r0 ? lo16 - r0 : 0u;
+                    hi16 = hi16 > r0 ? hi16 - r0 : 0u;
+                    if (i < PZ_PRV_N / 2) prv2[i] = lo16 | (hi16 << 16);
+                }
             }
         }
         __syncthreads();
+#ifdef PZ_PROF
+        c_tstage += __builtin_readcyclecounter() - c_ts0;
+#endif
         const uint32_t y0 = sub ? sh_next_entry : 0u;  // the sub-pass is entered at this anchor (relative)
         const uint32_t m = tid;                         // this lane's segment
         const uint32_t seg0 = t0r + m * S;
@@ -328,6 +428,9 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 __syncthreads();
                 if (marked) y_in = tEnt[m];
                 const bool work = marked && y_in != res_entry;
+#ifdef PZ_PROF
+                c_tjump += __builtin_readcyclecounter() - c_tr0;
+#endif
                 if (!__syncthreads_or(work ? 1 : 0)) break;
                 if (work) {
                     st = ST_FIX;
@@ -566,6 +669,8 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         atomicAdd((unsigned long long*)&g_fl_prof[52], (unsigned long long)c_ttrans);
         atomicAdd((unsigned long long*)&g_fl_prof[53], (unsigned long long)c_meas);
         atomicAdd((unsigned long long*)&g_fl_prof[54], (unsigned long long)c_trans);
+        atomicAdd((unsigned long long*)&g_fl_prof[55], (unsigned long long)c_tstage);
+        atomicAdd((unsigned long long*)&g_fl_prof[56], (unsigned long long)c_tjump);
     }
     (void)c_meas; (void)c_trans; (void)c_transl;
 #endif
