@@ -483,18 +483,27 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                     if (mw == 0 || __popcll(serve & ~mw) >= PZ_NEED) break;
                     PZ_CNT(c_fast, 1);
                     PZ_CNT(c_walk, __popcll(mw));
+                    // (the loads of candidate k + 1 are issued as soon as its position is known, before candidate k
+                    // is judged: one LDS round trip per step on the critical path; a load past the end of a walk
+                    // reads position 0's entries and is dropped)
+                    {
+                        uint32_t w = pz_lds4(win32, q + off);
+                        uint32_t nq = prv[q];
 #pragma unroll
-                    for (int u = 0; u < PZ_UNROLL; u++) {
-                        if (cnt != 0) {
-                            const uint32_t w = pz_lds4(win32, q + off);
-                            const uint32_t nq = prv[q];
-                            const bool hit = w == pref;
-                            if (hit) {
-                                qh = q;
-                                crem = cnt - 1u;
+                        for (int u = 0; u < PZ_UNROLL; u++) {
+                            const uint32_t w2 = pz_lds4(win32, nq + off);
+                            const uint32_t nq2 = prv[nq];
+                            if (cnt != 0) {
+                                const bool hit = w == pref;
+                                if (hit) {
+                                    qh = q;
+                                    crem = cnt - 1u;
+                                }
+                                q = nq;
+                                cnt = (hit || nq < lo) ? 0u : cnt - 1u;
+                                w = w2;
+                                nq = nq2;
                             }
-                            q = nq;
-                            cnt = (hit || nq < lo) ? 0u : cnt - 1u;
                         }
                     }
                 }
@@ -543,84 +552,90 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #ifdef PZ_PROF
                     c_tmeas += __builtin_readcyclecounter() - c_tb;
 #endif
-#pragma unroll 1
-                    for (int it = 0; it < PZ_TRANS_ITERS && st != ST_DONE && cnt == 0; it++) {
+                    if (cnt == 0) {
                         PZ_CNT(c_trans, 1);
+                        // one move per lane and visit; every path through it ends in at most one new call
+                        bool start = false;
+                        uint32_t sp = 0, sl = 0, sb = chain;
                         if (st == ST_WAIT) {
                             // the lane before has finished its own parse: where does that leave this segment?
                             const uint32_t v = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (v == PZ_NONE) break;
-                            st = ST_DONE;
-                            if (v >= seg0 && v < seg_end) {
-                                y_in = v;
-                                if ((A >> (v - seg0)) & 1ull) {  // on an anchor of the own parse
-                                    F = 0;
-                                    res_entry = v;
-                                    Z = v;
-                                    res_exit = X;
-                                } else {
-                                    st = ST_FIX;
-                                    a = v;
-                                    stopmask = A;
-                                    amask = 0;
-                                    PZ_START_CALL(a, 0u, chain);
+                            if (v != PZ_NONE) {
+                                st = ST_DONE;
+                                if (v >= seg0 && v < seg_end) {
+                                    y_in = v;
+                                    if ((A >> (v - seg0)) & 1ull) {  // on an anchor of the own parse
+                                        F = 0;
+                                        res_entry = v;
+                                        Z = v;
+                                        res_exit = X;
+                                    } else {
+                                        st = ST_FIX;
+                                        a = v;
+                                        stopmask = A;
+                                        amask = 0;
+                                        start = true;
+                                        sp = v;
+                                    }
                                 }
                             }
-                            continue;
-                        }
-                        // the call has ended: the automaton's next move
-                        bool emit;
-                        if (bdist) {  // a match, longer than the pending one if there is one
-                            if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
-                            plen = best;
-                            pdist = bdist;
-                            emit = plen >= lazy;  // deflate.zig:171-173
                         } else {
-                            emit = true;  // the pending match goes out (deflate.zig:182-184), or a literal
-                        }
-                        if (emit) {
-                            uint32_t desc = PZ_DESC_LIT, next = a + 1;
-                            if (plen) {
-                                desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
-                                next = a + j + plen;
+                            // the call has ended: the automaton's next move
+                            bool emit = true;  // the pending match goes out (deflate.zig:182-184), or a literal
+                            if (bdist) {       // a match, longer than the pending one if there is one
+                                if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
+                                plen = best;
+                                pdist = bdist;
+                                emit = plen >= lazy;  // deflate.zig:171-173
                             }
-                            descg[a + r0] = desc;
-                            amask |= 1ull << (a - seg0);
-                            a = next;
-                            j = 0;
-                            plen = 0;
-                            const bool meet = a < seg_end && ((stopmask >> ((a - seg0) & 63u)) & 1ull);
-                            if (a >= seg_end || meet) {
-                                // the parse leaves the segment or steps on an anchor of the lane's own parse
-                                if (st == ST_SPEC) {
-                                    A = amask;
-                                    X = a;
-                                    __hip_atomic_store(&tX[m], (uint16_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    amask = 0;
-                                    if (m == me) {  // the entry segment's own parse is the true one
-                                        res_entry = y0;
-                                        res_exit = a;
-                                        Z = y0;
-                                        st = ST_DONE;
+                            if (emit) {
+                                uint32_t desc = PZ_DESC_LIT, next = a + 1;
+                                if (plen) {
+                                    desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
+                                    next = a + j + plen;
+                                }
+                                descg[a + r0] = desc;
+                                amask |= 1ull << (a - seg0);
+                                a = next;
+                                j = 0;
+                                plen = 0;
+                                const bool meet = a < seg_end && ((stopmask >> ((a - seg0) & 63u)) & 1ull);
+                                if (a >= seg_end || meet) {
+                                    // the parse leaves the segment or steps on an anchor of the lane's own parse
+                                    if (st == ST_SPEC) {
+                                        A = amask;
+                                        X = a;
+                                        __hip_atomic_store(&tX[m], (uint16_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        amask = 0;
+                                        if (m == me) {  // the entry segment's own parse is the true one
+                                            res_entry = y0;
+                                            res_exit = a;
+                                            Z = y0;
+                                            st = ST_DONE;
+                                        } else {
+                                            st = ST_WAIT;
+                                        }
                                     } else {
-                                        st = ST_WAIT;
+                                        F = amask;
+                                        res_entry = y_in;
+                                        Z = meet ? a : PZ_NONE;
+                                        res_exit = meet ? X : a;
+                                        st = ST_DONE;
                                     }
                                 } else {
-                                    F = amask;
-                                    res_entry = y_in;
-                                    Z = meet ? a : PZ_NONE;
-                                    res_exit = meet ? X : a;
-                                    st = ST_DONE;
+                                    start = true;
+                                    sp = a;
                                 }
                             } else {
-                                PZ_START_CALL(a, 0u, chain);
+                                // keep the match, look one position further (deflate.zig:174-178), in a quarter
+                                // of the chain if the match is good enough (deflate.zig:241-245)
+                                start = true;
+                                sp = a + j + 1u;
+                                sl = plen;
+                                sb = plen >= good ? (chain >> 2) : chain;
                             }
-                        } else {
-                            // keep the match, look one position further (deflate.zig:174-178), in a quarter
-                            // of the chain if the match is good enough (deflate.zig:241-245)
-                            const uint32_t budget = plen >= good ? (chain >> 2) : chain;
-                            PZ_START_CALL(a + j + 1u, plen, budget);
                         }
+                        if (start) PZ_START_CALL(sp, sl, sb);
                     }
                 }
 #ifdef PZ_PROF
