@@ -368,6 +368,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     return FLATE_HIP_OK;
 }
 
+// k_gather_copy: about 4096 workgroups whatever the number of streams (one long stream is cut into slices)
+dim3 gather_grid(uint32_t n) { return dim3(n, std::max(1u, std::min(1024u, 4096u / std::max(n, 1u)))); }
+
 // Host-buffer calls: bring back only what was produced.  The slots are sized for the worst case (an
 // inflate caller may reserve 1000x the input); when the produced bytes are a small part of the slot
 // range they are packed on the device first (k_scan_lens + k_gather_copy), cross PCIe once, and are put
@@ -398,7 +401,7 @@ int copy_out_host(flate_hip_ctx* h, const uint8_t* d_out, const uint64_t* d_outl
     for (uint32_t i = 0; i <= n; i++) slot[i] = hout[i] - out_shift;
     HIP_OK(h, hipMemcpyAsync(h->st_slot.p, slot.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, st, d_outlen, n, (uint64_t*)h->st_packoff.p);
-    hipLaunchKernelGGL(k_gather_copy, dim3(n), dim3(256), 0, st, d_out, (const uint64_t*)h->st_slot.p, d_outlen,
+    hipLaunchKernelGGL(k_gather_copy, gather_grid(n), dim3(256), 0, st, d_out, (const uint64_t*)h->st_slot.p, d_outlen,
                        (uint8_t*)h->st_pack.p, (const uint64_t*)h->st_packoff.p);
     HIP_OK(h, hipGetLastError());
     std::vector<uint8_t> packed(total);
@@ -1115,7 +1118,7 @@ int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint6
         ProfScope ps(h, K_GATHER);
         hipLaunchKernelGGL(k_scan_lens, dim3(1), dim3(1024), 0, st, out_len, n_chunks, dst_off);
         if (n_chunks)
-            hipLaunchKernelGGL(k_gather_copy, dim3(n_chunks), dim3(256), 0, st, out, out_off, out_len, dst,
+            hipLaunchKernelGGL(k_gather_copy, gather_grid(n_chunks), dim3(256), 0, st, out, out_off, out_len, dst,
                                (const uint64_t*)dst_off);
     }
     HIP_OK(h, hipGetLastError());

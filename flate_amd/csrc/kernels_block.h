@@ -672,8 +672,11 @@ __global__ __launch_bounds__(1024) void k_scan_lens(const uint64_t* __restrict__
     if (tid == 0) dst_off[n] = carry;
 }
 
-// one workgroup per stream: interior destination dwords from unaligned source loads,
-// the (at most 3 + 3) edge bytes one by one -- neighbouring streams never share a byte.
+// gridDim.y workgroups per stream, each over slices of 16 KiB taken round robin (a batch of a few long
+// streams fills the chip as well as one of many short ones): interior destination bytes as 16-byte
+// stores from unaligned source dwords, the (at most 15 + 15) edge bytes of the stream one by one --
+// neighbouring streams never share a byte.
+#define FL_GATHER_SLICE 16384u
 __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__ out,
                                                      const uint64_t* __restrict__ out_off,
                                                      const uint64_t* __restrict__ out_len,
@@ -682,11 +685,34 @@ __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__
     const uint64_t n = out_len[c];
     const uint8_t* s = out + out_off[c];
     uint8_t* d = dst + dst_off[c];
-    const uint64_t head = min(n, (uint64_t)((4 - ((uintptr_t)d & 3)) & 3));
-    if (tid < head) d[tid] = s[tid];
-    const uint64_t ndw = (n - head) >> 2;
-    uint32_t* d32 = (uint32_t*)(d + head);
-    for (uint64_t i = tid; i < ndw; i += 256) d32[i] = fl_load_u32_unaligned(s + head + 4 * i);
-    const uint64_t tail0 = head + 4 * ndw;
-    if (tail0 + tid < n) d[tail0 + tid] = s[tail0 + tid];
+    const uint64_t head = min(n, (uint64_t)((16 - ((uintptr_t)d & 15)) & 15));
+    const uint64_t nq = (n - head) >> 4;  // 16-byte units
+    const uint64_t tail0 = head + 16 * nq;
+    if (blockIdx.y == 0) {
+        if (tid < head) d[tid] = s[tid];
+        if (tid < 16 && tail0 + tid < n) d[tail0 + tid] = s[tail0 + tid];
+    }
+    uint4* d16 = (uint4*)(d + head);
+    const uint8_t* s0 = s + head;
+    const uint32_t sh = (uint32_t)((uintptr_t)s0 & 3);
+    const uint32_t* sa = (const uint32_t*)(s0 - sh);  // aligned dwords: unit i = dwords 4 i .. 4 i + 4 shifted by sh bytes
+    const uint64_t per = FL_GATHER_SLICE / 16;
+    for (uint64_t u0 = (uint64_t)blockIdx.y * per; u0 < nq; u0 += (uint64_t)gridDim.y * per) {
+        const uint64_t u1 = min(u0 + per, nq);
+        for (uint64_t i = u0 + tid; i < u1; i += 256) {
+            const uint32_t* w = sa + 4 * i;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            uint4 v;
+            if (sh) {
+                const uint32_t w4 = w[4];  // (holds bytes of this unit: inside the stream)
+                v.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                v.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+                v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+            } else {
+                v = make_uint4(w0, w1, w2, w3);
+            }
+            d16[i] = v;
+        }
+    }
 }
