@@ -533,7 +533,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // k_lz_parse ORs the anchors in
             {
                 ProfScope ps(h, K_LZ_CHAIN);
-                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64), 0, st, d_in, dch, (uint16_t*)h->S.p,
+                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
                                    (uint32_t*)h->cflag.p);
             }
             {

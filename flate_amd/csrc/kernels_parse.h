@@ -36,7 +36,7 @@
 #include "kernels_lz.h"
 
 // ------------------------------------------------------------------ k_lz_chain
-// One wave per chunk; LDS = the head table (32768 x 16 bit = 64 KiB) + a 2 x 1 KiB staging buffer.
+// LDS = the head table (32768 x 16 bit = 64 KiB) + a 1 KiB staging buffer per wave.
 // "Exchange head[h] with p" is one LDS instruction per 64 positions: DS_MSKOR_RTN_B32 (D = (D & ~mask) | value,
 // returns the old word) on the 32-bit word that holds two 16-bit heads.  Lanes that hit the same word in
 // one instruction are served in lane order and one wave's DS instructions in program order (measured:
@@ -55,19 +55,28 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 }
 
 // Levels whose chain budget reaches this value keep the match finder of kernels_lz.h (flate_hip.hip).
+#ifndef FL_BULK_MIN_CHAIN
 #define FL_BULK_MIN_CHAIN 1024u
+#endif
 
-__global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
-                                                 uint16_t* __restrict__ prev_all, uint32_t* __restrict__ cflag) {
+// Four waves per chunk.  Wave w prepares block 4 k + w (1024 positions: loads, staging, hashes) while the others
+// prepare theirs; the exchanges themselves are issued block after block -- wave 0, barrier, wave 1, barrier, ... --
+// each wave waiting for its results before the barrier, so that the table sees the positions in ascending order.
+#define FL_CHAIN_WAVES 4
+__global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t* __restrict__ in,
+                                                                   const fl_chunk* __restrict__ chunks,
+                                                                   uint16_t* __restrict__ prev_all,
+                                                                   uint32_t* __restrict__ cflag) {
     __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
-    __shared__ uint32_t stg[2][FL_CHAIN_STG_DW];
+    __shared__ uint32_t stg_all[FL_CHAIN_WAVES][FL_CHAIN_STG_DW];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* sb = stg_all[wave];
     const uint32_t N = ck.in_len;
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;  // positions with 4 bytes left (Lookup.zig:24)
-    if (lane == 0) cflag[c] = 0u;
+    if (threadIdx.x == 0) cflag[c] = 0u;
     if (Mpos == 0) return;
     const uint8_t* src = in + ck.in_off;
     uint16_t* pv = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
@@ -80,8 +89,8 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
     if (N >= 64) {
         const uint32_t b0 = src[0] * 0x01010101u;
         bool same = true;
-        for (uint32_t g0 = 0; g0 < n_gran; g0 += 64) {
-            const uint32_t g = g0 + lane;
+        for (uint32_t g0 = 0; g0 < n_gran; g0 += 64 * FL_CHAIN_WAVES) {
+            const uint32_t g = g0 + threadIdx.x;
             if (g < n_gran) {
                 uint4 v = src16[g];
                 // bytes of the granule outside the chunk do not count
@@ -98,17 +107,21 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
                     same = same && ((w[k] ^ b0) & m) == 0;
                 }
             }
-            if (__any(!same)) break;
+            if (__syncthreads_or(same ? 0 : 1)) {
+                same = false;
+                break;
+            }
         }
-        if (!__any(!same)) {
-            if (lane == 0) cflag[c] = 1u;
+        if (same) {  // (the same verdict in every thread)
+            if (threadIdx.x == 0) cflag[c] = 1u;
             return;
         }
     }
     {
         uint4* h4 = (uint4*)head32;
-        for (uint32_t i = lane; i < 4096; i += 64) h4[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < 4096; i += 64 * FL_CHAIN_WAVES) h4[i] = make_uint4(0, 0, 0, 0);
     }
+    __syncthreads();
     // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs: granules
     // 64 b .. 64 b + 65 (sh + 1023 + 3 < 1056 = 66 granules); lane l loads granule 64 b + l, lanes 0..1 two more
     auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {
@@ -117,52 +130,62 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
         g1 = (lane < 2 && gb < n_gran) ? src16[gb] : make_uint4(0, 0, 0, 0);
     };
     const uint32_t n_blocks = (Mpos + 1023) >> 10;
-    uint4 ga0, ga1, gb0, gb1;  // two blocks in flight
-    load_block(0, ga0, ga1);
-    if (n_blocks > 1) load_block(1, gb0, gb1);
+    uint4 ga0, ga1;  // the wave's next block, in flight
+    load_block(wave, ga0, ga1);
     bool overtaken = false;
-    for (uint32_t b = 0; b < n_blocks; b++) {
-        uint32_t* sb = stg[b & 1];
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += FL_CHAIN_WAVES) {  // (uniform trip count: every wave meets every barrier)
+        const uint32_t b = b0 + wave;
         ((uint4*)sb)[lane] = ga0;
         if (lane < 2) ((uint4*)sb)[64 + lane] = ga1;
-        ga0 = gb0;
-        ga1 = gb1;
-        if (b + 2 < n_blocks) load_block(b + 2, gb0, gb1);
+        if (b + FL_CHAIN_WAVES < n_blocks) load_block(b + FL_CHAIN_WAVES, ga0, ga1);
         fl_lds_order();
-        // 16 steps of 64 positions: all exchanges are issued before the first result is looked at
-        uint32_t old[16];
+        // the 16 x 64 hashes of the block
+        uint32_t hw[16];   // word of the table, or the lane's dummy word for a position past the end
         uint32_t odd = 0;  // bit s: the hash of step s is odd (its head is the upper half of the word)
+        uint32_t val = 0;  // bit s: position of step s exists
 #pragma unroll
         for (uint32_t s = 0; s < 16; s++) {
             const uint32_t p = (b << 10) + (s << 6) + lane;
             const uint32_t off = (s << 6) + lane + sh;
             const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
             const uint32_t h = fl_hash_le(v);
-            const uint32_t hs = (h & 1u) << 4;
-            odd |= (h & 1u) << s;
-            // (no branch around the instruction: the compiler must not look at a result before the wait below)
             const bool valid = p < Mpos;
-            uint32_t* word = &head32[valid ? (h >> 1) : 16384u + lane];
-            old[s] = fl_lds_mskor_rtn(word, valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+            odd |= (h & 1u) << s;
+            val |= (valid ? 1u : 0u) << s;
+            hw[s] = valid ? (h >> 1) : 16384u + lane;
         }
-        // the results exist from here on (listed as operands so that no use of them is scheduled above the wait)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]),
-                       "+v"(old[7]), "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]), "+v"(old[12]),
-                       "+v"(old[13]), "+v"(old[14]), "+v"(old[15])
-                     :
-                     : "memory");
+        uint32_t old[16];
+#pragma unroll 1
+        for (uint32_t t = 0; t < FL_CHAIN_WAVES; t++) {
+            if (t == wave) {
+                // all exchanges are issued before the first result is looked at (no branch around the instruction)
+#pragma unroll
+                for (uint32_t s = 0; s < 16; s++) {
+                    const uint32_t p = (b << 10) + (s << 6) + lane;
+                    const uint32_t hs = ((odd >> s) & 1u) << 4;
+                    const bool valid = (val >> s) & 1u;
+                    old[s] = fl_lds_mskor_rtn(&head32[hw[s]], valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+                }
+                // the results exist from here on (listed as operands so that no use of them is scheduled above the wait)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]),
+                               "+v"(old[6]), "+v"(old[7]), "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]),
+                               "+v"(old[12]), "+v"(old[13]), "+v"(old[14]), "+v"(old[15])
+                             :
+                             : "memory");
+            }
+            __syncthreads();
+        }
         // the links: the half of the returned word this position's hash selects
 #pragma unroll
         for (uint32_t s = 0; s < 16; s++) {
             const uint32_t p = (b << 10) + (s << 6) + lane;
-            if (p < Mpos) {
+            if ((val >> s) & 1u) {
                 const uint32_t o = ((odd >> s) & 1u) ? (old[s] >> 16) : (old[s] & 0xffffu);
                 overtaken = overtaken || o > p;
                 pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
             }
         }
-        fl_lds_order();
     }
 #ifdef FL_CHAIN_FORCE_SLOW
     overtaken = true;  // (test builds: exercise the fallback)
@@ -170,12 +193,12 @@ __global__ __launch_bounds__(64) void k_lz_chain(const uint8_t* __restrict__ in,
 #ifdef FL_CHAIN_NO_FALLBACK
     overtaken = false;  // (test builds: the fast path alone, tools/ubench/chain_test.hip)
 #endif
-    if (__any(overtaken)) {
+    if (__syncthreads_or(overtaken ? 1 : 0)) {
         // never seen on gfx950: one position at a time, by one lane (Lookup.zig:35-40 as written)
         uint16_t* head16 = (uint16_t*)head32;
-        for (uint32_t i = lane; i < 16384; i += 64) head32[i] = 0;
-        fl_lds_order();
-        if (lane == 0) {
+        for (uint32_t i = threadIdx.x; i < 16384; i += 64 * FL_CHAIN_WAVES) head32[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
             for (uint32_t p = 0; p < Mpos; p++) {
                 const uint32_t h = fl_hash_le(fl_load_u32_clamped(src, p, N));
                 pv[p] = head16[h];

@@ -20,11 +20,11 @@ int main() {
         in.push_back(0); in.push_back(0); in.push_back(0);  // odd alignment of the next chunk
     }
     in.resize(in.size() + 64);
-    uint8_t* d_in; fl_chunk* d_ch; uint16_t* d_prev;
+    uint8_t* d_in; fl_chunk* d_ch; uint16_t* d_prev; uint32_t* d_cf; hipMalloc(&d_cf, 4 * NCH);
     hipMalloc(&d_in, in.size()); hipMalloc(&d_ch, sizeof(fl_chunk) * NCH); hipMalloc(&d_prev, 2 * 65536 * NCH);
     hipMemcpy(d_in, in.data(), in.size(), hipMemcpyHostToDevice); hipMemcpy(d_ch, ch.data(), sizeof(fl_chunk) * NCH, hipMemcpyHostToDevice);
     hipMemset(d_prev, 0xee, 2 * 65536 * NCH);
-    hipLaunchKernelGGL(k_lz_chain, dim3(NCH), dim3(64), 0, 0, d_in, d_ch, d_prev);
+    hipLaunchKernelGGL(k_lz_chain, dim3(NCH), dim3(64 * FL_CHAIN_WAVES), 0, 0, d_in, d_ch, d_prev, d_cf);
     hipError_t e = hipDeviceSynchronize();
     printf("kernel: %s\n", hipGetErrorString(e));
     std::vector<uint16_t> prev(65536 * NCH);
