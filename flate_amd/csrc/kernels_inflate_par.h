@@ -107,6 +107,7 @@ struct fp_shared {
     fp_long lit_long, dst_long;
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
     uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
+    uint32_t err_far;  // a copy of this round reaches before the start of the output (set in step 6, read after its barrier)
     uint32_t st_len;  // stored block: bytes
     uint32_t wbits;   // bits per wave and round
     uint32_t crc, adA, adB;
@@ -296,8 +297,15 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
     uint64_t t_prof_ = __builtin_readcyclecounter();
 #endif
     // ================================================================ blocks
+    // The flags in LDS (redo, blk_done, blk_final, blk_type, err_far) are only read right behind a barrier that
+    // follows their last write, into registers, and another barrier stands between those reads and the next write:
+    // every wave takes the same way through the loops.  `bail` = the stream goes to k_inflate.
+    bool bail = false;
     for (;;) {
-        if (sh->redo) break;
+        __syncthreads();  // (nobody writes between here and the header below)
+        bail = sh->redo != 0;
+        __syncthreads();  // every wave has looked before wave 0 parses the next header
+        if (bail) break;
         FP_T(32);
         // ---- block header (wave 0)
         if (wave == 0) {
@@ -351,15 +359,17 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
         }
         __syncthreads();
         FP_T(33);
-        if (sh->redo) break;
+        const uint32_t blk_type = sh->blk_type, blk_final = sh->blk_final;
+        bail = sh->redo != 0;
+        if (bail) break;
 
-        if (sh->blk_type == 0) {
+        if (blk_type == 0) {
             // ---- stored block (inflate.zig:89-102): bytes go out as they are, the ring keeps the last of them
             const uint32_t len = sh->st_len;
             const uint64_t wp = sh->wp;
             const uint32_t from = (uint32_t)(sh->bitpos >> 3);
             if (wp + len > ck.out_cap) {
-                if (tid == 0) sh->redo = FP_WHY(3);
+                bail = true;  // (the same in every thread) OutputTooSmall is k_inflate's to report
             } else {
                 for (uint32_t i = tid; i < len; i += FP_THREADS) dst[wp + i] = src[from + i];
                 const uint32_t tail = min(len, FP_RING);
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 sh->bitpos += (uint64_t)len * 8;
             }
             __syncthreads();
+            if (bail) break;
         } else {
             // ---- Huffman block: rounds over windows of 4 KiB
             for (;;) {
@@ -560,6 +571,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                     sh->r_next = next;  // window bit where the next round / block starts
                     sh->r_cutwave = 0xffffffffu;
                     if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
+                    sh->err_far = 0;
                     uint32_t run = 0;
                     for (uint32_t w = 0; w < nvalid; w++) {
                         sh->w_base[w] = run;
@@ -578,7 +590,8 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                     sh->unresolved[2] = 0;
                 }
                 __syncthreads();
-                if (sh->redo) break;
+                bail = sh->redo != 0;  // (step 6 below does not write it)
+                if (bail) break;
                 FP_T(37);
                 const uint32_t nv2 = sh->r_nvalid, cutwave = sh->r_cutwave;
                 // (6) fill: literals and copies from the history are final, the rest points at its source
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         // the window); short copies are written by their own lanes, long ones by the wave
                         const bool is_m = ok && (t >> 31);
                         const uint32_t mlen_l = (t >> 16) & 0x1ff, mdist_l = (t & 0xffff) + 1;
-                        if (is_m && (uint64_t)mdist_l > wp + my_off) sh->redo = FP_WHY(5);  // reaches before the start of the output
+                        if (is_m && (uint64_t)mdist_l > wp + my_off) sh->err_far = 1;  // reaches before the start of the output
                         const uint32_t src0 = my_off + 32768u - mdist_l;
                         const uint32_t shortmax = fl_wave_max(is_m && mlen_l <= 32 ? mlen_l : 0u);
                         for (uint32_t i = 0; i < shortmax; i++)
@@ -659,14 +672,10 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 }
                 __syncthreads();
                 FP_T(38);
-                if (sh->redo) break;
                 const uint32_t nout = sh->r_nout;
+                bail = sh->err_far != 0 || wp + nout > ck.out_cap;  // InvalidMatch / OutputTooSmall are k_inflate's to report
+                if (bail) break;
                 FP_CNT(50, nout);
-                if (wp + nout > ck.out_cap) {  // OutputTooSmall is k_inflate's to report
-                    if (tid == 0) sh->redo = FP_WHY(6);
-                    __syncthreads();
-                    break;
-                }
                 // (7) resolve the copies inside the window by pointer jumping over byte positions
                 for (uint32_t rr = 0;;) {
                     bool mine = false;
@@ -714,14 +723,15 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 }
                 __syncthreads();
                 FP_T(40);
-                if (sh->redo || sh->blk_done) break;
+                bail = sh->redo != 0;
+                if (bail || sh->blk_done) break;  // (the next writes of either flag come behind another barrier)
             }
-            if (sh->redo) break;
+            if (bail) break;
         }
-        if (sh->blk_final) break;
+        if (blk_final) break;
     }
     __syncthreads();
-    if (sh->redo) {
+    if (bail) {
         if (tid == 0) status[c] = FL_PAR_REDO;
         return;
     }

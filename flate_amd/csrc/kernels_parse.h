@@ -59,10 +59,12 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 #define FL_BULK_MIN_CHAIN 1024u
 #endif
 
-// Four waves per chunk.  Wave w prepares block 4 k + w (1024 positions: loads, staging, hashes) while the others
+// FL_CHAIN_WAVES (8) waves per chunk.  Wave w prepares block 8 k + w (1024 positions: loads, staging, hashes) while the others
 // prepare theirs; the exchanges themselves are issued block after block -- wave 0, barrier, wave 1, barrier, ... --
 // each wave waiting for its results before the barrier, so that the table sees the positions in ascending order.
-#define FL_CHAIN_WAVES 4
+#ifndef FL_CHAIN_WAVES
+#define FL_CHAIN_WAVES 8
+#endif
 __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ prev_all,
