@@ -18,12 +18,21 @@ def main(argv=None):
         print("not a .gz file", file=sys.stderr)
         return 1
     from flate_amd import gzip
-    with open(name, "rb") as src, open(name[:-3], "wb") as dst:
-        d = gzip.decompressor(src)
-        d.decompress(dst)
-        while d.more_input():  # further members of the same file
-            d.reset()
+    # decoded into a temporary file beside the target: an archive that fails to decode leaves an existing
+    # file of that name as it was (and no partial output behind)
+    out_name, tmp_name = name[:-3], name[:-3] + ".gunzip-tmp"
+    try:
+        with open(name, "rb") as src, open(tmp_name, "wb") as dst:
+            d = gzip.decompressor(src)
             d.decompress(dst)
+            while d.more_input():  # further members of the same file
+                d.reset()
+                d.decompress(dst)
+        os.replace(tmp_name, out_name)
+    except BaseException:
+        if os.path.exists(tmp_name):
+            os.unlink(tmp_name)
+        raise
     return 0
 
 
