@@ -1,0 +1,114 @@
+"""GPU parity tests in the shapes BASELINE.json's configurations have on one rank: the
+reduced shapes live in test_gpu_compress.py / test_gpu_inflate.py, these are the real ones at sizes the oracle
+still finishes in seconds.
+
+  configs[3]  huffman-only gzip of ONE long Silesia-like stream, through flate_hip_compress_batch_sharded
+              (the C ABI the multi-GPU run uses, here with an RCCL communicator of one rank)
+  configs[4]  gunzip of a batch of 1 MiB gzip level-6 members made by the oracle from Silesia-like slices
+              (few long streams: k_inflate_par), outputs + consumed counts + the container's CRC-32 / ISIZE
+  and one stream of several MiB through the same inflater.
+"""
+import ctypes as C
+import os
+import zlib as pyzlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from gpu_util import engine
+
+pytestmark = pytest.mark.gpu
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _one_rank_comm():
+    import torch
+    import torch.distributed  # noqa: F401  (loads the RCCL that torch ships)
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+    uid = _UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    return rccl, comm
+
+
+def test_config4_one_long_huffman_only_gzip_stream_through_the_sharded_entry_point():
+    import torch
+    from flate_amd import _capi, synth
+    eng = engine()
+    data = synth.silesia_like(synth.SEED_SILESIA + 4, 8 * 1024 * 1024 + 12345).tobytes()
+    want = O.compress(data, O.GZIP, O.HUFFMAN)
+    rccl, comm = _one_rank_comm()
+    try:
+        dev = torch.device("cuda", 0)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        in_off = torch.tensor([0, len(data)], dtype=torch.int64, device=dev)
+        cap = (eng.compress_bound(len(data), O.GZIP, O.HUFFMAN) + 15) & ~15
+        out_off = torch.tensor([0, cap], dtype=torch.int64, device=dev)
+        out = torch.zeros(cap + 8, dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        gathered = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        sizes = torch.zeros(1, dtype=torch.int64, device=dev)
+        dst_off = torch.zeros(2, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        L = _capi.lib()
+        rc = L.flate_hip_compress_batch_sharded(eng._h, comm, 0, 1, d_in.data_ptr(), in_off.data_ptr(), 1, O.GZIP, O.HUFFMAN,
+                                                out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), status.data_ptr(),
+                                                gathered.data_ptr(), cap, sizes.data_ptr(), dst_off.data_ptr())
+        assert rc == 0, eng._L.flate_hip_last_error(eng._h)
+        torch.cuda.synchronize()
+        assert int(status[0]) == 0 and int(sizes[0]) == len(want) and int(out_len[0]) == len(want)
+        assert gathered[:len(want)].cpu().numpy().tobytes() == want
+        assert pyzlib.decompress(want, 31) == data  # (and a third implementation reads it)
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
+def test_config5_gunzip_of_oracle_made_1mib_level6_members():
+    from flate_amd import synth
+    eng = engine()
+    n, size = 16, 1 << 20
+    data = synth.silesia_like(synth.SEED_SILESIA + 5, n * size).tobytes()
+    parts = [data[i * size:(i + 1) * size] for i in range(n)]
+    members = [O.compress(p, O.GZIP, 6) for p in parts]
+    outs, st, used = eng.decompress_many(members, O.GZIP, caps=[size] * n)  # (slots of exactly ISIZE bytes)
+    assert st == [0] * n
+    assert outs == parts
+    assert used == [len(m) for m in members]
+    # the footer is checked: a member whose CRC-32 or ISIZE is off by one bit is refused with the reference's names
+    bad_crc = bytearray(members[3])
+    bad_crc[-5] ^= 1
+    bad_size = bytearray(members[4])
+    bad_size[-1] ^= 0x40
+    outs, st, used = eng.decompress_many([bytes(bad_crc), bytes(bad_size), members[5]], O.GZIP, caps=[size + 8] * 3)
+    assert [O.STATUS[s] for s in st] == ["WrongGzipChecksum", "WrongGzipSize", "Ok"]
+    assert outs[2] == parts[5]
+    # two members back to back in one input: `consumed` stops behind the first (inflate.zig:301-309)
+    outs, st, used = eng.decompress_many([members[0] + members[1]], O.GZIP, caps=[size + 8])
+    assert st == [0] and outs[0] == parts[0] and used == [len(members[0])]
+
+
+@pytest.mark.parametrize("mode", [6, O.HUFFMAN, 0])
+def test_one_stream_of_several_mib(mode):
+    from flate_amd import synth
+    eng = engine()
+    data = synth.silesia_like(synth.SEED_SILESIA + 6, 5 * 1024 * 1024 + 777).tobytes()
+    comp = O.compress(data, O.ZLIB, mode)
+    outs, st, used = eng.decompress_many([comp], O.ZLIB, caps=[len(data)])
+    assert st == [0] and used == [len(comp)]
+    assert outs[0] == data
+    # truncated in the middle / one bit flipped in the last quarter: the oracle's verdict
+    cut = comp[:len(comp) // 2]
+    flip = bytearray(comp)
+    flip[(len(comp) * 7) // 8] ^= 0x04
+    for bad in (cut, bytes(flip)):
+        outs, st, used = eng.decompress_many([bad], O.ZLIB, caps=[len(data) + 8])
+        name, want, wused = O.decompress(bad, O.ZLIB, 0, cap=len(data) + 8)
+        assert O.STATUS[st[0]] == name
