@@ -42,13 +42,16 @@ enum KernelId {
     K_ENCODE,
     K_INFLATE,
     K_INFLATE_PAR,
+    K_SPAN_SCAN,
+    K_INFLATE_SPAN,
     K_GATHER,
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
                                            "k_lz_chain", "k_lz_parse", "k_lz_emit",
                                            "k_lz_tok", "k_st_parse", "k_st_emit", "k_plan",
-                                           "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_gather"};
+                                           "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_span_scan", "k_inflate_span",
+                                           "k_gather"};
 
 struct DevBuf {
     void* p = nullptr;
@@ -81,6 +84,7 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag;
+    DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff;  // inflate of long streams by spans
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
@@ -560,6 +564,231 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     return enqueue_back_end(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status);
 }
 
+
+// Long streams, few of them: cut each at block starts into spans and decode the spans at once, twice
+// (kernels_inflate_par.h, "spans").  Streams that come out whole get their status / out_len / consumed here and
+// chunks[i].skip = 1 (the kernels that follow leave them alone); everything else stays as it was.
+// Returns the number of streams finished, or a negative FLATE_HIP_E_*.
+#define FL_SPAN_MIN_BYTES (512u * 1024u)   // streams shorter than this are not cut
+#define FL_SPAN_BYTES (96u * 1024u)        // compressed bytes per span, about
+#define FL_SPAN_MAX 1024u                  // spans per call
+int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std::vector<fl_chunk>& chunks, int container,
+                     int flags, uint8_t* d_out, uint64_t* d_outlen, int32_t* d_status, uint64_t* d_consumed) {
+    const uint32_t n_chunks = (uint32_t)chunks.size();
+    const char* e = getenv("FLATE_HIP_INFLATE_SPANS");  // 0: never; else the minimum stream size in bytes
+    const uint64_t min_bytes = e ? (uint64_t)atoll(e) : FL_SPAN_MIN_BYTES;
+    if (!min_bytes || (flags & 1)) return 0;
+    const bool dbg = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
+    std::vector<uint32_t> elig;
+    for (uint32_t i = 0; i < n_chunks; i++)
+        if (chunks[i].in_len >= min_bytes) elig.push_back(i);
+    if (elig.empty() || elig.size() > 64) return 0;
+    int rc;
+    // ---- where spans may start
+    std::vector<fl_scan_point> points;
+    std::vector<uint32_t> pt_first(elig.size() + 1, 0);
+    const uint32_t per_stream_max = std::max<uint32_t>(2u, FL_SPAN_MAX / (uint32_t)elig.size());
+    for (size_t k = 0; k < elig.size(); k++) {
+        const fl_chunk& c = chunks[elig[k]];
+        const uint64_t bits = (uint64_t)c.in_len * 8;
+        const uint32_t P = (uint32_t)std::min<uint64_t>(per_stream_max, std::max<uint64_t>(2, c.in_len / FL_SPAN_BYTES));
+        for (uint32_t j = 1; j < P; j++) {
+            fl_scan_point pt;
+            pt.from_bit = bits / P * j;
+            pt.limit_bit = j + 1 < P ? bits / P * (j + 1) : bits;
+            pt.stream = elig[k];
+            pt.pad = 0;
+            points.push_back(pt);
+        }
+        pt_first[k + 1] = (uint32_t)points.size();
+    }
+    const uint32_t npts = (uint32_t)points.size();
+    if ((rc = ensure(h, h->sp_points, sizeof(fl_scan_point) * npts))) return -1;
+    if ((rc = ensure(h, h->sp_found, sizeof(uint64_t) * npts))) return -1;
+    if (hipMemcpyAsync(h->sp_points.p, points.data(), sizeof(fl_scan_point) * npts, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
+    {
+        ProfScope ps(h, K_SPAN_SCAN);
+        hipLaunchKernelGGL(k_span_scan, dim3(npts), dim3(FP_THREADS), 0, st, d_in, dch, flags,
+                           (const fl_scan_point*)h->sp_points.p, (uint64_t*)h->sp_found.p);
+    }
+    std::vector<uint64_t> found(npts);
+    if (hipMemcpyAsync(found.data(), h->sp_found.p, sizeof(uint64_t) * npts, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    // ---- the spans: the stream start, then every distinct position found
+    std::vector<fl_span> spans;
+    std::vector<uint64_t> cand;
+    std::vector<uint32_t> cand_off(n_chunks + 1, 0), sp_first(elig.size() + 1, 0);
+    {
+        size_t k = 0;
+        for (uint32_t i = 0; i < n_chunks; i++) {
+            cand_off[i] = (uint32_t)cand.size();
+            if (k < elig.size() && elig[k] == i) {
+                fl_span s0;
+                s0.start_bit = 0;
+                s0.wp = 0;
+                s0.stream = i;
+                s0.first = 1;
+                s0.prev = FP_NO_SPAN;
+                s0.live = 0;
+                spans.push_back(s0);
+                uint64_t last = 0;
+                for (uint32_t j = pt_first[k]; j < pt_first[k + 1]; j++) {
+                    if (found[j] == ~0ull || found[j] <= last) continue;  // (ascending: the targets are)
+                    last = found[j];
+                    fl_span s1 = s0;
+                    s1.start_bit = found[j];
+                    s1.first = 0;
+                    spans.push_back(s1);
+                    cand.push_back(found[j]);
+                }
+                k++;
+                sp_first[k] = (uint32_t)spans.size();
+            }
+        }
+        cand_off[n_chunks] = (uint32_t)cand.size();
+    }
+    const uint32_t nsp = (uint32_t)spans.size();
+    if (dbg) fprintf(stderr, "[spans] %zu streams, %u scan points, %u spans\n", elig.size(), npts, nsp);
+    if (nsp == (uint32_t)elig.size()) return 0;  // nothing to cut
+    if ((rc = ensure(h, h->sp_spans, sizeof(fl_span) * nsp))) return -1;
+    if ((rc = ensure(h, h->sp_res, sizeof(fl_span_res) * nsp))) return -1;
+    if ((rc = ensure(h, h->sp_cand, sizeof(uint64_t) * (cand.size() + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_candoff, sizeof(uint32_t) * (n_chunks + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_tails, (size_t)FP_TAIL * nsp))) return -1;
+    if ((rc = ensure(h, h->sp_tails_b, (size_t)FP_TAIL * nsp))) return -1;
+    if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (!cand.empty() && hipMemcpyAsync(h->sp_cand.p, cand.data(), sizeof(uint64_t) * cand.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->sp_candoff.p, cand_off.data(), sizeof(uint32_t) * (n_chunks + 1), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    // ---- pass 1
+    {
+        ProfScope ps(h, K_INFLATE_SPAN);
+        hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+                           (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u);
+    }
+    std::vector<fl_span_res> r1(nsp), r2(nsp);
+    if (hipMemcpyAsync(r1.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    // ---- the chain of every stream
+    struct StreamPlan {
+        bool ok = false;
+        std::vector<uint32_t> chain;
+        uint64_t total = 0, end_bit = 0;
+    };
+    std::vector<StreamPlan> plans(elig.size());
+    bool any = false;
+    for (size_t k = 0; k < elig.size(); k++) {
+        StreamPlan& pl = plans[k];
+        const fl_chunk& c = chunks[elig[k]];
+        uint32_t cur = sp_first[k];
+        uint64_t acc = 0;
+        bool ok = true;
+        for (uint32_t guard = 0; guard <= nsp; guard++) {
+            const fl_span_res& r = r1[cur];
+            if (dbg && guard < 6) fprintf(stderr, "[spans] pass 1 span %u: start %llu status %u end %llu out %llu final %u\n", cur, (unsigned long long)spans[cur].start_bit, r.status, (unsigned long long)r.end_bit, (unsigned long long)r.out_len, r.final_seen);
+            if (r.status != 0) { ok = false; break; }
+            spans[cur].live = 1;
+            spans[cur].wp = acc;
+            spans[cur].prev = pl.chain.empty() ? FP_NO_SPAN : pl.chain.back();
+            pl.chain.push_back(cur);
+            acc += r.out_len;
+            if (acc > c.out_cap) { ok = false; break; }
+            if (r.final_seen) { pl.end_bit = r.end_bit; break; }
+            // the span that starts where this one stopped
+            uint32_t lo = sp_first[k] + 1, hi = sp_first[k + 1];
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (spans[mid].start_bit < r.end_bit) lo = mid + 1; else hi = mid;
+            }
+            if (lo >= sp_first[k + 1] || spans[lo].start_bit != r.end_bit || lo <= cur) { ok = false; break; }
+            cur = lo;
+        }
+        if (ok && (pl.chain.empty() || !r1[pl.chain.back()].final_seen)) ok = false;
+        if (dbg) fprintf(stderr, "[spans] stream %u: chain of %zu spans, %llu bytes, ok=%d\n", elig[k], pl.chain.size(), (unsigned long long)acc, (int)ok);
+        if (!ok)
+            for (uint32_t j = sp_first[k]; j < sp_first[k + 1]; j++) spans[j].live = 0;
+        pl.ok = ok;
+        pl.total = acc;
+        any = any || ok;
+    }
+    if (!any) return 0;
+    // ---- pass 1 again with the other filling of the history (live spans), the true tails, pass 2
+    std::vector<uint32_t> chain_all, chain_off(1, 0);
+    for (size_t k = 0; k < elig.size(); k++) {
+        if (plans[k].ok) chain_all.insert(chain_all.end(), plans[k].chain.begin(), plans[k].chain.end());
+        chain_off.push_back((uint32_t)chain_all.size());
+    }
+    if ((rc = ensure(h, h->sp_chain, sizeof(uint32_t) * (chain_all.size() + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_chainoff, sizeof(uint32_t) * chain_off.size()))) return -1;
+    if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    {
+        ProfScope ps(h, K_INFLATE_SPAN);
+        hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+                           (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u);
+        hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
+                           (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
+        hipLaunchKernelGGL(k_inflate_span<2>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+                           (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u);
+    }
+    if (hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    // ---- every tail as in pass 1, the checksum, the footer
+    int done = 0;
+    for (size_t k = 0; k < elig.size(); k++) {
+        StreamPlan& pl = plans[k];
+        if (!pl.ok) continue;
+        fl_chunk& c = chunks[elig[k]];
+        bool ok = true;
+        uint32_t crc = 0;
+        uint64_t adA = 0, adB = 0;
+        for (size_t j = 0; j < pl.chain.size() && ok; j++) {
+            const uint32_t si = pl.chain[j];
+            const fl_span_res &a = r1[si], &b = r2[si];
+            if (b.status != 0 || b.out_len != a.out_len || b.end_bit != a.end_bit) ok = false;
+            if (j + 1 < pl.chain.size() && !b.tail_same) ok = false;
+            if (dbg && !ok) fprintf(stderr, "[spans] span %u (chain %zu): pass 2 status %u len %llu/%llu end %llu/%llu tail_same %u\n", si, j, b.status, (unsigned long long)b.out_len, (unsigned long long)a.out_len, (unsigned long long)b.end_bit, (unsigned long long)a.end_bit, b.tail_same);  // (nobody decodes with the last span's tail)
+            const uint64_t after = pl.total - (spans[si].wp + a.out_len);
+            crc ^= fl_crc_mulmod(b.crc, fl_crc_xpow8n(h->crc.xpow8, after));
+            adA += b.adA;
+            adB += b.adB % 65521u + (uint64_t)(b.adA % 65521u) * (after % 65521u) % 65521u;
+        }
+        const uint64_t fb = (pl.end_bit + 7) >> 3;
+        const uint32_t flen = container == 1 ? 8u : container == 2 ? 4u : 0u;
+        if (ok && fb + flen > c.in_len) ok = false;  // truncated: the old way names it
+        if (ok && flen) {
+            uint8_t f[8] = {0};
+            if (hipMemcpy(f, d_in + c.in_off + fb, flen, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (container == 1) {
+                const uint32_t fcrc = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+                const uint32_t fsz = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+                ok = fcrc == crc && fsz == (uint32_t)pl.total;
+            } else {
+                const uint32_t a = (uint32_t)((1 + adA % 65521u) % 65521u);
+                const uint32_t b = (uint32_t)((pl.total % 65521u + adB % 65521u) % 65521u);
+                const uint32_t fad = ((uint32_t)f[0] << 24) | ((uint32_t)f[1] << 16) | ((uint32_t)f[2] << 8) | (uint32_t)f[3];
+                ok = fad == ((b << 16) | a);
+            }
+        }
+        if (dbg) fprintf(stderr, "[spans] stream %u after pass 2: ok=%d crc %08x\n", elig[k], (int)ok, crc);
+        if (!ok) continue;  // (the bytes pass 2 wrote are written again by the kernels that follow)
+        const uint32_t ci = elig[k];
+        const int32_t zero = 0;
+        const uint64_t total = pl.total, used = fb + flen;
+        if (hipMemcpyAsync(d_status + ci, &zero, sizeof(zero), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        if (hipMemcpyAsync(d_outlen + ci, &total, sizeof(total), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        if (d_consumed && hipMemcpyAsync(d_consumed + ci, &used, sizeof(used), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;  // (the sources are on this stack)
+        c.skip = 1;
+        done++;
+    }
+    return done;
+}
+
 }  // namespace
 
 extern "C" {
@@ -613,6 +842,9 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
+    for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
+                      &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff})
+        if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->cflag, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
@@ -1027,6 +1259,18 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * n_chunks))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), sizeof(fl_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     HIP_OK(h, hipStreamSynchronize(st));
+    // A few long streams: each by many workgroups at once (spans); what comes out whole is skipped below.
+    if (!pin_io) {
+        const int done = try_span_inflate(h, st, d_in, chunks, container, flags, d_out, d_outlen, d_status, d_consumed);
+        if (done < 0) {
+            h->last_error = std::string("inflate by spans: ") + hipGetErrorString(hipGetLastError());
+            return FLATE_HIP_E_LAUNCH;
+        }
+        if (done > 0) {
+            HIP_OK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), sizeof(fl_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+            HIP_OK(h, hipStreamSynchronize(st));
+        }
+    }
     // Long streams of a batch that has few of them: a workgroup per stream (kernels_inflate_par.h).  It marks
     // what it does not finish (short streams, anything irregular) FL_PAR_REDO, and k_inflate takes those.
     bool use_par = false;

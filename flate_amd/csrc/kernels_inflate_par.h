@@ -107,6 +107,7 @@ struct fp_shared {
     fp_long lit_long, dst_long;
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
     uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
+    uint32_t nblk, stop;  // spans: blocks decoded so far; the span ends here
     uint32_t err_far;  // a copy of this round reaches before the start of the output (set in step 6, read after its barrier)
     uint32_t st_len;  // stored block: bytes
     uint32_t wbits;   // bits per wave and round
@@ -237,26 +238,78 @@ __device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  
 
 __device__ __forceinline__ uint32_t fp_tok_len(uint32_t t) { return (t >> 31) ? ((t >> 16) & 0x1ffu) : 1u; }
 
-// One workgroup per stream.  `min_bytes`: shorter streams are left to k_inflate.
-__global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __restrict__ in,
-                                                               const fl_chunk* __restrict__ chunks, int container,
-                                                               int flags, uint32_t min_bytes, fl_crc_consts cc,
-                                                               uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
-                                                               int32_t* __restrict__ status,
-                                                               uint64_t* __restrict__ consumed) {
+// ------------------------------------------------------------------ spans: one long stream, many workgroups
+// (round 3).  A stream is cut at block starts found by k_span_scan (dynamic-block headers that parse) into SPANS;
+// a span is decoded by one workgroup from its block start until it lands on the start of another span or behind
+// the final block.  What a span cannot know is the 32 KiB of output before it, and how far into the output it
+// starts:
+//   pass 1 (MODE 1)  every span at once, nothing written: where the span ends, how many bytes it makes, and the
+//                    last 32 KiB of them (its TAIL).  Run twice, with two fillings of the unknown history:
+//                    byte h of it is A[h] = h & 255 in run A and B[h] = A[h] ^ ((h >> 8) + 1) in run B.  A tail
+//                    byte that comes out the same in both runs does not depend on the history; one that differs
+//                    is a copy (of a copy ...) of history byte h = ((a ^ b) - 1) << 8 | a -- the same h in both
+//                    runs, because where a byte is copied from is decided by the tokens, not by the bytes;
+//   host             follows the chain of spans from the stream start (a span that is not landed on is dead),
+//                    adds up the output offsets;
+//   k_span_resolve   the true tails, span after span along the chain: a byte that depends on the history is
+//                    byte h of the (already true) tail before it;
+//   pass 2 (MODE 2)  every live span again, with its true history, the bytes written to their place; its tail
+//                    must come out as resolved (checked).
+// Checksum pieces are folded and the footer is checked by the host.  Anything irregular: the stream is decoded
+// again by the kernels below, as before.  inflate.zig:220-239 is serial per stream; this is the same function,
+// with the one thing a span cannot know kept symbolic until it is known.
+struct fl_span {
+    uint64_t start_bit;  // of its first block header, from the first byte of the stream (first span: unused)
+    uint64_t wp;         // pass 2: offset of its first output byte in the stream's output
+    uint32_t stream;     // chunk index
+    uint32_t first;      // 1: starts at the stream's first byte (container header)
+    uint32_t prev;       // pass 2: the span before it in the chain (its tail is this span's history), ~0u: none
+    uint32_t live;       // pass 2: on the chain
+};
+struct fl_span_res {
+    uint64_t end_bit;  // where it stopped: the start of another span, or the bit behind the final block
+    uint64_t out_len;
+    uint32_t status;      // 0: decoded; anything else: the stream goes the old way
+    uint32_t final_seen;  // stopped behind the final block
+    uint32_t crc, adA, adB;  // pass 2: checksum pieces of its output (adB counts from the end of the span)
+    uint32_t tail_same;      // pass 2: the tail equals the one of pass 1
+};
+#define FP_TAIL 32768u
+#define FP_NO_SPAN 0xffffffffu
+
+// MODE 0: the whole stream (k_inflate_par); 1 / 2: a span, passes 1 and 2 (k_inflate_span)
+template <int MODE>
+__device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks, int container,
+                                        int flags, uint32_t min_bytes, fl_crc_consts cc, uint8_t* __restrict__ out,
+                                        uint64_t* __restrict__ out_len, int32_t* __restrict__ status,
+                                        uint64_t* __restrict__ consumed, const fl_span* __restrict__ spans,
+                                        fl_span_res* __restrict__ sres, const uint64_t* __restrict__ cand,
+                                        const uint32_t* __restrict__ cand_off, uint8_t* __restrict__ tails, uint32_t fill) {
     __shared__ fp_shared sh_mem;
     FL_LDS fp_shared* sh = (FL_LDS fp_shared*)&sh_mem;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
-    const uint32_t c = blockIdx.x;
+    fl_span sp;
+    sp.start_bit = 0;
+    sp.wp = 0;
+    sp.stream = blockIdx.x;
+    sp.first = 1;
+    sp.prev = FP_NO_SPAN;
+    sp.live = 1;
+    if (MODE != 0) sp = spans[blockIdx.x];
+    if ((MODE == 2 || (MODE == 1 && fill)) && !sp.live) return;  // (run A of pass 1 finds out which spans are live)
+    const uint32_t c = sp.stream;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((ck.in_len < min_bytes && ck.out_cap < 16ull * min_bytes) || (flags & 1)) {  // (reference-strict Q6 headers: k_inflate's job as well)
+    if (MODE == 0 && ((ck.in_len < min_bytes && ck.out_cap < 16ull * min_bytes) || (flags & 1))) {  // (reference-strict Q6 headers: k_inflate's job as well)
         if (tid == 0) status[c] = FL_PAR_REDO;
         return;
     }
     const uint8_t* src = in + ck.in_off;
-    uint8_t* dst = out + ck.out_off;
+    uint8_t* dst = out + ck.out_off + sp.wp;  // (sh->wp counts from the span's first output byte)
+    const uint64_t out_room = MODE == 1 ? ~0ull : (ck.out_cap > sp.wp ? ck.out_cap - sp.wp : 0ull);
+    // output bytes that exist before the span's first: a distance may reach that far back
+    const uint64_t hist_avail = MODE == 0 ? 0ull : MODE == 1 ? (sp.first ? 0ull : (uint64_t)FP_TAIL) : min((uint64_t)FP_TAIL, sp.wp);
     const uint64_t total_bits = (uint64_t)ck.in_len * 8;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
@@ -284,12 +337,33 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
         sh->wbits = FP_WBITS;
     }
     if (wave == 0) {
-        fl_br_seek(r, 0);
-        const int rc = fl_inf_header(r, container);
-        if (lane == 0) {
-            if (rc) sh->redo = FP_WHY(1);
-            sh->bitpos = reader_pos();
+        if (sp.first) {
+            fl_br_seek(r, 0);
+            const int rc = fl_inf_header(r, container);
+            if (lane == 0) {
+                if (rc) sh->redo = FP_WHY(1);
+                sh->bitpos = reader_pos();
+            }
+        } else if (lane == 0) {
+            sh->bitpos = sp.start_bit;
         }
+    }
+    if (MODE != 0) {
+        // the 32 KiB before the span: pass 1: filling A or B (see above); pass 2: its predecessor's true tail
+        const uint8_t* hist = (MODE == 2 && sp.prev != FP_NO_SPAN) ? tails + (uint64_t)sp.prev * FP_TAIL : nullptr;
+        for (uint32_t i = tid; i < FP_TAIL / 4; i += FP_THREADS) {
+            uint32_t v = 0;
+            if (hist) {
+                v = ((const uint32_t*)hist)[i];
+            } else if (MODE == 1) {
+                // bytes 4 i .. 4 i + 3: A = low byte of the index, B = A ^ (high byte of the index + 1)
+                const uint32_t lowb = ((4 * i) & 0xff) * 0x01010101u + 0x03020100u;
+                const uint32_t hib = ((4 * i) >> 8) + 1u;
+                v = fill ? (lowb ^ (hib * 0x01010101u)) : lowb;
+            }
+            ((FL_LDS uint32_t*)&sh->ring[FP_RING - FP_TAIL])[i] = v;
+        }
+        if (tid == 0) sh->nblk = 0;
     }
     __syncthreads();
 
@@ -300,12 +374,28 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
     // The flags in LDS (redo, blk_done, blk_final, blk_type, err_far) are only read right behind a barrier that
     // follows their last write, into registers, and another barrier stands between those reads and the next write:
     // every wave takes the same way through the loops.  `bail` = the stream goes to k_inflate.
-    bool bail = false;
+    bool bail = false, final_seen = false;
     for (;;) {
+        if (MODE != 0 && tid == 0) {
+            // a span ends where another one starts (the sorted list of the stream's span starts)
+            uint32_t stop = 0;
+            if (sh->nblk != 0) {
+                const uint64_t bp = sh->bitpos;
+                uint32_t lo_i = cand_off[c], hi_i = cand_off[c + 1];
+                while (lo_i < hi_i) {
+                    const uint32_t mid = (lo_i + hi_i) >> 1;
+                    if (cand[mid] < bp) lo_i = mid + 1; else hi_i = mid;
+                }
+                stop = lo_i < cand_off[c + 1] && cand[lo_i] == bp;
+            }
+            sh->stop = stop;
+            sh->nblk = sh->nblk + 1;
+        }
         __syncthreads();  // (nobody writes between here and the header below)
         bail = sh->redo != 0;
+        const bool stop_here = MODE != 0 && sh->stop != 0;
         __syncthreads();  // every wave has looked before wave 0 parses the next header
-        if (bail) break;
+        if (bail || stop_here) break;
         FP_T(32);
         // ---- block header (wave 0)
         if (wave == 0) {
@@ -368,10 +458,11 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
             const uint32_t len = sh->st_len;
             const uint64_t wp = sh->wp;
             const uint32_t from = (uint32_t)(sh->bitpos >> 3);
-            if (wp + len > ck.out_cap) {
+            if (wp + len > out_room) {
                 bail = true;  // (the same in every thread) OutputTooSmall is k_inflate's to report
             } else {
-                for (uint32_t i = tid; i < len; i += FP_THREADS) dst[wp + i] = src[from + i];
+                if (MODE != 1)
+                    for (uint32_t i = tid; i < len; i += FP_THREADS) dst[wp + i] = src[from + i];
                 const uint32_t tail = min(len, FP_RING);
                 for (uint32_t i = tid; i < tail; i += FP_THREADS) {
                     const uint64_t o = wp + len - tail + i;
@@ -628,7 +719,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                         // the window); short copies are written by their own lanes, long ones by the wave
                         const bool is_m = ok && (t >> 31);
                         const uint32_t mlen_l = (t >> 16) & 0x1ff, mdist_l = (t & 0xffff) + 1;
-                        if (is_m && (uint64_t)mdist_l > wp + my_off) sh->err_far = 1;  // reaches before the start of the output
+                        if (is_m && (uint64_t)mdist_l > wp + my_off + hist_avail) sh->err_far = 1;  // reaches before the start of the output
                         const uint32_t src0 = my_off + 32768u - mdist_l;
                         const uint32_t shortmax = fl_wave_max(is_m && mlen_l <= 32 ? mlen_l : 0u);
                         for (uint32_t i = 0; i < shortmax; i++)
@@ -673,7 +764,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 __syncthreads();
                 FP_T(38);
                 const uint32_t nout = sh->r_nout;
-                bail = sh->err_far != 0 || wp + nout > ck.out_cap;  // InvalidMatch / OutputTooSmall are k_inflate's to report
+                bail = sh->err_far != 0 || wp + nout > out_room;  // InvalidMatch / OutputTooSmall are k_inflate's to report
                 if (bail) break;
                 FP_CNT(50, nout);
                 // (7) resolve the copies inside the window by pointer jumping over byte positions
@@ -711,7 +802,8 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 }
                 FP_T(39);
                 // (8) the window's bytes leave
-                for (uint32_t j = tid; j < nout; j += FP_THREADS) dst[wp + j] = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
+                if (MODE != 1)
+                    for (uint32_t j = tid; j < nout; j += FP_THREADS) dst[wp + j] = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
                 __syncthreads();
                 if (tid == 0) {
                     const uint64_t nb = bitpos + sh->r_next;  // r_next counts from the window's first bit
@@ -728,16 +820,47 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
             }
             if (bail) break;
         }
-        if (blk_final) break;
+        if (blk_final) {
+            final_seen = true;
+            break;
+        }
     }
     __syncthreads();
     if (bail) {
-        if (tid == 0) status[c] = FL_PAR_REDO;
+        if (tid == 0) {
+            if (MODE == 0)
+                status[c] = FL_PAR_REDO;
+            else
+                sres[blockIdx.x].status = 1;
+        }
         return;
     }
 
     // ================================================================ footer (container.zig:154-166)
     const uint64_t n_out = sh->wp;
+    if (MODE != 0) {
+        // the span's tail: the last 32 KiB of the output up to its end (what was there before it included)
+        const uint32_t wb = (uint32_t)(n_out % FP_RING);
+        uint8_t* tl = tails + (uint64_t)blockIdx.x * FP_TAIL;
+        bool differs = false;
+        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) {
+            const uint8_t v = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
+            if (MODE == 1)
+                tl[i] = v;
+            else
+                differs = differs || tl[i] != v;
+        }
+        const int any_diff = __syncthreads_or(differs ? 1 : 0);
+        if (tid == 0) {
+            fl_span_res* rr = &sres[blockIdx.x];
+            rr->end_bit = sh->bitpos;
+            rr->out_len = n_out;
+            rr->final_seen = final_seen ? 1u : 0u;
+            rr->tail_same = any_diff ? 0u : 1u;
+            rr->status = 0;
+        }
+        if (MODE == 1) return;
+    }
     if (container != 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         FL_LDS uint32_t* tab = (FL_LDS uint32_t*)ws->lit_lut;  // the code tables are no longer needed
@@ -785,6 +908,15 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
         }
         __syncthreads();
     }
+    if (MODE == 2) {
+        if (tid == 0) {
+            fl_span_res* rr = &sres[blockIdx.x];
+            rr->crc = sh->crc;
+            rr->adA = sh->adA;
+            rr->adB = sh->adB;
+        }
+        return;
+    }
     if (wave == 0) {
         reader_at(sh->bitpos);
         fl_br_align(r);
@@ -810,5 +942,156 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                 if (consumed) consumed[c] = fl_br_consumed(r);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ k_span_scan
+// Where can a span start?  At the first bit position at or behind a target position at which a dynamic block
+// header parses (inflate.zig:137-218: type bits 10, HLIT / HDIST in range, a complete code-length code, complete
+// literal / distance codes with an end-of-block symbol).  One workgroup per target: every lane tests one bit
+// position against what costs a few instructions (type, HLIT, HDIST, Kraft sum of the code-length code), wave 0
+// then runs the real header parser on the survivors in ascending order.  A position that passes by accident
+// inside compressed data is harmless: no span lands on it, its span is dead.
+struct fl_scan_point {
+    uint64_t from_bit, limit_bit;  // search [from_bit, limit_bit)
+    uint32_t stream, pad;
+};
+struct fp_scan_shared {
+    fl_inflate_ws ws;
+    uint32_t inring[FL_INF_INRING / 4];
+    uint32_t stage[48];
+    uint32_t surv[FP_THREADS];
+    uint32_t wcount[FP_WAVES];
+    uint32_t found;
+    uint64_t found_bit;
+};
+__global__ __launch_bounds__(FP_THREADS, 1) void k_span_scan(const uint8_t* __restrict__ in,
+                                                             const fl_chunk* __restrict__ chunks, int flags,
+                                                             const fl_scan_point* __restrict__ points,
+                                                             uint64_t* __restrict__ found_out) {
+    __shared__ fp_scan_shared sm;
+    FL_LDS fp_scan_shared* sh = (FL_LDS fp_scan_shared*)&sm;
+    FL_LDS fl_inflate_ws* ws = &sh->ws;
+    const fl_scan_point pt = points[blockIdx.x];
+    const fl_chunk ck = chunks[pt.stream];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* src = in + ck.in_off;
+    const uint64_t total_bits = (uint64_t)ck.in_len * 8;
+    fl_bitr r;  // wave 0 only
+    r.data = src;
+    r.nbytes = ck.in_len;
+    r.lane = lane;
+    r.inring = (FL_LDS uint32_t*)sh->inring;
+    r.left = (int64_t)total_bits;
+    if (tid == 0) sh->found = 0;
+    __syncthreads();
+    for (uint64_t base = pt.from_bit; base < pt.limit_bit; base += FP_THREADS) {
+        // the bits [base, base + 1024 + 160) of the stream
+        const uint32_t byte0 = (uint32_t)(base >> 3);
+        if (tid < 48) sh->stage[tid] = fl_load_u32_clamped(src, byte0 + 4 * tid, ck.in_len);
+        __syncthreads();
+        const uint64_t bit = base + tid;
+        bool pass = false;
+        if (bit < pt.limit_bit && bit + 17 + 12 <= total_bits) {
+            const uint32_t rel = (uint32_t)(base & 7) + tid;
+            uint32_t lo, hi, lo2, hi2;
+            fp_fetch64(sh->stage, rel, lo, hi);
+            fp_fetch64(sh->stage, rel + 62, lo2, hi2);
+            const uint64_t b64 = (uint64_t)lo | ((uint64_t)hi << 32);
+            const uint32_t btype = (lo >> 1) & 3, hlit = (lo >> 3) & 31, hdist = (lo >> 8) & 31, ncl = ((lo >> 13) & 15) + 4;
+            uint32_t kraft = 0, nz = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 19; i++) {
+                const uint32_t len = i < 15 ? (uint32_t)(b64 >> (17 + 3 * i)) & 7u : (lo2 >> (3 * i - 45)) & 7u;
+                if (i < ncl && len) {
+                    kraft += 128u >> len;
+                    nz++;
+                }
+            }
+            pass = btype == 2 && hlit <= 29 && hdist <= 29 && (kraft == 128 || nz <= 1) && bit + 17 + 3 * ncl <= total_bits;
+        }
+        // survivors in ascending order
+        const uint64_t pm = __ballot(pass);
+        if (lane == 0) sh->wcount[wave] = (uint32_t)__popcll(pm);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < FP_WAVES; w++) {
+            const uint32_t n = sh->wcount[w];
+            before += w < wave ? n : 0u;
+            total += n;
+        }
+        if (pass) sh->surv[before + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = tid;
+        __syncthreads();
+        if (wave == 0) {
+            for (uint32_t k = 0; k < total; k++) {
+                const uint64_t cb = base + sh->surv[k];
+                // the reader at that bit (as in fp_body)
+                r.left = (int64_t)(total_bits - cb);
+                fl_br_seek(r, (uint32_t)(cb >> 3));
+                const uint32_t kb = (uint32_t)cb & 7;
+                if (kb) {
+                    fl_br_refill(r);
+                    r.buf >>= kb;
+                    r.have -= kb;
+                }
+                uint32_t bfinal = 0, btype = 3;
+                int rc = fl_br_read(r, 1, bfinal);
+                if (!rc) rc = fl_br_read(r, 2, btype);
+                if (!rc && btype == 2) rc = fl_inf_dynamic_header(r, ws, flags, lane);
+                if (!rc && btype == 2) {
+                    if (lane == 0) {
+                        sh->found = 1;
+                        sh->found_bit = cb;
+                    }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh->found) break;
+    }
+    if (tid == 0) found_out[blockIdx.x] = sh->found ? sh->found_bit : ~0ull;
+}
+
+// One workgroup per stream.  `min_bytes`: shorter streams are left to k_inflate.
+__global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __restrict__ in,
+                                                               const fl_chunk* __restrict__ chunks, int container,
+                                                               int flags, uint32_t min_bytes, fl_crc_consts cc,
+                                                               uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
+                                                               int32_t* __restrict__ status,
+                                                               uint64_t* __restrict__ consumed) {
+    fp_body<0>(in, chunks, container, flags, min_bytes, cc, out, out_len, status, consumed, nullptr, nullptr, nullptr,
+               nullptr, nullptr, 0u);
+}
+
+// One workgroup per span (see above); PASS 1 or 2.
+template <int PASS>
+__global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* __restrict__ in,
+                                                                const fl_chunk* __restrict__ chunks, int container,
+                                                                int flags, fl_crc_consts cc, uint8_t* __restrict__ out,
+                                                                const fl_span* __restrict__ spans,
+                                                                fl_span_res* __restrict__ sres,
+                                                                const uint64_t* __restrict__ cand,
+                                                                const uint32_t* __restrict__ cand_off,
+                                                                uint8_t* __restrict__ tails, uint32_t fill) {
+    fp_body<PASS>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails,
+                  fill);
+}
+
+// The true tails of a stream's spans, in chain order (one workgroup per stream; see above).  tails_a is resolved in place.
+__global__ __launch_bounds__(FP_THREADS) void k_span_resolve(const uint32_t* __restrict__ chain,
+                                                             const uint32_t* __restrict__ chain_off, uint8_t* tails_a,
+                                                             const uint8_t* __restrict__ tails_b) {
+    const uint32_t k = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t j = chain_off[k] + 1; j < chain_off[k + 1]; j++) {
+        uint8_t* ta = tails_a + (uint64_t)chain[j] * FP_TAIL;
+        const uint8_t* tb = tails_b + (uint64_t)chain[j] * FP_TAIL;
+        const uint8_t* tp = tails_a + (uint64_t)chain[j - 1] * FP_TAIL;
+        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) {
+            const uint32_t a = ta[i], b = tb[i];
+            if (a != b) ta[i] = tp[(((a ^ b) - 1u) << 8) | a];
+        }
+        __threadfence();
+        __syncthreads();
     }
 }

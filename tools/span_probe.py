@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One long stream through the inflater: time, kernels, bytes (tuning aid for the span path).
+usage: python tools/span_probe.py [MiB=64] [mode=6] [container=1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from flate_amd import Engine, synth
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+container = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+kind = sys.argv[4] if len(sys.argv) > 4 else "text"
+eng = Engine(0)
+n = mib << 20
+data = (synth.text(synth.SEED_TEXT, n) if kind == "text" else synth.silesia_like(synth.SEED_SILESIA, n)).tobytes()
+comp, st = eng.compress_many([data], container, mode)
+assert st == [0]
+comp = comp[0]
+print("stream: %d -> %d bytes" % (len(data), len(comp)))
+for env in ("0", None):
+    if env is None:
+        os.environ.pop("FLATE_HIP_INFLATE_SPANS", None)
+    else:
+        os.environ["FLATE_HIP_INFLATE_SPANS"] = env
+    eng.profile_reset(); eng.profile_enable(True)
+    t0 = time.time()
+    outs, st, used = eng.decompress_many([comp], container, caps=[len(data)])
+    dt = time.time() - t0
+    prof = eng.profile_read(); eng.profile_enable(False)
+    ok = st == [0] and outs[0] == data and used == [len(comp)]
+    print("spans %-4s: ok=%s status=%s wall %.1f ms (host copies included)  kernels: %s" % (
+        "off" if env == "0" else "on", ok, st, dt * 1e3, {k: round(v[0], 2) for k, v in prof.items()}))
