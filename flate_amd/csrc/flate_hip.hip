@@ -584,6 +584,20 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         if (chunks[i].in_len >= min_bytes) elig.push_back(i);
     if (elig.empty() || elig.size() > 64) return 0;
     int rc;
+    // A stream that begins with a stored block is most likely stored throughout (store-only mode, incompressible
+    // data): no dynamic header to cut it at.  It keeps the old way rather than paying for a scan that finds nothing.
+    {
+        std::vector<uint32_t> keep;
+        for (uint32_t i : elig) {
+            uint8_t hd[16] = {0};
+            if (hipMemcpy(hd, d_in + chunks[i].in_off, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            int at = container == 1 ? ((hd[3] & 0x1c) ? -1 : 10) : container == 2 ? 2 : 0;  // (gzip with optional fields: not looked at)
+            if (at >= 0 && ((hd[at] >> 1) & 3) == 0) continue;
+            keep.push_back(i);
+        }
+        elig.swap(keep);
+        if (elig.empty()) return 0;
+    }
     // ---- where spans may start
     std::vector<fl_scan_point> points;
     std::vector<uint32_t> pt_first(elig.size() + 1, 0);
@@ -724,13 +738,19 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    // (streams without a single copy that reaches before its span -- huffman-only, store-only ones -- need neither)
+    bool uses_hist = false;
+    for (uint32_t si : chain_all) uses_hist = uses_hist || r1[si].uses_hist != 0;
+    if (dbg) fprintf(stderr, "[spans] history needed: %d\n", (int)uses_hist);
     {
         ProfScope ps(h, K_INFLATE_SPAN);
-        hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
-                           (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u);
-        hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
-                           (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
+        if (uses_hist) {
+            hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+                               (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
+                               (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u);
+            hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
+                               (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
+        }
         hipLaunchKernelGGL(k_inflate_span<2>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                            (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
                            (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u);

@@ -107,7 +107,7 @@ struct fp_shared {
     fp_long lit_long, dst_long;
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
     uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
-    uint32_t nblk, stop;  // spans: blocks decoded so far; the span ends here
+    uint32_t nblk, stop, uses_hist;  // spans: blocks decoded so far; the span ends here; a copy reached before its start
     uint32_t err_far;  // a copy of this round reaches before the start of the output (set in step 6, read after its barrier)
     uint32_t st_len;  // stored block: bytes
     uint32_t wbits;   // bits per wave and round
@@ -272,7 +272,9 @@ struct fl_span_res {
     uint32_t status;      // 0: decoded; anything else: the stream goes the old way
     uint32_t final_seen;  // stopped behind the final block
     uint32_t crc, adA, adB;  // pass 2: checksum pieces of its output (adB counts from the end of the span)
-    uint32_t tail_same;      // pass 2: the tail equals the one of pass 1
+    uint32_t tail_same;      // pass 2: the tail equals the resolved one
+    uint32_t uses_hist;      // pass 1: a copy reaches before the span's first byte
+    uint32_t pad;
 };
 #define FP_TAIL 32768u
 #define FP_NO_SPAN 0xffffffffu
@@ -363,7 +365,10 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             }
             ((FL_LDS uint32_t*)&sh->ring[FP_RING - FP_TAIL])[i] = v;
         }
-        if (tid == 0) sh->nblk = 0;
+        if (tid == 0) {
+            sh->nblk = 0;
+            sh->uses_hist = 0;
+        }
     }
     __syncthreads();
 
@@ -719,7 +724,8 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         // the window); short copies are written by their own lanes, long ones by the wave
                         const bool is_m = ok && (t >> 31);
                         const uint32_t mlen_l = (t >> 16) & 0x1ff, mdist_l = (t & 0xffff) + 1;
-                        if (is_m && (uint64_t)mdist_l > wp + my_off + hist_avail) sh->err_far = 1;  // reaches before the start of the output
+                        if (is_m && (uint64_t)mdist_l > wp + my_off + hist_avail) sh->err_far = 1;
+                        if (MODE == 1 && is_m && (uint64_t)mdist_l > wp + my_off) sh->uses_hist = 1;  // reaches before the start of the output
                         const uint32_t src0 = my_off + 32768u - mdist_l;
                         const uint32_t shortmax = fl_wave_max(is_m && mlen_l <= 32 ? mlen_l : 0u);
                         for (uint32_t i = 0; i < shortmax; i++)
@@ -857,6 +863,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             rr->out_len = n_out;
             rr->final_seen = final_seen ? 1u : 0u;
             rr->tail_same = any_diff ? 0u : 1u;
+            rr->uses_hist = sh->uses_hist;
             rr->status = 0;
         }
         if (MODE == 1) return;
@@ -947,28 +954,150 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
 
 // ------------------------------------------------------------------ k_span_scan
 // Where can a span start?  At the first bit position at or behind a target position at which a dynamic block
-// header parses (inflate.zig:137-218: type bits 10, HLIT / HDIST in range, a complete code-length code, complete
-// literal / distance codes with an end-of-block symbol).  One workgroup per target: every lane tests one bit
-// position against what costs a few instructions (type, HLIT, HDIST, Kraft sum of the code-length code), wave 0
-// then runs the real header parser on the survivors in ascending order.  A position that passes by accident
-// inside compressed data is harmless: no span lands on it, its span is dead.
+// header parses (inflate.zig:137-218: type bits 10, HLIT / HDIST in range, a complete code-length code, code
+// lengths that decode without overrun into a complete literal / length code with an end-of-block symbol and a
+// usable distance code).  One workgroup per target, windows of 64 Kibit:
+//   1. every lane tests bit positions against what costs a few instructions (type, HLIT, HDIST, the Kraft sum of
+//      the code-length code): about 1 in 250 survives;
+//   2. every survivor gets a LANE that decodes its code lengths on its own (canonical code-length code held in
+//      registers, bits straight from memory) and checks the sums;
+//   3. wave 0 runs the real header parser (fl_inf_dynamic_header) on what is left, lowest position first.
+// Steps 1 and 2 may refuse a header the parser would take (the span before just gets longer) but what they pass
+// is only a candidate until step 3 agrees.  A position that parses by accident inside compressed data is
+// harmless too: no span lands on it, its span is dead.
 struct fl_scan_point {
     uint64_t from_bit, limit_bit;  // search [from_bit, limit_bit)
     uint32_t stream, pad;
 };
+#define FP_SCAN_WIN_BITS 65536u
+#define FP_SCAN_STAGE_DW (FP_SCAN_WIN_BITS / 32 + 8)
+#define FP_SCAN_CAP 2048u
 struct fp_scan_shared {
     fl_inflate_ws ws;
     uint32_t inring[FL_INF_INRING / 4];
-    uint32_t stage[48];
-    uint32_t surv[FP_THREADS];
-    uint32_t wcount[FP_WAVES];
+    uint32_t stage[FP_SCAN_STAGE_DW];
+    uint32_t surv[FP_SCAN_CAP];  // window bit offsets of the survivors of step 1 (any order)
+    uint32_t nsurv, npass;
+    uint32_t passed[64];         // ... of step 2
     uint32_t found;
-    uint64_t found_bit;
 };
-__global__ __launch_bounds__(FP_THREADS, 1) void k_span_scan(const uint8_t* __restrict__ in,
-                                                             const fl_chunk* __restrict__ chunks, int flags,
-                                                             const fl_scan_point* __restrict__ points,
-                                                             uint64_t* __restrict__ found_out) {
+
+// 64 bits of the stream from bit position `bit` (zero beyond the end)
+__device__ __forceinline__ uint64_t fp_bits_at(const uint8_t* src, uint32_t in_len, uint64_t bit) {
+    const uint32_t by = (uint32_t)(bit >> 3), k = (uint32_t)bit & 7;
+    const uint64_t lo = fl_load_u32_clamped(src, by, in_len), mid = fl_load_u32_clamped(src, by + 4, in_len);
+    const uint64_t hi = fl_load_u32_clamped(src, by + 8, in_len);
+    const uint64_t v = lo | (mid << 32);
+    return k ? (v >> k) | (hi << (64 - k)) : v;
+}
+
+// Step 2 for one position, by one lane.
+__device__ bool fp_scan_header_lane(const uint8_t* src, uint32_t in_len, uint64_t bit) {
+    const uint64_t total_bits = (uint64_t)in_len * 8;
+    uint64_t b = fp_bits_at(src, in_len, bit);
+    const uint32_t hlit = (uint32_t)(b >> 3) & 31, hdist = (uint32_t)(b >> 8) & 31, ncl = ((uint32_t)(b >> 13) & 15) + 4;
+    const uint32_t nlit = hlit + 257, ntot = nlit + hdist + 1;
+    uint64_t pos = bit + 17;
+    // code lengths of the code-length alphabet (3 bits each, permuted order), packed by symbol
+    uint64_t clen = 0;
+    {
+        const uint64_t b2 = fp_bits_at(src, in_len, pos);
+        // order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+        const uint64_t order = 0x10ull | (0x11ull << 5) | (0x12ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) |
+                               (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+        const uint64_t order2 = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+        for (uint32_t i = 0; i < ncl; i++) {
+            const uint32_t sym = i < 12 ? (uint32_t)(order >> (5 * i)) & 31 : (uint32_t)(order2 >> (5 * (i - 12))) & 31;
+            const uint64_t l = (b2 >> (3 * i)) & 7;  // (3 * 18 + 3 = 57 bits)
+            clen |= l << (3 * sym);
+        }
+        pos += 3 * ncl;
+    }
+    // canonical code: per length the number of codes, and the symbols ordered by (length, symbol)
+    uint32_t count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t sy = 0; sy < 19; sy++) {
+        const uint32_t l = (uint32_t)(clen >> (3 * sy)) & 7;
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) count[k] += l == k ? 1u : 0u;
+    }
+    uint64_t symlo = 0, symhi = 0;  // 19 x 5 bits
+    {
+        uint32_t n = 0;
+        for (uint32_t k = 1; k < 8; k++)
+            for (uint32_t sy = 0; sy < 19; sy++)
+                if (((uint32_t)(clen >> (3 * sy)) & 7) == k) {
+                    if (n < 12)
+                        symlo |= (uint64_t)sy << (5 * n);
+                    else
+                        symhi |= (uint64_t)sy << (5 * (n - 12));
+                    n++;
+                }
+    }
+    uint32_t kl = 0, kd = 0, nd = 0, prev = 0, eob = 0;  // Kraft sums (in units of 2^-15), distance codes, last length
+    uint32_t i = 0;
+    uint32_t have = 0;
+    b = 0;
+    while (i < ntot) {
+        if (have < 16) {
+            if (pos >= total_bits) return false;
+            b = fp_bits_at(src, in_len, pos);
+            have = 64;
+        }
+        // one symbol of the code-length code, bit by bit (huffman_decoder.zig:156-175 finds it the same way)
+        uint32_t code = 0, first = 0, index = 0, sym = 32, used = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) {
+            if (sym == 32) {
+                code |= (uint32_t)(b >> (k - 1)) & 1;
+                const uint32_t c = count[k];
+                if (code < first + c) {
+                    const uint32_t n = index + (code - first);
+                    sym = n < 12 ? (uint32_t)(symlo >> (5 * n)) & 31 : (uint32_t)(symhi >> (5 * (n - 12))) & 31;
+                    used = k;
+                }
+                index += c;
+                first = (first + c) << 1;
+                code <<= 1;
+            }
+        }
+        if (sym == 32) return false;
+        b >>= used;
+        have -= used;
+        pos += used;
+        uint32_t rep = 1, len = sym;
+        if (sym == 16) {
+            if (i == 0) return false;
+            rep = 3 + ((uint32_t)b & 3);
+            len = prev;
+            b >>= 2; have -= 2; pos += 2;
+        } else if (sym == 17) {
+            rep = 3 + ((uint32_t)b & 7);
+            len = 0;
+            b >>= 3; have -= 3; pos += 3;
+        } else if (sym == 18) {
+            rep = 11 + ((uint32_t)b & 127);
+            len = 0;
+            b >>= 7; have -= 7; pos += 7;
+        }
+        if (i + rep > ntot) return false;
+        if (len) {
+            // (a run may cross from the literal / length lengths into the distance lengths)
+            const uint32_t nl = i < nlit ? min(rep, nlit - i) : 0u;
+            kl += nl * (32768u >> len);
+            kd += (rep - nl) * (32768u >> len);
+            nd += rep - nl;
+            if (i <= 256 && i + rep > 256) eob = 1;
+        }
+        prev = len;
+        i += rep;
+    }
+    if (pos > total_bits) return false;
+    return eob && kl == 32768u && (kd == 32768u || nd <= 1);
+}
+
+__global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
+                                                          int flags, const fl_scan_point* __restrict__ points,
+                                                          uint64_t* __restrict__ found_out) {
     __shared__ fp_scan_shared sm;
     FL_LDS fp_scan_shared* sh = (FL_LDS fp_scan_shared*)&sm;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
@@ -983,50 +1112,67 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_span_scan(const uint8_t* __re
     r.lane = lane;
     r.inring = (FL_LDS uint32_t*)sh->inring;
     r.left = (int64_t)total_bits;
-    if (tid == 0) sh->found = 0;
-    __syncthreads();
-    for (uint64_t base = pt.from_bit; base < pt.limit_bit; base += FP_THREADS) {
-        // the bits [base, base + 1024 + 160) of the stream
-        const uint32_t byte0 = (uint32_t)(base >> 3);
-        if (tid < 48) sh->stage[tid] = fl_load_u32_clamped(src, byte0 + 4 * tid, ck.in_len);
+    uint64_t found_bit = ~0ull;
+    for (uint64_t base = pt.from_bit; base < pt.limit_bit; base += FP_SCAN_WIN_BITS) {
+        const uint32_t byte0 = (uint32_t)(base >> 3), bsh = (uint32_t)base & 7;
+        for (uint32_t i = tid; i < FP_SCAN_STAGE_DW; i += FP_THREADS) sh->stage[i] = fl_load_u32_clamped(src, byte0 + 4 * i, ck.in_len);
+        if (tid == 0) {
+            sh->nsurv = 0;
+            sh->npass = 0;
+            sh->found = 0;
+        }
         __syncthreads();
-        const uint64_t bit = base + tid;
-        bool pass = false;
-        if (bit < pt.limit_bit && bit + 17 + 12 <= total_bits) {
-            const uint32_t rel = (uint32_t)(base & 7) + tid;
-            uint32_t lo, hi, lo2, hi2;
-            fp_fetch64(sh->stage, rel, lo, hi);
-            fp_fetch64(sh->stage, rel + 62, lo2, hi2);
-            const uint64_t b64 = (uint64_t)lo | ((uint64_t)hi << 32);
-            const uint32_t btype = (lo >> 1) & 3, hlit = (lo >> 3) & 31, hdist = (lo >> 8) & 31, ncl = ((lo >> 13) & 15) + 4;
-            uint32_t kraft = 0, nz = 0;
+        // ---- 1
+        for (uint32_t j = 0; j < FP_SCAN_WIN_BITS; j += FP_THREADS) {
+            const uint32_t wb = j + tid;
+            const uint64_t bit = base + wb;
+            if (bit < pt.limit_bit && bit + 17 + 12 <= total_bits) {
+                uint32_t lo, hi, lo2, hi2;
+                fp_fetch64(sh->stage, bsh + wb, lo, hi);
+                const uint32_t btype = (lo >> 1) & 3, hlit = (lo >> 3) & 31, hdist = (lo >> 8) & 31, ncl = ((lo >> 13) & 15) + 4;
+                if (btype == 2 && hlit <= 29 && hdist <= 29) {
+                    fp_fetch64(sh->stage, bsh + wb + 62, lo2, hi2);
+                    const uint64_t b64 = (uint64_t)lo | ((uint64_t)hi << 32);
+                    uint32_t kraft = 0, nz = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 19; i++) {
-                const uint32_t len = i < 15 ? (uint32_t)(b64 >> (17 + 3 * i)) & 7u : (lo2 >> (3 * i - 45)) & 7u;
-                if (i < ncl && len) {
-                    kraft += 128u >> len;
-                    nz++;
+                    for (uint32_t i = 0; i < 19; i++) {
+                        const uint32_t len = i < 15 ? (uint32_t)(b64 >> (17 + 3 * i)) & 7u : (lo2 >> (3 * i - 45)) & 7u;
+                        if (i < ncl && len) {
+                            kraft += 128u >> len;
+                            nz++;
+                        }
+                    }
+                    if ((kraft == 128 || nz <= 1) && bit + 17 + 3 * ncl <= total_bits) {
+                        const uint32_t k = atomicAdd(&sm.nsurv, 1u);
+                        if (k < FP_SCAN_CAP) sh->surv[k] = wb;
+                    }
                 }
             }
-            pass = btype == 2 && hlit <= 29 && hdist <= 29 && (kraft == 128 || nz <= 1) && bit + 17 + 3 * ncl <= total_bits;
         }
-        // survivors in ascending order
-        const uint64_t pm = __ballot(pass);
-        if (lane == 0) sh->wcount[wave] = (uint32_t)__popcll(pm);
         __syncthreads();
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < FP_WAVES; w++) {
-            const uint32_t n = sh->wcount[w];
-            before += w < wave ? n : 0u;
-            total += n;
+        // ---- 2
+        const uint32_t ns = min(sh->nsurv, FP_SCAN_CAP);
+        for (uint32_t k = tid; k < ns; k += FP_THREADS) {
+            const uint32_t wb = sh->surv[k];
+            if (fp_scan_header_lane(src, ck.in_len, base + wb)) {
+                const uint32_t q = atomicAdd(&sm.npass, 1u);
+                if (q < 64) sh->passed[q] = wb;
+            }
         }
-        if (pass) sh->surv[before + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = tid;
         __syncthreads();
+        // ---- 3
         if (wave == 0) {
-            for (uint32_t k = 0; k < total; k++) {
-                const uint64_t cb = base + sh->surv[k];
-                // the reader at that bit (as in fp_body)
-                r.left = (int64_t)(total_bits - cb);
+            const uint32_t np = min(sh->npass, 64u);
+            uint32_t mine = lane < np ? sh->passed[lane] : 0xffffffffu;
+            for (uint32_t round = 0; round < np; round++) {
+                // the lowest position not tried yet
+                uint32_t lowest = mine;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) lowest = min(lowest, (uint32_t)__shfl_xor((int)lowest, d, 64));
+                if (lowest == 0xffffffffu) break;
+                if (mine == lowest) mine = 0xffffffffu;
+                const uint64_t cb = base + lowest;
+                r.left = (int64_t)(total_bits - cb);  // the reader at that bit (as in fp_body)
                 fl_br_seek(r, (uint32_t)(cb >> 3));
                 const uint32_t kb = (uint32_t)cb & 7;
                 if (kb) {
@@ -1039,18 +1185,19 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_span_scan(const uint8_t* __re
                 if (!rc) rc = fl_br_read(r, 2, btype);
                 if (!rc && btype == 2) rc = fl_inf_dynamic_header(r, ws, flags, lane);
                 if (!rc && btype == 2) {
-                    if (lane == 0) {
-                        sh->found = 1;
-                        sh->found_bit = cb;
-                    }
+                    if (lane == 0) sh->found = lowest + 1u;
                     break;
                 }
             }
         }
         __syncthreads();
-        if (sh->found) break;
+        if (sh->found) {
+            found_bit = base + (sh->found - 1u);
+            break;
+        }
+        __syncthreads();  // (the lists are rewritten by the next window)
     }
-    if (tid == 0) found_out[blockIdx.x] = sh->found ? sh->found_bit : ~0ull;
+    if (tid == 0) found_out[blockIdx.x] = found_bit;
 }
 
 // One workgroup per stream.  `min_bytes`: shorter streams are left to k_inflate.
