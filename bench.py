@@ -630,6 +630,34 @@ def other_workloads(args, torch, eng, device):
         res[name] = {"MBps": round(d.numel() * 2 / dt / 1e6, 1), "ratio": round(float(lens.sum()) / d.numel(), 4),
                      "sampled_chunks_equal_oracle": ok}
         del job, d
+    res.update(one_stream_inflate(args, torch, eng, device))
+    return res
+
+
+def one_stream_inflate(args, torch, eng, device):
+    """Inflate of ONE long stream, device-resident (the reference's own decompress benchmark is one 177 MB file,
+    readme.md:47 / bin/inflate_bench.zig:14): a gzip level-6 stream of 177,244,160 bytes of text and the
+    huffman-only stream of BASELINE.json configs[3] (128 MiB of the Silesia-like mix), both made by this engine."""
+    from flate_amd import synth
+    res = {}
+    cases = [("gunzip_one_177MB_level6_text_stream", lambda: synth.text_torch(synth.SEED_TEXT + 7, 177_244_160, device=device), 6),
+             ("gunzip_one_128MiB_huffman_only_stream",
+              lambda: torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA, 128 << 20)).to(device), 1)]
+    for name, mk, mode in cases:
+        d = mk()
+        n = d.numel()
+        job = CompressJob(torch, eng, d, n, 1, mode)
+        job.step()
+        torch.cuda.synchronize()
+        lens = job.results()
+        comp, comp_off, n_comp = job.packed(lens)
+        inf = InflateJob(torch, eng, comp, comp_off, 1, job.in_off, n, 1)
+        dt, prof = timed(torch, None, eng, inf.step, 3, 1, 1)
+        ok = int(inf.dec_st.abs().sum().item()) == 0 and bool(torch.equal(inf.dec[:n], d))
+        assert ok or args.no_verify, "%s: inflate(deflate(x)) != x" % name
+        res[name] = {"MBps": round(n * 3 / dt / 1e6, 1), "ms": round(dt / 3 * 1e3, 2), "compressed_bytes": int(n_comp),
+                     "kernels_ms": {k: round(v[0] / 3, 2) for k, v in sorted(prof.items())}, "output_equals_input": ok}
+        del job, inf, d, comp
     return res
 
 

@@ -579,25 +579,16 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     const uint64_t min_bytes = e ? (uint64_t)atoll(e) : FL_SPAN_MIN_BYTES;
     if (!min_bytes || (flags & 1)) return 0;
     const bool dbg = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
+    // Worth it (every span is decoded two or three times) when the long streams of the batch are too few to fill
+    // the chip with a workgroup each: at most 32 of them
     std::vector<uint32_t> elig;
-    for (uint32_t i = 0; i < n_chunks; i++)
+    uint32_t n_long = 0;
+    for (uint32_t i = 0; i < n_chunks; i++) {
+        n_long += chunks[i].in_len >= 32768u ? 1u : 0u;
         if (chunks[i].in_len >= min_bytes) elig.push_back(i);
-    if (elig.empty() || elig.size() > 64) return 0;
-    int rc;
-    // A stream that begins with a stored block is most likely stored throughout (store-only mode, incompressible
-    // data): no dynamic header to cut it at.  It keeps the old way rather than paying for a scan that finds nothing.
-    {
-        std::vector<uint32_t> keep;
-        for (uint32_t i : elig) {
-            uint8_t hd[16] = {0};
-            if (hipMemcpy(hd, d_in + chunks[i].in_off, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-            int at = container == 1 ? ((hd[3] & 0x1c) ? -1 : 10) : container == 2 ? 2 : 0;  // (gzip with optional fields: not looked at)
-            if (at >= 0 && ((hd[at] >> 1) & 3) == 0) continue;
-            keep.push_back(i);
-        }
-        elig.swap(keep);
-        if (elig.empty()) return 0;
     }
+    if (elig.empty() || n_long > 32 || elig.size() > 256) return 0;
+    int rc;
     // ---- where spans may start
     std::vector<fl_scan_point> points;
     std::vector<uint32_t> pt_first(elig.size() + 1, 0);
