@@ -12,6 +12,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <functional>
 
 #include "../../include/flate_hip.h"
 #include "kernels_block.h"
@@ -84,6 +86,9 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag;
+    void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
+    void* pin_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0;
     DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff;  // inflate of long streams by spans
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
@@ -853,6 +858,8 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
                       &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff})
         if (b->p) (void)hipFree(b->p);
@@ -960,6 +967,57 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     const std::vector<uint64_t>& hout = pl ? pl->hout : hout_;
     const uint64_t in_lo = hin[0], in_hi = hin[n_chunks];
     const uint64_t out_lo = hout[0], out_hi = hout[n_chunks];
+
+    // Pageable host buffers of some size (what every caller of the facade's compress(reader, writer) has): a
+    // staged hipMemcpy each way moves about 10 GB/s and nothing overlaps.  Instead a few host threads copy the
+    // input into a pinned mirror, the call runs on the mirrors (sub-batches, DMA copies on their own streams
+    // beside the kernels: the pinned path below), and the threads copy the produced bytes out of the mirror.
+    if (memkind == FLATE_HIP_MEM_HOST && !fs && !pl && (in_hi - in_lo) >= (8ull << 20) && in && out &&
+        !is_pinned_host(in + in_lo) && !is_pinned_host(out + out_lo) && !getenv("FLATE_HIP_NO_PIN_MIRROR")) {
+        auto grow = [&](void*& p, size_t& cap, size_t want) -> bool {
+            if (want <= cap) return true;
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t sz = want + want / 8 + 4096;
+            if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                p = nullptr;
+                return false;
+            }
+            cap = sz;
+            return true;
+        };
+        if (grow(h->pin_in, h->pin_in_cap, (in_hi - in_lo) + 16) && grow(h->pin_out, h->pin_out_cap, (out_hi - out_lo) + 16)) {
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            const unsigned nt = std::min(8u, hw);
+            auto parallel = [&](uint64_t items, const std::function<void(uint64_t, uint64_t)>& fn) {
+                std::vector<std::thread> th;
+                const uint64_t per = (items + nt - 1) / nt;
+                for (unsigned t = 1; t < nt; t++) {
+                    const uint64_t a = std::min(items, t * per), b = std::min(items, a + per);
+                    if (b > a) th.emplace_back(fn, a, b);
+                }
+                fn(0, std::min(items, per));
+                for (auto& x : th) x.join();
+            };
+            const uint8_t* src = in + in_lo;
+            uint8_t* pin = (uint8_t*)h->pin_in;
+            parallel(in_hi - in_lo, [&](uint64_t a, uint64_t b) { memcpy(pin + a, src + a, b - a); });
+            // the mirrors take the place of the caller's buffers: same offsets
+            rc = compress_impl(h, pin - in_lo, in_off, n_chunks, container, mode, (uint8_t*)h->pin_out - out_lo, out_off, out_len,
+                               status, memkind, nullptr, nullptr);
+            if (rc) return rc;
+            const uint8_t* pout = (const uint8_t*)h->pin_out;
+            parallel(n_chunks, [&](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; i++) {
+                    const uint64_t n = std::min<uint64_t>(out_len[i], hout[i + 1] - hout[i]);
+                    if (n) memcpy(out + hout[i], pout + (hout[i] - out_lo), n);
+                }
+            });
+            return FLATE_HIP_OK;
+        }
+    }
 
     // device views of the caller's buffers
     const uint8_t* d_in = in;
