@@ -1225,20 +1225,54 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
                   fill);
 }
 
-// The true tails of a stream's spans, in chain order (one workgroup per stream; see above).  tails_a is resolved in place.
+// The true tails of a stream's spans, in chain order (one workgroup per stream; see above).  tails_a is resolved in
+// place.  The tail before the current one is kept in LDS: a span costs one round of loads and one barrier.
 __global__ __launch_bounds__(FP_THREADS) void k_span_resolve(const uint32_t* __restrict__ chain,
                                                              const uint32_t* __restrict__ chain_off, uint8_t* tails_a,
                                                              const uint8_t* __restrict__ tails_b) {
+    __shared__ uint32_t tl[2][FP_TAIL / 4];
     const uint32_t k = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t j = chain_off[k] + 1; j < chain_off[k + 1]; j++) {
-        uint8_t* ta = tails_a + (uint64_t)chain[j] * FP_TAIL;
-        const uint8_t* tb = tails_b + (uint64_t)chain[j] * FP_TAIL;
-        const uint8_t* tp = tails_a + (uint64_t)chain[j - 1] * FP_TAIL;
-        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) {
-            const uint32_t a = ta[i], b = tb[i];
-            if (a != b) ta[i] = tp[(((a ^ b) - 1u) << 8) | a];
+    const uint32_t j0 = chain_off[k], j1 = chain_off[k + 1];
+    if (j0 >= j1) return;
+    {
+        const uint4* t0 = (const uint4*)(tails_a + (uint64_t)chain[j0] * FP_TAIL);
+        ((uint4*)tl[0])[2 * tid] = t0[2 * tid];
+        ((uint4*)tl[0])[2 * tid + 1] = t0[2 * tid + 1];
+    }
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t j = j0 + 1; j < j1; j++) {
+        uint4* ta = (uint4*)(tails_a + (uint64_t)chain[j] * FP_TAIL);
+        const uint4* tb = (const uint4*)(tails_b + (uint64_t)chain[j] * FP_TAIL);
+        const uint8_t* prev = (const uint8_t*)tl[cur];
+        uint32_t* mine = tl[cur ^ 1];
+        uint4 a[2] = {ta[2 * tid], ta[2 * tid + 1]};
+        const uint4 b[2] = {tb[2 * tid], tb[2 * tid + 1]};
+        bool changed = false;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint32_t aw[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+            const uint32_t bw[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t x = aw[w] ^ bw[w];
+                if (x) {  // a byte that differs is history byte ((a ^ b) - 1) << 8 | a of the tail before
+                    changed = true;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        const uint32_t xa = (aw[w] >> (8 * y)) & 0xff, xd = (x >> (8 * y)) & 0xff;
+                        if (xd) aw[w] = (aw[w] & ~(0xffu << (8 * y))) | ((uint32_t)prev[((xd - 1u) << 8) | xa] << (8 * y));
+                    }
+                }
+                mine[8 * tid + 4 * q + w] = aw[w];
+            }
+            a[q] = make_uint4(aw[0], aw[1], aw[2], aw[3]);
         }
-        __threadfence();
+        if (changed) {
+            ta[2 * tid] = a[0];
+            ta[2 * tid + 1] = a[1];
+        }
         __syncthreads();
+        cur ^= 1;
     }
 }
