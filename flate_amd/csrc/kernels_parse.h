@@ -230,10 +230,25 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #define PZ_NEED 48               // ... fewer when this many lanes wait for the slow block
 #endif
 #ifndef PZ_UNROLL
-#define PZ_UNROLL 8               // chain steps between two looks at the other lanes
+#define PZ_UNROLL 16              // chain steps between two looks at the other lanes
 #endif
 #ifndef PZ_TRANS_ITERS
 #define PZ_TRANS_ITERS 1         // automaton moves per lane and slow block (runs of literals)
+#endif
+#define PZ_STR2(X) #X
+#define PZ_STR(X) PZ_STR2(X)
+#if PZ_UNROLL == 8
+#define PZ_HALF_UNROLL 4
+#elif PZ_UNROLL == 4
+#define PZ_HALF_UNROLL 2
+#elif PZ_UNROLL == 16
+#define PZ_HALF_UNROLL 8
+#elif PZ_UNROLL == 24
+#define PZ_HALF_UNROLL 12
+#elif PZ_UNROLL == 32
+#define PZ_HALF_UNROLL 16
+#else
+#error PZ_UNROLL: 4, 8, 16, 24 or 32
 #endif
 #define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
 #define PZ_SEG_B 32u
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     uint32_t* descg = desc_all + ck.pos_off;
     uint32_t* trueg = true_all + (ck.pos_off >> 5);
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    const uint32_t prv_lds = (uint32_t)(size_t)(fl_lds_u32*)prv, win_lds = (uint32_t)(size_t)(fl_lds_u32*)win32;  // LDS byte addresses
     if (cflag[c] == 1u) {
         // The chunk is one repeated byte (k_lz_chain saw it and built no chains).  Positions 0 and 1 are
         // literals (the only candidate of position 1 is position 0, the chain's null: deflate.zig:248); from
@@ -466,9 +482,21 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             // ---- the automaton (deflate.zig:154-205)
             uint64_t amask = 0;
             uint32_t j = 0, plen = 0, pdist = 0;
-            uint32_t p = 0, q = 0, cnt = 0, crem = 0, lo = 1, best = 0, bdist = 0, maxlen = 0, off = 0, pref = 0;
+            uint32_t p = 0, q = 0, cnt = 0, crem = 0, lo = 1, best = 0, bdist = 0, maxlen = 0, pref = 0;
             uint32_t qh = PZ_NOHIT;
+            // A walking lane holds what its candidate q needs to be judged: the link nqA = prv[q] and the two aligned
+            // window dwords w0A, w1A that hold q's bytes number off .. off + 3 (xq = q + offb: the LDS byte address of
+            // the first of them; offb = off + the LDS address of the window).  The burst below loads the same for the
+            // link while q is judged, into nqB, w0B, w1B, and swaps the roles every step.
+            uint32_t nqA = 0, w0A = 0, w1A = 0, xq = 0, offb = win_lds;
             // cnt = candidates the current call may still look at, 0 when the lane is not walking a chain
+            // pref = the call's own bytes number off .. off + 3, off = best - 3: a candidate that is to beat `best`
+            // agrees with all of them (SlidingWindow.zig:91-98 tests the last one)
+#define PZ_SET_FILTER(OFF)                                                     \
+    do {                                                                       \
+        offb = (OFF) + win_lds;                                                \
+        pref = pz_lds4(win32, p + (OFF));                                      \
+    } while (0)
 #define PZ_START_CALL(PP, LL, BUDGET)                                          \
     do {                                                                       \
         p = (PP);                                                              \
@@ -478,8 +506,14 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         q = prv[p];                                                            \
         lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
         cnt = (maxlen > best && q >= lo) ? (BUDGET) : 0u;                      \
-        off = best ? best - 3u : 0u;                                           \
-        pref = pz_lds4(win32, p + off);                                        \
+        PZ_SET_FILTER(best ? best - 3u : 0u);                                  \
+    } while (0)
+#define PZ_LOAD_CAND()                                                         \
+    do {                                                                       \
+        xq = q + offb;                                                         \
+        nqA = prv[q];                                                          \
+        w0A = win32[(xq - win_lds) >> 2];                                      \
+        w1A = win32[((xq - win_lds) >> 2) + 1];                                \
     } while (0)
             // a parse that starts on a position where it has to stop already (FIX only)
             if (st == ST_FIX && ((stopmask >> ((a - seg0) & 63u)) & 1ull)) {
@@ -489,7 +523,10 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 res_exit = X;
                 st = ST_DONE;
             }
-            if (st != ST_DONE) PZ_START_CALL(a, 0u, chain);
+            if (st != ST_DONE) {
+                PZ_START_CALL(a, 0u, chain);
+                if (cnt != 0) PZ_LOAD_CAND();
+            }
             for (;;) {
                 PZ_CNT(c_loops, 1);
 #ifdef PZ_PROF
@@ -508,27 +545,83 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                     if (mw == 0 || __popcll(serve & ~mw) >= PZ_NEED) break;
                     PZ_CNT(c_fast, 1);
                     PZ_CNT(c_walk, __popcll(mw));
-                    // (the loads of candidate k + 1 are issued as soon as its position is known, before candidate k
-                    // is judged: one LDS round trip per step on the critical path; a load past the end of a walk
-                    // reads position 0's entries and is dropped)
-                    {
-                        uint32_t w = pz_lds4(win32, q + off);
-                        uint32_t nq = prv[q];
-#pragma unroll
-                        for (int u = 0; u < PZ_UNROLL; u++) {
-                            const uint32_t w2 = pz_lds4(win32, nq + off);
-                            const uint32_t nq2 = prv[nq];
-                            if (cnt != 0) {
-                                const bool hit = w == pref;
-                                if (hit) {
-                                    qh = q;
-                                    crem = cnt - 1u;
-                                }
-                                q = nq;
-                                cnt = (hit || nq < lo) ? 0u : cnt - 1u;
-                                w = w2;
-                                nq = nq2;
+                    if (cnt != 0) {
+                        // PZ_UNROLL steps written out by hand.  Per step and wave the serial chain is: the link of the
+                        // candidate arrives -> its LDS address -> the load of ITS link; the candidate itself is judged
+                        // while that load (and the load of the link's window dwords) is in flight, from registers that
+                        // change roles every step (measured, profiles/r03_parse_experiments.txt: an instruction on the
+                        // chain costs three times one in the shadow of the loads).  A lane leaves the burst -- its exec
+                        // bit is cleared -- when its candidate passes the filter (qh, nqh, cnt keep what the measure
+                        // needs) or its walk ends.
+                        uint32_t nqB, w0B, w1B, a1, a2, xn, t, nqh = 0;
+                        uint64_t s_save, s_t, s_hit;
+                        asm volatile(
+                            "s_mov_b64 %[ssave], exec\n\t"
+                            "s_mov_b64 %[shit], 0\n\t"
+                            ".rept " PZ_STR(PZ_HALF_UNROLL) "\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqA], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqB], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqA], %[offb]\n\t"
+                            "v_and_b32 %[a2], -4, %[xn]\n\t"
+                            "ds_read_b32 %[w0B], %[a2]\n\t"
+                            "ds_read_b32 %[w1B], %[a2] offset:4\n\t"
+                            "v_alignbyte_b32 %[t], %[w1A], %[w0A], %[xq]\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqA], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqA], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqA]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqB], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqA], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqB], %[offb]\n\t"
+                            "v_and_b32 %[a2], -4, %[xn]\n\t"
+                            "ds_read_b32 %[w0A], %[a2]\n\t"
+                            "ds_read_b32 %[w1A], %[a2] offset:4\n\t"
+                            "v_alignbyte_b32 %[t], %[w1B], %[w0B], %[xq]\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqB], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqB], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqB]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            ".endr\n\t"
+                            ".Lpz_done_%=:\n\t"
+                            "s_mov_b64 %[st], exec\n\t"
+                            "s_mov_b64 exec, %[ssave]\n\t"
+                            : [q] "+v"(q), [cnt] "+v"(cnt), [nqA] "+v"(nqA), [w0A] "+v"(w0A), [w1A] "+v"(w1A), [xq] "+v"(xq),
+                              [qh] "+v"(qh), [nqh] "+v"(nqh), [nqB] "=&v"(nqB), [w0B] "=&v"(w0B), [w1B] "=&v"(w1B),
+                              [a1] "=&v"(a1), [a2] "=&v"(a2), [xn] "=&v"(xn), [t] "=&v"(t), [ssave] "=&s"(s_save),
+                              [st] "=&s"(s_t), [shit] "=&s"(s_hit)
+                            : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
+                            : "vcc", "memory");
+                        // s_t: the lanes that are still walking (their candidate's data is in the A registers again:
+                        // an even number of steps); s_hit: those that stopped on a candidate that passes the filter
+                        const uint32_t ln = threadIdx.x & 63u;
+                        if (!((s_t >> ln) & 1ull)) {
+                            if ((s_hit >> ln) & 1ull) {
+                                crem = cnt - 1u;
+                                q = nqh;  // (the walk goes on behind the candidate, at its link)
                             }
+                            cnt = 0;
                         }
                     }
                 }
@@ -568,8 +661,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             if (l >= nice || l >= maxlen) {
                                 cnt = 0;  // ... unless the match is good enough / nothing longer is possible
                             } else {
-                                off = l - 3u;
-                                pref = pz_lds4(win32, p + off);
+                                PZ_SET_FILTER(l - 3u);
                             }
                         }
                         qh = PZ_NOHIT;
@@ -662,12 +754,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                         }
                         if (start) PZ_START_CALL(sp, sl, sb);
                     }
+                    if (cnt != 0) PZ_LOAD_CAND();  // (every lane that comes out of this block walking has a new q)
                 }
 #ifdef PZ_PROF
                 c_ttrans += __builtin_readcyclecounter() - c_tb;
 #endif
             }
 #undef PZ_START_CALL
+#undef PZ_SET_FILTER
+#undef PZ_LOAD_CAND
 #ifdef PZ_PROF
             if (round == 0) c_tspec += __builtin_readcyclecounter() - c_tr0; else c_tstitch += __builtin_readcyclecounter() - c_tr0;
 #endif
