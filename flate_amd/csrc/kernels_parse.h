@@ -224,13 +224,13 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #define PZ_NOHIT 0xffffffffu
 #define PZ_DESC_LIT 0x40000000u  // descriptor of an anchor that emits one literal
 #ifndef PZ_BURST
-#define PZ_BURST 16              // chain steps between two visits of the slow block, at most
+#define PZ_BURST 20              // chain steps between two visits of the slow block, at most
 #endif
 #ifndef PZ_NEED
 #define PZ_NEED 48               // ... fewer when this many lanes wait for the slow block
 #endif
 #ifndef PZ_UNROLL
-#define PZ_UNROLL 16              // chain steps between two looks at the other lanes
+#define PZ_UNROLL 20              // chain steps between two looks at the other lanes
 #endif
 #ifndef PZ_TRANS_ITERS
 #define PZ_TRANS_ITERS 1         // automaton moves per lane and slow block (runs of literals)
@@ -241,6 +241,10 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #define PZ_HALF_UNROLL 4
 #elif PZ_UNROLL == 4
 #define PZ_HALF_UNROLL 2
+#elif PZ_UNROLL == 12
+#define PZ_HALF_UNROLL 6
+#elif PZ_UNROLL == 20
+#define PZ_HALF_UNROLL 10
 #elif PZ_UNROLL == 16
 #define PZ_HALF_UNROLL 8
 #elif PZ_UNROLL == 24
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #elif PZ_UNROLL == 32
 #define PZ_HALF_UNROLL 16
 #else
-#error PZ_UNROLL: 4, 8, 16, 24 or 32
+#error PZ_UNROLL: 4, 8, 12, 16, 20, 24 or 32
 #endif
 #define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
 #define PZ_SEG_B 32u
