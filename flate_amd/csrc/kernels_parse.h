@@ -351,50 +351,106 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint64_t c_ts0 = __builtin_readcyclecounter();
 #endif
         {
+            // Sub-pass B needs positions [r0, 65536); [r0, PZ_TA + ...) of them sit in LDS already, r0 positions further up
+            // (r0 is a multiple of 4: whole dwords of both tables).  They are moved down -- the links re-based -- and only
+            // the rest comes from memory: a third of the loads.
+            const uint32_t wkeep = sub ? PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u : 0u;          // window dwords that stay
+            const uint32_t pkeep = sub ? (PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u : 0u;         // link dwords that stay
             const uint32_t ash = (uint32_t)((uintptr_t)(src + r0) & 3);
             const uint32_t* a32 = (const uint32_t*)(src + r0 - ash);
             const uint32_t ndw = (Nr + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
-            constexpr uint32_t WB = 7;                 // 2 batches cover PZ_WIN_DW / PZ_THREADS dwords per thread
-            for (uint32_t base = 0; base < PZ_WIN_DW; base += WB * PZ_THREADS) {
-                uint32_t lo[WB], hi[WB];
+            const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
+            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);    // r0 is even
+            uint32_t* prv2 = (uint32_t*)prv;
+            auto put_win = [&](uint32_t i, uint32_t lo, uint32_t hi) {
+                uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, ash);
+                if (4 * i + 4 > Nr) v = 4 * i < Nr ? (v & ((1u << (8 * (Nr - 4 * i))) - 1u)) : 0u;  // zero padding
+                if (i < PZ_WIN_DW) win32[i] = v;
+            };
+            auto put_prv = [&](uint32_t i, uint32_t v) {  // two links per dword; relative to r0, 0 = none (also everything below r0)
+                const uint32_t pa = 2 * i + r0;  // absolute position of the low half
+                if (pa >= Mpos) v &= 0xffff0000u;  // positions without a hash entry have no link (never written)
+                if (pa + 1 >= Mpos) v &= 0x0000ffffu;
+                uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
+                lo16 = lo16 > r0 ? lo16 - r0 : 0u;
+                hi16 = hi16 > r0 ? hi16 - r0 : 0u;
+                if (i < PZ_PRV_N / 2) prv2[i] = lo16 | (hi16 << 16);
+            };
+            if (!sub) {
+                constexpr uint32_t WB = 7;  // 2 batches cover PZ_WIN_DW / PZ_THREADS dwords per thread
+                for (uint32_t base = 0; base < PZ_WIN_DW; base += WB * PZ_THREADS) {
+                    uint32_t lo[WB], hi[WB];
 #pragma unroll
-                for (uint32_t u = 0; u < WB; u++) {
-                    const uint32_t i = base + u * PZ_THREADS + tid;
+                    for (uint32_t u = 0; u < WB; u++) {
+                        const uint32_t i = base + u * PZ_THREADS + tid;
+                        lo[u] = i < ndw ? a32[i] : 0u;
+                        hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < WB; u++) put_win(base + u * PZ_THREADS + tid, lo[u], hi[u]);
+                }
+                constexpr uint32_t PB = 8;
+                for (uint32_t base = 0; base < PZ_PRV_N / 2; base += PB * PZ_THREADS) {
+                    uint32_t lv[PB];
+#pragma unroll
+                    for (uint32_t u = 0; u < PB; u++) {
+                        const uint32_t i = base + u * PZ_THREADS + tid;
+                        lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < PB; u++) put_prv(base + u * PZ_THREADS + tid, lv[u]);
+                }
+            } else {
+                // the new part: loads first ...
+                constexpr uint32_t WN = (PZ_WIN_DW - (PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u) + PZ_THREADS - 1) / PZ_THREADS;
+                constexpr uint32_t PN = (PZ_PRV_N / 2 - (PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u + PZ_THREADS - 1) / PZ_THREADS;
+                uint32_t lo[WN], hi[WN], lv[PN];
+#pragma unroll
+                for (uint32_t u = 0; u < WN; u++) {
+                    const uint32_t i = wkeep + u * PZ_THREADS + tid;
                     lo[u] = i < ndw ? a32[i] : 0u;
                     hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < WB; u++) {
-                    const uint32_t i = base + u * PZ_THREADS + tid;
-                    uint32_t v = __builtin_amdgcn_alignbyte(hi[u], lo[u], ash);
-                    if (4 * i + 4 > Nr) v = 4 * i < Nr ? (v & ((1u << (8 * (Nr - 4 * i))) - 1u)) : 0u;  // zero padding
-                    if (i < PZ_WIN_DW) win32[i] = v;
-                }
-            }
-            // two links per dword; relative to r0, 0 = none (also everything below r0)
-            const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
-            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);    // r0 is even
-            uint32_t* prv2 = (uint32_t*)prv;
-            constexpr uint32_t PB = 8;
-            for (uint32_t base = 0; base < PZ_PRV_N / 2; base += PB * PZ_THREADS) {
-                uint32_t lv[PB];
-#pragma unroll
-                for (uint32_t u = 0; u < PB; u++) {
-                    const uint32_t i = base + u * PZ_THREADS + tid;
+                for (uint32_t u = 0; u < PN; u++) {
+                    const uint32_t i = pkeep + u * PZ_THREADS + tid;
                     lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
                 }
+                // ... then what stays: read by everybody, a barrier, written r0 positions further down
+                constexpr uint32_t WK = ((PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u) + PZ_THREADS - 1) / PZ_THREADS;
+                constexpr uint32_t PK = ((PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u + PZ_THREADS - 1) / PZ_THREADS;
+                uint32_t kw[WK], kp[PK];
 #pragma unroll
-                for (uint32_t u = 0; u < PB; u++) {
-                    const uint32_t i = base + u * PZ_THREADS + tid;
-                    const uint32_t pa = 2 * i + r0;  // absolute position of the low half
-                    uint32_t v = lv[u];
-                    if (pa >= Mpos) v &= 0xffff0000u;  // positions without a hash entry have no link (never written)
-                    if (pa + 1 >= Mpos) v &= 0x0000ffffu;
-                    uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
-                    lo16 = lo16 > r0 ? lo16 - r0 : 0u;
-                    hi16 = hi16 > r0 ? hi16 - r0 : 0u;
-                    if (i < PZ_PRV_N / 2) prv2[i] = lo16 | (hi16 << 16);
+                for (uint32_t u = 0; u < WK; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    kw[u] = i < wkeep ? win32[i + r0 / 4u] : 0u;
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < PK; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    kp[u] = i < pkeep ? prv2[i + r0 / 2u] : 0u;
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t u = 0; u < WK; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    if (i < wkeep) win32[i] = kw[u];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < PK; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    if (i < pkeep) {  // (sub-pass A's links count from position 0)
+                        const uint32_t v = kp[u];
+                        uint32_t lo16 = v & 0xffffu, hi16 = v >> 16;
+                        lo16 = lo16 > r0 ? lo16 - r0 : 0u;
+                        hi16 = hi16 > r0 ? hi16 - r0 : 0u;
+                        prv2[i] = lo16 | (hi16 << 16);
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < WN; u++) put_win(wkeep + u * PZ_THREADS + tid, lo[u], hi[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < PN; u++) put_prv(pkeep + u * PZ_THREADS + tid, lv[u]);
             }
         }
         __syncthreads();
