@@ -642,6 +642,109 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
     }
 }
 
+// The same, one WAVE per block (batches of many blocks: the chunk path): no split of a block among waves, so no
+// first pass over the tokens to find out where each wave's bits start -- half the instructions.  A wave's chain is
+// four times as long, four times as many blocks are in flight.
+template <bool TOKENS>
+__global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode_wave(const uint8_t* __restrict__ in,
+                                                              const fl_chunk* __restrict__ chunks,
+                                                              const uint32_t* __restrict__ blk_chunk,
+                                                              const fl_block_plan* __restrict__ plans,
+                                                              const uint32_t* __restrict__ tokens /* [chunk][65536] */,
+                                                              uint32_t* __restrict__ out32, uint32_t n_blocks) {
+    __shared__ uint32_t lit_all[FL_ENC_WAVES][FL_NUM_LIT + 2];
+    __shared__ uint32_t dist_all[FL_ENC_WAVES][FL_NUM_DIST + 2];
+    __shared__ uint32_t stg[FL_ENC_WAVES][FL_STG_DW];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x * FL_ENC_WAVES + wave;
+    if (b >= n_blocks) return;  // (no workgroup barrier below: every wave is on its own)
+    const fl_block_plan* plan = &plans[b];
+    if (!plan->valid) return;
+    const uint32_t cidx = blk_chunk[b];
+    const fl_chunk ck = chunks[cidx];
+    uint32_t* lit_lds = lit_all[wave];
+    uint32_t* dist_lds = dist_all[wave];
+    const uint64_t bit_off = plan->bit_off;
+    const uint8_t* src = in + ck.in_off;
+
+    if (plan->type == FL_BLOCK_STORED) {
+        // storedHeader + bytes (block_writer.zig:283-291, 385-388)
+        const uint32_t len = plan->in_len;
+        const uint64_t p = (bit_off + 3 + 7) >> 3;
+        if (lane == 0) {
+            if (plan->final_block) fl_atomic_or_bits(out32, bit_off, 1, 1);
+            const uint32_t lw = (len & 0xffff) | ((~len & 0xffff) << 16);
+            fl_atomic_or_bits(out32, p * 8, lw, 32);
+        }
+        fl_copy_bytes(out32, p + 4, src + plan->in_start, len, lane, 64);
+        return;
+    }
+
+    for (uint32_t i = lane; i < FL_NUM_LIT; i += 64)
+        lit_lds[i] = (uint32_t)plan->lit[i].code | ((uint32_t)plan->lit[i].len << 16);
+    if (lane < FL_NUM_DIST) dist_lds[lane] = (uint32_t)plan->dist[lane].code | ((uint32_t)plan->dist[lane].len << 16);
+    for (uint32_t i = lane; i < FL_STG_DW; i += 64) stg[wave][i] = 0;
+    fl_lds_order();
+
+    const uint32_t hdr_nbits = plan->hdr_nbits;
+    const uint32_t n_hdr = (hdr_nbits + 7) >> 3;
+    const uint32_t n_sym = plan->tok_count;
+    const uint32_t n_items = n_hdr + n_sym + 1;
+    const uint8_t* bytes = src + plan->tok_start;
+    const uint32_t* toks = TOKENS ? tokens + ck.pos_off + plan->tok_start : nullptr;
+    const uint8_t* hdr = plan->hdr;
+
+    const uint32_t i0 = 0, i1 = n_items;  // the whole block
+    uint64_t cur = bit_off;
+
+    // pass 2: pack
+    const uint64_t first_dw = cur >> 5;
+    uint32_t* sw = stg[wave];
+    for (uint32_t ib = i0; ib < i1; ib += 64) {
+        const uint32_t i = ib + lane;
+        fl_item it;
+        it.v = 0;
+        it.n = 0;
+        if (i < i1) it = fl_block_item<TOKENS>(i, n_hdr, hdr_nbits, n_sym, hdr, bytes, toks, lit_lds, dist_lds);
+        const uint32_t incl = fl_wave_incl_scan(it.n, lane);
+        const uint32_t total = __shfl(incl, 63, 64);
+        const uint64_t base_dw = cur >> 5;
+        if (it.n) {
+            const uint32_t rel = (uint32_t)(cur - (base_dw << 5)) + (incl - it.n);
+            const uint32_t dw = rel >> 5, sh = rel & 31;
+            const uint64_t a = it.v << sh;
+            const uint32_t hi = sh ? (uint32_t)(it.v >> (64 - sh)) : 0u;
+            if ((uint32_t)a) atomicOr(&sw[dw], (uint32_t)a);
+            if ((uint32_t)(a >> 32)) atomicOr(&sw[dw + 1], (uint32_t)(a >> 32));
+            if (hi) atomicOr(&sw[dw + 2], hi);
+        }
+        fl_lds_order();
+        const uint64_t end = cur + total;
+        const uint32_t nd = (uint32_t)((end >> 5) - base_dw);  // complete dwords
+        for (uint32_t k = lane; k < nd; k += 64) {
+            const uint32_t v = sw[k];
+            if (base_dw + k == first_dw) {
+                if (v) atomicOr(&out32[base_dw + k], v);
+            } else {
+                out32[base_dw + k] = v;
+            }
+        }
+        const uint32_t carry = sw[nd];
+        fl_lds_order();
+        // clear the window, keep the partial dword as the new first one
+        for (uint32_t k = lane; k <= nd + 2 && k < FL_STG_DW; k += 64) sw[k] = 0;
+        fl_lds_order();
+        if (lane == 0) sw[0] = carry;
+        fl_lds_order();
+        cur = end;
+    }
+    if ((cur & 31) && lane == 0) {
+        const uint32_t v = sw[0];
+        if (v) atomicOr(&out32[cur >> 5], v);
+    }
+}
+
 // ------------------------------------------------------------------ packing
 // dst_off = exclusive scan of out_len (one workgroup; n is at most a few 100k)
 __global__ __launch_bounds__(1024) void k_scan_lens(const uint64_t* __restrict__ len, uint32_t n,

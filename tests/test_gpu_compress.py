@@ -587,3 +587,37 @@ def test_runny_windows_take_their_variant_and_match_the_oracle():
         assert st == [0] * len(long_cases)
         for d, o in zip(long_cases, outs):
             assert o == O.compress(d, O.GZIP, level), level
+
+
+def test_batches_of_many_blocks_take_the_wave_per_block_encoder(monkeypatch):
+    """From 8192 plan slots up (4096 chunks of the chunk path in one pass) the bit packer runs one wave per block
+    (k_encode_wave): every chunk of such a batch against the oracle -- text, incompressible (stored blocks), empty,
+    one byte, all-zero, and a few of full size whose first block holds 32768 tokens.  (Host buffers staged in one
+    piece: the pinned mirrors would cut the batch into sub-batches of 1024 chunks.)"""
+    from flate_amd import synth
+    monkeypatch.setenv("FLATE_HIP_NO_PIN_MIRROR", "1")
+    eng = engine()
+    rng = np.random.default_rng(31337)
+    text = synth.text(synth.SEED_TEXT + 77, 12 << 20).tobytes()
+    chunks, pos = [], 0
+    for i in range(4300):
+        kind = i % 43
+        if kind == 0:
+            c = b""
+        elif kind == 1:
+            c = b"x"
+        elif kind == 2:
+            c = rng.integers(0, 256, int(rng.integers(1, 5000)), dtype=np.uint8).tobytes()
+        elif kind == 3:
+            c = bytes(int(rng.integers(1, 9000)))
+        elif kind == 4 and i < 400:
+            c = text[pos:pos + 65535]
+        else:
+            c = text[pos:pos + int(rng.integers(20, 4000))]
+        pos = (pos + len(c)) % (len(text) - 70000)
+        chunks.append(c)
+    for container, mode in ((0, 6), (1, 4)):
+        outs, st = eng.compress_many(chunks, container, mode)
+        assert st == [0] * len(chunks)
+        for i, (c, got) in enumerate(zip(chunks, outs)):
+            assert got == O.compress(c, container, mode), (i, len(c), container, mode)
