@@ -71,8 +71,13 @@ class OutputGather:
     `gathered[r * width : r * width + sizes[r]]` is rank r's packed output afterwards.
 
     Stream contract: the engine must run on torch's CURRENT stream (Engine.set_stream(
-    torch.cuda.current_stream().cuda_stream) with a non-default stream current): the pack kernel, the
-    collectives and the next step's kernels are then ordered by that one stream.
+    torch.cuda.current_stream().cuda_stream) with a non-default stream current): the pack kernel and the next
+    step's kernels are ordered by that one stream.
+
+    Overlap (CUDA tensors, calibrated, FLATE_GATHER_OVERLAP != 0): the exchange of step k runs on a stream of its
+    own, behind an event recorded after step k's pack kernel, and reads one of two pack buffers -- so it moves
+    over xGMI while the kernels of step k + 1 compute; the pack of step k + 2 waits for it.  `sizes_host()`,
+    `overflowed()` and `shard()` wait for the exchange first; a device-wide synchronize does too.
     """
 
     def __init__(self, world, rank, device, local_cap, engine=None, algo=None):
@@ -97,6 +102,15 @@ class OutputGather:
         if algo is None:
             algo = "p2p" if (dist.is_initialized() and dist.get_backend() == "nccl") else "all_gather"
         self.algo = algo
+        import os
+        self.overlap = device.type == "cuda" and os.environ.get("FLATE_GATHER_OVERLAP", "1") != "0"
+        self.k = 0
+        if self.overlap:
+            self.comm_stream = torch.cuda.Stream(device=device)
+            self.packed_bufs = [self.packed, torch.empty_like(self.packed)]
+            self.dst_offs = [None, None]
+            self.ev_pack = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     def _pack(self, out, out_off, out_len):
         import torch
@@ -106,18 +120,19 @@ class OutputGather:
         pack_streams(self.engine, out, out_off, out_len, self.packed, self.dst_off)
         return n
 
-    def _exchange(self, width):
+    def _exchange(self, width, packed=None):
         import torch.distributed as dist
         g = self.gathered
+        packed = self.packed if packed is None else packed
         if self.algo == "all_gather" or self.world == 1:
-            dist.all_gather_into_tensor(g[: self.world * width], self.packed[:width])
+            dist.all_gather_into_tensor(g[: self.world * width], packed[:width])
             return
         ops = []
         for d in range(1, self.world):
             to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
-            ops.append(dist.P2POp(dist.isend, self.packed[:width], to))
+            ops.append(dist.P2POp(dist.isend, packed[:width], to))
             ops.append(dist.P2POp(dist.irecv, g[frm * width:(frm + 1) * width], frm))
-        g[self.rank * width:(self.rank + 1) * width].copy_(self.packed[:width])
+        g[self.rank * width:(self.rank + 1) * width].copy_(packed[:width])
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 
@@ -138,6 +153,14 @@ class OutputGather:
         None (sizes stay in `self.sizes` on the device).  Otherwise returns the per-rank packed sizes."""
         import torch
         import torch.distributed as dist
+        if self.calibrated and self.overlap:
+            try:
+                return self._run_overlapped(out, out_off, out_len)
+            except Exception as e:  # noqa: BLE001 -- the serial form below still does the job
+                import sys
+                sys.stderr.write("rank %d: overlapped output gather failed (%r): serial from here on\n" % (self.rank, e))
+                self.overlap = False
+                torch.cuda.synchronize(self.device)
         n = self._pack(out, out_off, out_len)
         dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
         if self.calibrated:
@@ -150,11 +173,41 @@ class OutputGather:
         self._exchange(self.width)
         return sizes
 
+    def _run_overlapped(self, out, out_off, out_len):
+        import torch
+        import torch.distributed as dist
+        if True:
+            # step k's exchange on its own stream, behind the pack; the kernels of step k + 1 do not wait for it
+            i = self.k & 1
+            self.k += 1
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.ev_done[i])  # (the exchange that read this pack buffer last is over)
+            n = out_len.numel()
+            if self.dst_offs[i] is None or self.dst_offs[i].numel() != n + 1:
+                self.dst_offs[i] = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            pack_streams(self.engine, out, out_off, out_len, self.packed_bufs[i], self.dst_offs[i])
+            self.ev_pack[i].record(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.ev_pack[i])
+                dist.all_gather_into_tensor(self.sizes, self.dst_offs[i][n:n + 1])
+                self.over += (self.sizes.max() > self.width).to(torch.int64)
+                self._exchange(self.width, self.packed_bufs[i])
+                self.ev_done[i].record(self.comm_stream)
+            return None
+
+    def _wait_exchange(self):
+        if getattr(self, "overlap", False):
+            import torch
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
     def overflowed(self):
+        self._wait_exchange()
         return bool(int(self.over.item()))
 
     def sizes_host(self):
+        self._wait_exchange()
         return [int(x) for x in self.sizes.cpu().tolist()]
 
     def shard(self, r, sizes):
+        self._wait_exchange()
         return self.gathered[r * self.width: r * self.width + sizes[r]]
