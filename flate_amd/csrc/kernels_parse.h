@@ -890,6 +890,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     __shared__ uint32_t winp[FL_TOK_WIN_DW];
     __shared__ uint32_t hist[2][320];
     __shared__ uint32_t wtot[16];
+    __shared__ uint16_t alist[16][FL_TOK_SPAN];  // per wave: the positions (in its span) of the span's anchors, ascending
     __shared__ uint32_t v1_sh;
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
@@ -916,20 +917,27 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
         const uint32_t h1 = min(h0 + FL_TOK_PART, N);
         const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
-        // the wave's 512 anchor bits (16 words), its descriptors
+        // the wave's 512 anchor bits (16 words); the positions of its anchors go to a list (a third of the positions
+        // of text are anchors: the rounds below are over anchors, 64 at a time, not over positions)
         uint32_t tw = 0;
         if (lane < 16 && span0 + 32 * lane < h1) tw = trueg[(span0 >> 5) + lane];
-        // d[r]: 0 = no anchor, PZ_DESC_LIT = one literal, else j literals and a match
-        uint32_t d[FL_TOK_R];
+        uint32_t na = 0;  // anchors of the span (wave-uniform)
 #pragma unroll
         for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t p = span0 + r * 64 + lane;
             const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r);
             const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r + 1);
-            const uint64_t m64 = (uint64_t)wlo | ((uint64_t)whi << 32);
-            uint32_t dd = 0;
-            if (p < h1 && ((m64 >> lane) & 1ull)) dd = descg[p];
-            d[r] = dd;
+            const uint64_t m64 = (uint64_t)wlo | ((uint64_t)whi << 32);  // (no bit is set beyond the end of the input)
+            const uint64_t below = lane ? (m64 & (~0ull >> (64 - lane))) : 0ull;
+            if ((m64 >> lane) & 1ull) alist[wave][na + (uint32_t)__popcll(below)] = (uint16_t)(r * 64 + lane);
+            na += (uint32_t)__popcll(m64);
+        }
+        fl_lds_order();
+        // d[k]: descriptor of anchor number 64 k + lane (0 = none): PZ_DESC_LIT = one literal, else j literals and a match
+        uint32_t d[FL_TOK_R];
+#pragma unroll
+        for (int k = 0; k < (int)FL_TOK_R; k++) {
+            const uint32_t j = 64 * k + lane;
+            d[k] = j < na ? descg[span0 + alist[wave][j]] : 0u;
         }
         // the part's bytes (+ lookahead for the literals of its last anchors), zero padded
         {
@@ -949,14 +957,15 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
             run0 += wtot[w];
         }
 #pragma unroll 1  // (rolled: the descriptors rotate through d[0])
-        for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t p = span0 + r * 64 + lane;
-            const uint32_t q = p - h0;
+        for (uint32_t k0 = 0; k0 < na; k0 += 64) {
+            const uint32_t j = k0 + lane;
             const uint32_t d0r = d[0];
 #pragma unroll
             for (int k = 0; k + 1 < (int)FL_TOK_R; k++) d[k] = d[k + 1];
             d[FL_TOK_R - 1] = d0r;
-            const bool mk = d0r != 0;
+            const bool mk = d0r != 0;  // (= j < na: every anchor has a descriptor)
+            const uint32_t p = span0 + (mk ? (uint32_t)alist[wave][j] : 0u);
+            const uint32_t q = p - h0;
             const uint32_t dd = (d0r & PZ_DESC_LIT) ? 0u : d0r;
             const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;  // literals of this anchor
             const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
