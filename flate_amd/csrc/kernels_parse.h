@@ -488,6 +488,8 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             uint32_t a = 0;
             uint64_t stopmask = 0;
             uint32_t y_in = PZ_NONE;
+            bool fixing = false;     // this lane parses its segment again in this round ...
+            uint32_t ex_used = 0;    // ... and this is the exit the round's path assumed for it
             if (round == 0) {
                 if (m < nseg && seg_end > y0) {
                     st = ST_SPEC;
@@ -497,6 +499,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 // the path, assuming every segment not resolved yet leaves through its own exit
                 if (m < nseg) {
                     const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
+                    ex_used = ex;
                     tExg[m] = (uint16_t)ex;
                     tNxt[0][m] = (uint16_t)(ex >= endr ? nseg : PZ_SEG_OF(ex - t0r));
                     tMark[m] = m == me ? 1 : 0;
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                     st = ST_FIX;
                     a = y_in;
                     stopmask = A;
+                    fixing = true;
                 }
             }
             // ---- the automaton (deflate.zig:154-205)
@@ -701,13 +705,11 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             uint32_t a0, a1, b0, b1;
                             fl_lds_load8(win32, p + l, a0, a1);
                             fl_lds_load8(win32, qh + l, b0, b1);
-                            const uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1;
-                            if (x0) {
-                                l += (uint32_t)__builtin_ctz(x0) >> 3;
-                                break;
-                            }
-                            if (x1) {
-                                l += 4 + ((uint32_t)__builtin_ctz(x1) >> 3);
+                            // (one 64-bit test: all six dwords are loaded together, one LDS round trip per 8 bytes -- with
+                            // two tests the compiler loads the second half only after the first has compared equal)
+                            const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                            if (x) {
+                                l += (uint32_t)__builtin_ctzll(x) >> 3;
                                 break;
                             }
                             l += 8;
@@ -826,6 +828,9 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #ifdef PZ_PROF
             if (round == 0) c_tspec += __builtin_readcyclecounter() - c_tr0; else c_tstitch += __builtin_readcyclecounter() - c_tr0;
 #endif
+            // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with
+            // it the marks and entries found above -- no round to confirm it.
+            if (round >= 1 && !__syncthreads_or((fixing && res_exit != ex_used) ? 1 : 0)) break;
         }
         // ---- the true anchors of this sub-pass
         if (m < nseg) {
