@@ -37,6 +37,26 @@ class FlateHipError(RuntimeError):
 _lib = None
 
 
+def _share_torchs_hip_runtime():
+    """A process that also runs PyTorch-ROCm must have ONE HIP runtime: torch ships its own libamdhip64, and if this
+    library were loaded first it would bring in /opt/rocm's -- the second runtime to come up then finds no usable device
+    (measured: flate_hip_create fails with NO_DEVICE after `import torch`).  So torch's copy, if there is one, is
+    loaded first (same SONAME: the library below binds to it).  torch itself is not imported."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for d in (spec.submodule_search_locations or []) if spec else []:
+            cand = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                return
+    except Exception:  # noqa: BLE001 -- without torch there is nothing to share
+        pass
+
+
 def lib():
     """Load the shared library (pure dlopen: no GPU needed until flate_hip_create)."""
     global _lib
@@ -45,6 +65,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FlateHipError("libflate_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C flate_amd/csrc` (%s)" % LIB_PATH)
+    _share_torchs_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64p, i32p = C.c_void_p, C.c_void_p, C.c_void_p
     L.flate_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
