@@ -621,3 +621,24 @@ def test_batches_of_many_blocks_take_the_wave_per_block_encoder(monkeypatch):
         assert st == [0] * len(chunks)
         for i, (c, got) in enumerate(zip(chunks, outs)):
             assert got == O.compress(c, container, mode), (i, len(c), container, mode)
+
+
+def test_pageable_host_buffers_go_through_pinned_mirrors(monkeypatch):
+    """Pageable host buffers of 8 MiB or more (numpy arrays: what compress_many hands over) are copied into pinned
+    mirrors by host threads and compressed in overlapped sub-batches; the bytes are those of the one-piece staging
+    (FLATE_HIP_NO_PIN_MIRROR) and of the oracle."""
+    from flate_amd import synth
+    eng = engine()
+    data = synth.text(synth.SEED_TEXT + 55, 20 * 1024 * 1024 + 333).tobytes()
+    chunks = [data[i:i + 65535] for i in range(0, len(data), 65535)]
+    chunks[7] = b""
+    chunks[11] = np.random.default_rng(3).integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    outs, st = eng.compress_many(chunks, 1, 6)
+    assert st == [0] * len(chunks)
+    monkeypatch.setenv("FLATE_HIP_NO_PIN_MIRROR", "1")
+    outs2, st2 = eng.compress_many(chunks, 1, 6)
+    assert st2 == st and outs2 == outs
+    for i in (0, 7, 11, 100, len(chunks) - 1):
+        assert outs[i] == O.compress(chunks[i], 1, 6), i
+    back, st3, _ = eng.decompress_many(outs, 1, caps=[65536] * len(chunks))
+    assert st3 == [0] * len(chunks) and back == chunks
