@@ -486,7 +486,8 @@ int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32
         // (long streams): a workgroup per block, its waves share the block
         if (mode >= 4 && nb >= 8192u)
             hipLaunchKernelGGL(k_encode_wave<true>, dim3((nb + FL_ENC_WAVES - 1) / FL_ENC_WAVES), dim3(64 * FL_ENC_WAVES), 0, st,
-                               d_in, dch, dbc, (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out, nb);
+                               d_in, dch, dbc, (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out, nb,
+                               (prm.stream || (nb & 1u)) ? 0u : 1u);
         else if (mode >= 4)
             hipLaunchKernelGGL(k_encode<true>, dim3(nb), dim3(64 * FL_ENC_WAVES), 0, st, d_in, dch, dbc,
                                (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out);

@@ -651,14 +651,21 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode_wave(const uint8_t
                                                               const uint32_t* __restrict__ blk_chunk,
                                                               const fl_block_plan* __restrict__ plans,
                                                               const uint32_t* __restrict__ tokens /* [chunk][65536] */,
-                                                              uint32_t* __restrict__ out32, uint32_t n_blocks) {
+                                                              uint32_t* __restrict__ out32, uint32_t n_blocks,
+                                                              uint32_t pair_slots) {
     __shared__ uint32_t lit_all[FL_ENC_WAVES][FL_NUM_LIT + 2];
     __shared__ uint32_t dist_all[FL_ENC_WAVES][FL_NUM_DIST + 2];
     __shared__ uint32_t stg[FL_ENC_WAVES][FL_STG_DW];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t b = blockIdx.x * FL_ENC_WAVES + wave;
+    uint32_t b = blockIdx.x * FL_ENC_WAVES + wave;
     if (b >= n_blocks) return;  // (no workgroup barrier below: every wave is on its own)
+    if (pair_slots) {
+        // chunk path: two plan slots per chunk and the second one is rarely used: all first slots before the second
+        // ones, so that resident waves are waves with work (as in k_plan)
+        const uint32_t half = n_blocks >> 1;
+        b = b < half ? 2 * b : 2 * (b - half) + 1;
+    }
     const fl_block_plan* plan = &plans[b];
     if (!plan->valid) return;
     const uint32_t cidx = blk_chunk[b];
