@@ -514,12 +514,28 @@ def cpu_baseline_all_cores(args, data, off_np):
         a, b = int(off_np[w * per]), int(off_np[(w + 1) * per])
         jobs.append((host[a:b], [int(off_np[w * per + i]) - a for i in range(per + 1)], args.container, args.mode))
     ctx = mp.get_context("fork")
+    import resource as _res
+    _r = _res.getrusage(_res.RUSAGE_CHILDREN)
+    _ru0 = _r.ru_utime + _r.ru_stime
     t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
         pool.map(_cpu_worker, jobs)
     dt = time.perf_counter() - t0
-    return {"value": round(hi / dt / 1e6, 2), "unit": "MB/s", "cores": workers, "host_cores_visible": cores, "kind": "port",
-            "sample": "%d chunks (%d MiB) of the same input over %d worker processes, wall time incl. process start"
+    # what the box really gives: its CPU quota (cgroup), and the cores the workers kept busy (CPU seconds / wall)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()[:2]
+            quota = None if a == "max" else round(int(a) / int(b), 1)
+    except (OSError, ValueError):
+        pass
+    import resource
+    ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+    busy = round((ru.ru_utime + ru.ru_stime - _ru0) / dt, 1) if dt > 0 else None
+    return {"value": round(hi / dt / 1e6, 2), "unit": "MB/s", "cores": workers, "host_cores_visible": cores,
+            "cpu_quota_cores": quota, "cores_kept_busy": busy, "kind": "port",
+            "sample": "%d chunks (%d MiB) of the same input over %d worker processes, wall time incl. process start; "
+                      "`cores` = worker processes, `cores_kept_busy` = their CPU seconds per second of wall time"
                       % (k, hi >> 20, workers)}
 
 
