@@ -377,29 +377,24 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 if (i < PZ_PRV_N / 2) prv2[i] = lo16 | (hi16 << 16);
             };
             if (!sub) {
-                constexpr uint32_t WB = 7;  // 2 batches cover PZ_WIN_DW / PZ_THREADS dwords per thread
-                for (uint32_t base = 0; base < PZ_WIN_DW; base += WB * PZ_THREADS) {
-                    uint32_t lo[WB], hi[WB];
+                // everything a thread stages is requested before anything is written: one round of memory latency
+                constexpr uint32_t WB = (PZ_WIN_DW + PZ_THREADS - 1) / PZ_THREADS, PB = (PZ_PRV_N / 2 + PZ_THREADS - 1) / PZ_THREADS;
+                uint32_t lo[WB], hi[WB], lv[PB];
 #pragma unroll
-                    for (uint32_t u = 0; u < WB; u++) {
-                        const uint32_t i = base + u * PZ_THREADS + tid;
-                        lo[u] = i < ndw ? a32[i] : 0u;
-                        hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < WB; u++) put_win(base + u * PZ_THREADS + tid, lo[u], hi[u]);
+                for (uint32_t u = 0; u < WB; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    lo[u] = i < ndw ? a32[i] : 0u;
+                    hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
                 }
-                constexpr uint32_t PB = 8;
-                for (uint32_t base = 0; base < PZ_PRV_N / 2; base += PB * PZ_THREADS) {
-                    uint32_t lv[PB];
 #pragma unroll
-                    for (uint32_t u = 0; u < PB; u++) {
-                        const uint32_t i = base + u * PZ_THREADS + tid;
-                        lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < PB; u++) put_prv(base + u * PZ_THREADS + tid, lv[u]);
+                for (uint32_t u = 0; u < PB; u++) {
+                    const uint32_t i = u * PZ_THREADS + tid;
+                    lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
                 }
+#pragma unroll
+                for (uint32_t u = 0; u < WB; u++) put_win(u * PZ_THREADS + tid, lo[u], hi[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < PB; u++) put_prv(u * PZ_THREADS + tid, lv[u]);
             } else {
                 // the new part: loads first ...
                 constexpr uint32_t WN = (PZ_WIN_DW - (PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u) + PZ_THREADS - 1) / PZ_THREADS;
