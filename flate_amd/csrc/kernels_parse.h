@@ -914,13 +914,19 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     for (uint32_t i = tid; i < 640; i += FL_EMITZ_THREADS) (&hist[0][0])[i] = 0;
     if (tid == 0) v1_sh = N;
     uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
+    uint32_t tw_next = 0;  // the wave's 16 words of anchor bits of the next part
+    if (lane < 16 && wave * FL_TOK_SPAN + 32 * lane < min((uint32_t)FL_TOK_PART, N)) tw_next = trueg[((wave * FL_TOK_SPAN) >> 5) + lane];
     for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
         const uint32_t h1 = min(h0 + FL_TOK_PART, N);
         const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
         // the wave's 512 anchor bits (16 words); the positions of its anchors go to a list (a third of the positions
         // of text are anchors: the rounds below are over anchors, 64 at a time, not over positions)
-        uint32_t tw = 0;
-        if (lane < 16 && span0 + 32 * lane < h1) tw = trueg[(span0 >> 5) + lane];
+        const uint32_t tw = tw_next;  // (requested one part ahead)
+        {
+            const uint32_t h0n = h0 + FL_TOK_PART, h1n = min(h0n + FL_TOK_PART, N), s0n = h0n + wave * FL_TOK_SPAN;
+            tw_next = 0;
+            if (h0n < N && lane < 16 && s0n + 32 * lane < h1n) tw_next = trueg[(s0n >> 5) + lane];
+        }
         uint32_t na = 0;  // anchors of the span (wave-uniform)
 #pragma unroll
         for (int r = 0; r < (int)FL_TOK_R; r++) {
