@@ -1634,7 +1634,27 @@ int flate_hip_compress_batch_sharded(flate_hip_handle h, void* nccl_comm, int ra
         h->last_error = "ncclAllGather failed";
         rc = FLATE_HIP_E_LAUNCH;
     }
-    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, slice_bytes);
+    // every peer gets the largest packed shard's worth of bytes, not the slice's capacity (the sizes are read once:
+    // one wait on the stream; a caller needs them anyway to use gathered[])
+    uint64_t send_bytes = slice_bytes;
+    if (!rc && world > 1) {
+        std::vector<uint64_t> hs((size_t)world);
+        if (hipMemcpyAsync(hs.data(), sizes, sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) {
+            h->last_error = "reading the packed sizes failed";
+            rc = FLATE_HIP_E_LAUNCH;
+        } else {
+            uint64_t mx = 0;
+            for (uint64_t v : hs) mx = std::max(mx, v);
+            if (mx > slice_bytes) {
+                h->last_error = "a packed shard is larger than slice_bytes";
+                rc = FLATE_HIP_E_INVALID_ARG;
+            } else {
+                send_bytes = std::min<uint64_t>(slice_bytes, (mx + 15) & ~(uint64_t)15);
+            }
+        }
+    }
+    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, send_bytes);
     h->sync = was_sync;
     if (!rc && h->sync) HIP_OK(h, hipStreamSynchronize(h->stream));
     return rc;

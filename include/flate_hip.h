@@ -193,7 +193,8 @@ int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint6
  *   (device memory), and every slice goes to every peer in ONE grouped batch of ncclSend / ncclRecv
  *   (xGMI is point to point: each link carries one peer's shard, no ring).  slice_bytes must bound
  *   every rank's packed shard (e.g. the sum of its compress bounds) and be the same on all ranks.
- *   Afterwards gathered[r * slice_bytes .. + sizes[r]) is rank r's output on every rank -- what the
+ *   Every peer is sent the largest packed shard's worth of bytes (the sizes are read on the host once per call), not
+ *   the slice's capacity.  Afterwards gathered[r * slice_bytes .. + sizes[r]) is rank r's output on every rank -- what the
  *   reference's writer would hold after compressing the ranks' chunks one after the other.
  * decompress: the local streams are inflated straight into this rank's slice (out_off relative to
  *   the slice), then the slices are exchanged the same way.
