@@ -671,7 +671,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                               [a1] "=&v"(a1), [a2] "=&v"(a2), [xn] "=&v"(xn), [t] "=&v"(t), [ssave] "=&s"(s_save),
                               [st] "=&s"(s_t), [shit] "=&s"(s_hit)
                             : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
-                            : "vcc", "memory");
+                            : "vcc", "scc", "memory");
                         // s_t: the lanes that are still walking (their candidate's data is in the A registers again:
                         // an even number of steps); s_hit: those that stopped on a candidate that passes the filter
                         const uint32_t ln = threadIdx.x & 63u;
