@@ -970,13 +970,15 @@ struct fl_scan_point {
     uint32_t stream, pad;
 };
 #define FP_SCAN_WIN_BITS 65536u
-#define FP_SCAN_STAGE_DW (FP_SCAN_WIN_BITS / 32 + 8)
+#define FP_SCAN_STAGE_DW (FP_SCAN_WIN_BITS / 32 + 8 + 80)  // + what a header at the end of the window reaches into (at most 17 + 57 + 316 * 14 bits ... the lane gives up beyond the stage)
 #define FP_SCAN_CAP 2048u
+#define FP_SCAN_LANES 256u  // lanes that validate at a time (128 bytes of LDS each)
 struct fp_scan_shared {
     fl_inflate_ws ws;
     uint32_t inring[FL_INF_INRING / 4];
     uint32_t stage[FP_SCAN_STAGE_DW];
     uint32_t surv[FP_SCAN_CAP];  // window bit offsets of the survivors of step 1 (any order)
+    uint8_t vtab[FP_SCAN_LANES][128];  // step 2: a lookup table of the code-length code per validating lane
     uint32_t nsurv, npass;
     uint32_t passed[64];         // ... of step 2
     uint32_t found;
@@ -991,17 +993,25 @@ __device__ __forceinline__ uint64_t fp_bits_at(const uint8_t* src, uint32_t in_l
     return k ? (v >> k) | (hi << (64 - k)) : v;
 }
 
-// Step 2 for one position, by one lane.
-__device__ bool fp_scan_header_lane(const uint8_t* src, uint32_t in_len, uint64_t bit) {
+// Step 2 for one position, by one lane.  `tab`: the lane's 128 bytes of LDS -- the code-length code as a lookup table by
+// the next 7 stream bits: symbol << 3 | code bits, 0 = no code.
+__device__ bool fp_scan_header_lane(const FL_LDS uint32_t* stage, uint32_t rel0, uint32_t in_len, uint64_t bit, FL_LDS uint8_t* tab) {
+    // rel0: position of `bit` in the staged window (bits); the stage ends at 32 * FP_SCAN_STAGE_DW - 64
     const uint64_t total_bits = (uint64_t)in_len * 8;
-    uint64_t b = fp_bits_at(src, in_len, bit);
+    auto bits_at = [&](uint64_t at) -> uint64_t {
+        uint32_t lo, hi;
+        fp_fetch64(stage, rel0 + (uint32_t)(at - bit), lo, hi);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    };
+    const uint32_t rel_end = 32u * FP_SCAN_STAGE_DW - 64u - 64u;
+    uint64_t b = bits_at(bit);
     const uint32_t hlit = (uint32_t)(b >> 3) & 31, hdist = (uint32_t)(b >> 8) & 31, ncl = ((uint32_t)(b >> 13) & 15) + 4;
     const uint32_t nlit = hlit + 257, ntot = nlit + hdist + 1;
     uint64_t pos = bit + 17;
     // code lengths of the code-length alphabet (3 bits each, permuted order), packed by symbol
     uint64_t clen = 0;
     {
-        const uint64_t b2 = fp_bits_at(src, in_len, pos);
+        const uint64_t b2 = bits_at(pos);
         // order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
         const uint64_t order = 0x10ull | (0x11ull << 5) | (0x12ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) |
                                (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
@@ -1013,25 +1023,42 @@ __device__ bool fp_scan_header_lane(const uint8_t* src, uint32_t in_len, uint64_
         }
         pos += 3 * ncl;
     }
-    // canonical code: per length the number of codes, and the symbols ordered by (length, symbol)
-    uint32_t count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t sy = 0; sy < 19; sy++) {
-        const uint32_t l = (uint32_t)(clen >> (3 * sy)) & 7;
-#pragma unroll
-        for (uint32_t k = 1; k < 8; k++) count[k] += l == k ? 1u : 0u;
-    }
-    uint64_t symlo = 0, symhi = 0;  // 19 x 5 bits
+    // the canonical code (huffman_decoder.zig:62-117: codes of one length are consecutive, shorter ones first) as a
+    // table by the next 7 bits of the stream, first bit = most significant bit of the code
     {
-        uint32_t n = 0;
-        for (uint32_t k = 1; k < 8; k++)
-            for (uint32_t sy = 0; sy < 19; sy++)
-                if (((uint32_t)(clen >> (3 * sy)) & 7) == k) {
-                    if (n < 12)
-                        symlo |= (uint64_t)sy << (5 * n);
-                    else
-                        symhi |= (uint64_t)sy << (5 * (n - 12));
-                    n++;
+        uint32_t cnt8 = 0, nz = 0;  // codes per length, 4 bits each (at most 19 ... fits: a complete code has at most 2 of length 1)
+        uint32_t count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t sy = 0; sy < 19; sy++) {
+            const uint32_t l = (uint32_t)(clen >> (3 * sy)) & 7;
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++) count[k] += l == k ? 1u : 0u;
+            nz += l ? 1u : 0u;
+        }
+        (void)cnt8;
+        if (nz <= 1) return false;  // (a code-length code of one symbol: legal, never seen; the span before gets longer)
+        uint32_t next[8];
+        uint32_t code = 0;
+        next[0] = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) {
+            code = (code + count[k - 1]) << 1;
+            next[k] = code;
+        }
+        for (uint32_t i = 0; i < 32; i++) ((FL_LDS uint32_t*)tab)[i] = 0;
+        for (uint32_t sy = 0; sy < 19; sy++) {
+            const uint32_t l = (uint32_t)(clen >> (3 * sy)) & 7;
+            if (!l) continue;
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++)
+                if (l == k) {
+                    c = next[k];
+                    next[k] = c + 1;
                 }
+            if (c >> l) return false;  // oversubscribed
+            const uint32_t rev = __brev(c) >> (32 - l);
+            for (uint32_t j = rev; j < 128; j += 1u << l) tab[j] = (uint8_t)((sy << 3) | l);
+        }
     }
     uint32_t kl = 0, kd = 0, nd = 0, prev = 0, eob = 0;  // Kraft sums (in units of 2^-15), distance codes, last length
     uint32_t i = 0;
@@ -1039,28 +1066,13 @@ __device__ bool fp_scan_header_lane(const uint8_t* src, uint32_t in_len, uint64_
     b = 0;
     while (i < ntot) {
         if (have < 16) {
-            if (pos >= total_bits) return false;
-            b = fp_bits_at(src, in_len, pos);
+            if (pos >= total_bits || rel0 + (uint32_t)(pos - bit) > rel_end) return false;  // (beyond the stage: given up)
+            b = bits_at(pos);
             have = 64;
         }
-        // one symbol of the code-length code, bit by bit (huffman_decoder.zig:156-175 finds it the same way)
-        uint32_t code = 0, first = 0, index = 0, sym = 32, used = 0;
-#pragma unroll
-        for (uint32_t k = 1; k < 8; k++) {
-            if (sym == 32) {
-                code |= (uint32_t)(b >> (k - 1)) & 1;
-                const uint32_t c = count[k];
-                if (code < first + c) {
-                    const uint32_t n = index + (code - first);
-                    sym = n < 12 ? (uint32_t)(symlo >> (5 * n)) & 31 : (uint32_t)(symhi >> (5 * (n - 12))) & 31;
-                    used = k;
-                }
-                index += c;
-                first = (first + c) << 1;
-                code <<= 1;
-            }
-        }
-        if (sym == 32) return false;
+        const uint32_t e = tab[(uint32_t)b & 127u];
+        const uint32_t used = e & 7, sym = e >> 3;
+        if (!used) return false;
         b >>= used;
         have -= used;
         pos += used;
@@ -1087,6 +1099,9 @@ __device__ bool fp_scan_header_lane(const uint8_t* src, uint32_t in_len, uint64_
             kd += (rep - nl) * (32768u >> len);
             nd += rep - nl;
             if (i <= 256 && i + rep > 256) eob = 1;
+            // (an oversubscribed code cannot become complete again: what is not a header is given up here, after a few
+            // dozen symbols, long before its lengths have all been decoded)
+            if (kl > 32768u || kd > 32768u) return false;
         }
         prev = len;
         i += rep;
@@ -1122,45 +1137,60 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
             sh->found = 0;
         }
         __syncthreads();
-        // ---- 1
-        for (uint32_t j = 0; j < FP_SCAN_WIN_BITS; j += FP_THREADS) {
-            const uint32_t wb = j + tid;
+        // ---- 1: first what costs a handful of instructions (type bits, HLIT, HDIST: 1 position in 4.5 passes), for all
+        // 64 positions of the lane; then the Kraft sum of the code-length code for those that passed
+        uint64_t cheap = 0;
+#pragma unroll 4
+        for (uint32_t jj = 0; jj < FP_SCAN_WIN_BITS / FP_THREADS; jj++) {
+            const uint32_t wb = jj * FP_THREADS + tid;
             const uint64_t bit = base + wb;
-            if (bit < pt.limit_bit && bit + 17 + 12 <= total_bits) {
-                uint32_t lo, hi, lo2, hi2;
-                fp_fetch64(sh->stage, bsh + wb, lo, hi);
-                const uint32_t btype = (lo >> 1) & 3, hlit = (lo >> 3) & 31, hdist = (lo >> 8) & 31, ncl = ((lo >> 13) & 15) + 4;
-                if (btype == 2 && hlit <= 29 && hdist <= 29) {
-                    fp_fetch64(sh->stage, bsh + wb + 62, lo2, hi2);
-                    const uint64_t b64 = (uint64_t)lo | ((uint64_t)hi << 32);
-                    uint32_t kraft = 0, nz = 0;
+            const uint32_t di = (bsh + wb) >> 5, shf = (bsh + wb) & 31;
+            const uint32_t lo = __builtin_amdgcn_alignbit(sh->stage[di + 1], sh->stage[di], shf);  // 32 bits from that position
+            const uint32_t btype = (lo >> 1) & 3, hlit = (lo >> 3) & 31, hdist = (lo >> 8) & 31;
+            if (btype == 2 && hlit <= 29 && hdist <= 29 && bit < pt.limit_bit && bit + 17 + 12 <= total_bits) cheap |= 1ull << jj;
+        }
+        while (cheap) {
+            const uint32_t jj = (uint32_t)__builtin_ctzll(cheap);
+            cheap &= cheap - 1;
+            const uint32_t wb = jj * FP_THREADS + tid;
+            const uint64_t bit = base + wb;
+            uint32_t lo, hi, lo2, hi2;
+            fp_fetch64(sh->stage, bsh + wb, lo, hi);
+            fp_fetch64(sh->stage, bsh + wb + 62, lo2, hi2);
+            const uint32_t ncl = ((lo >> 13) & 15) + 4;
+            const uint64_t b64 = (uint64_t)lo | ((uint64_t)hi << 32);
+            uint32_t kraft = 0, nz = 0;
 #pragma unroll
-                    for (uint32_t i = 0; i < 19; i++) {
-                        const uint32_t len = i < 15 ? (uint32_t)(b64 >> (17 + 3 * i)) & 7u : (lo2 >> (3 * i - 45)) & 7u;
-                        if (i < ncl && len) {
-                            kraft += 128u >> len;
-                            nz++;
-                        }
-                    }
-                    if ((kraft == 128 || nz <= 1) && bit + 17 + 3 * ncl <= total_bits) {
-                        const uint32_t k = atomicAdd(&sm.nsurv, 1u);
-                        if (k < FP_SCAN_CAP) sh->surv[k] = wb;
-                    }
+            for (uint32_t i = 0; i < 19; i++) {
+                const uint32_t len = i < 15 ? (uint32_t)(b64 >> (17 + 3 * i)) & 7u : (lo2 >> (3 * i - 45)) & 7u;
+                if (i < ncl && len) {
+                    kraft += 128u >> len;
+                    nz++;
                 }
+            }
+            if ((kraft == 128 || nz <= 1) && bit + 17 + 3 * ncl <= total_bits) {
+                const uint32_t k = atomicAdd(&sm.nsurv, 1u);
+                if (k < FP_SCAN_CAP) sh->surv[k] = wb;
             }
         }
         __syncthreads();
         // ---- 2
         const uint32_t ns = min(sh->nsurv, FP_SCAN_CAP);
-        for (uint32_t k = tid; k < ns; k += FP_THREADS) {
+#ifdef FP_SCAN_PROF
+        if (tid == 0) { atomicAdd((unsigned long long*)&g_fl_prof[10], 1ull); atomicAdd((unsigned long long*)&g_fl_prof[11], (unsigned long long)sh->nsurv); }
+#endif
+        for (uint32_t k = tid; tid < FP_SCAN_LANES && k < ns; k += FP_SCAN_LANES) {
             const uint32_t wb = sh->surv[k];
-            if (fp_scan_header_lane(src, ck.in_len, base + wb)) {
+            if (fp_scan_header_lane(sh->stage, bsh + wb, ck.in_len, base + wb, (FL_LDS uint8_t*)sh->vtab[tid])) {
                 const uint32_t q = atomicAdd(&sm.npass, 1u);
                 if (q < 64) sh->passed[q] = wb;
             }
         }
         __syncthreads();
         // ---- 3
+#ifdef FP_SCAN_PROF
+        if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[12], (unsigned long long)sh->npass);
+#endif
         if (wave == 0) {
             const uint32_t np = min(sh->npass, 64u);
             uint32_t mine = lane < np ? sh->passed[lane] : 0xffffffffu;
