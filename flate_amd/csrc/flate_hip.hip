@@ -89,7 +89,9 @@ struct flate_hip_ctx {
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
-    DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff;  // inflate of long streams by spans
+    uint32_t n_cu = 0;  // of the device (spans)
+    DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff,
+        sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part;  // inflate of long streams by spans
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
@@ -581,7 +583,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
 // chunks[i].skip = 1 (the kernels that follow leave them alone); everything else stays as it was.
 // Returns the number of streams finished, or a negative FLATE_HIP_E_*.
 #define FL_SPAN_MIN_BYTES (512u * 1024u)   // streams shorter than this are not cut
-#define FL_SPAN_BYTES (96u * 1024u)        // compressed bytes per span, about
+#define FL_SPAN_BYTES (64u * 1024u)        // compressed bytes per span, at least
 #define FL_SPAN_MAX 1024u                  // spans per call
 int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std::vector<fl_chunk>& chunks, int container,
                      int flags, uint8_t* d_out, uint64_t* d_outlen, int32_t* d_status, uint64_t* d_consumed) {
@@ -603,11 +605,23 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // ---- where spans may start
     std::vector<fl_scan_point> points;
     std::vector<uint32_t> pt_first(elig.size() + 1, 0);
-    const uint32_t per_stream_max = std::max<uint32_t>(2u, FL_SPAN_MAX / (uint32_t)elig.size());
+    // A span is a workgroup, a workgroup has a CU to itself: as many spans as CUs (a few less: what else runs), or
+    // a multiple of that for long inputs -- 313 spans on 256 CUs take as long as 499 (measured: 170 MiB of text as
+    // 249 / 313 / 374 / 499 / 703 spans: 12.3 / 17.5 / 16.2 / 14.3 / 16.3 ms), and every span costs k_span_scan and
+    // k_span_resolve a step.
+    if (h->n_cu == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
+        h->n_cu = (uint32_t)v;
+    }
+    uint64_t elig_bytes = 0;
+    for (uint32_t ci : elig) elig_bytes += chunks[ci].in_len;
+    const uint64_t rounds = std::min<uint64_t>(4, std::max<uint64_t>(1, (elig_bytes + h->n_cu * 131072ull) / (h->n_cu * 262144ull)));
+    const uint64_t want = std::min<uint64_t>({(uint64_t)FL_SPAN_MAX, rounds * h->n_cu - std::min<uint32_t>(8u, h->n_cu / 2), std::max<uint64_t>(2, elig_bytes / FL_SPAN_BYTES)});
     for (size_t k = 0; k < elig.size(); k++) {
         const fl_chunk& c = chunks[elig[k]];
         const uint64_t bits = (uint64_t)c.in_len * 8;
-        const uint32_t P = (uint32_t)std::min<uint64_t>(per_stream_max, std::max<uint64_t>(2, c.in_len / FL_SPAN_BYTES));
+        const uint32_t P = (uint32_t)std::max<uint64_t>(2, want * c.in_len / elig_bytes);
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
             pt.from_bit = bits / P * j;
@@ -676,12 +690,29 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (!cand.empty() && hipMemcpyAsync(h->sp_cand.p, cand.data(), sizeof(uint64_t) * cand.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_candoff.p, cand_off.data(), sizeof(uint32_t) * (n_chunks + 1), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-    // ---- pass 1
+    // ---- the pool run A writes to: what the streams can hold (at most 32 bytes for every compressed one: beyond
+    // that a stream goes the old way), two pieces of slack per span
+    fl_span_pool pool;
+    {
+        uint64_t bytes = 0;
+        for (uint32_t ci : elig) bytes += std::min<uint64_t>(chunks[ci].out_cap, 32ull * chunks[ci].in_len);
+        const uint64_t pieces = std::min<uint64_t>((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1, 0xffffff00ull);
+        if ((rc = ensure(h, h->sp_pool, (size_t)(pieces * FP_PIECE + 16)))) return -1;
+        if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp))) return -1;
+        if ((rc = ensure(h, h->sp_poolctl, 16))) return -1;
+        if (hipMemsetAsync(h->sp_poolctl.p, 0, 16, st) != hipSuccess) return -1;
+        pool.base = (uint8_t*)h->sp_pool.p;
+        pool.next = (uint32_t*)h->sp_poolctl.p;
+        pool.tab = (uint32_t*)h->sp_pooltab.p;
+        pool.pieces = (uint32_t)pieces;
+        pool.pad = 0;
+    }
+    // ---- run A
     {
         ProfScope ps(h, K_INFLATE_SPAN);
-        hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+        hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                            (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u);
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u, pool);
     }
     std::vector<fl_span_res> r1(nsp), r2(nsp);
     if (hipMemcpyAsync(r1.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
@@ -729,55 +760,88 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         any = any || ok;
     }
     if (!any) return 0;
-    // ---- pass 1 again with the other filling of the history (live spans), the true tails, pass 2
+    // ---- run B with the other filling of the history (live spans, in place), the true tails, k_span_fix
     std::vector<uint32_t> chain_all, chain_off(1, 0);
     for (size_t k = 0; k < elig.size(); k++) {
         if (plans[k].ok) chain_all.insert(chain_all.end(), plans[k].chain.begin(), plans[k].chain.end());
         chain_off.push_back((uint32_t)chain_all.size());
     }
-    if ((rc = ensure(h, h->sp_chain, sizeof(uint32_t) * (chain_all.size() + 1)))) return -1;
-    if ((rc = ensure(h, h->sp_chainoff, sizeof(uint32_t) * chain_off.size()))) return -1;
-    if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-    if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-    if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     // (streams without a single copy that reaches before its span -- huffman-only, store-only ones -- need neither)
     bool uses_hist = false;
     for (uint32_t si : chain_all) uses_hist = uses_hist || r1[si].uses_hist != 0;
     if (dbg) fprintf(stderr, "[spans] history needed: %d\n", (int)uses_hist);
+    std::vector<fl_fix_item> items;
+    std::vector<uint32_t> item_first(elig.size() + 1, 0);
+    for (size_t k = 0; k < elig.size(); k++) {
+        if (plans[k].ok) {
+            for (uint32_t si : plans[k].chain) {
+                const uint64_t n = r1[si].out_len;
+                for (uint64_t o = 0; o < n; o += FP_PIECE) {
+                    fl_fix_item it;
+                    it.dst = chunks[elig[k]].out_off + spans[si].wp + o;
+                    it.span = si;
+                    it.local = (uint32_t)o;
+                    it.len = (uint32_t)std::min<uint64_t>(FP_PIECE, n - o);
+                    it.kind = spans[si].first ? 0u : uses_hist ? 2u : 1u;
+                    it.prev = spans[si].prev;
+                    it.pad = 0;
+                    items.push_back(it);
+                }
+            }
+        }
+        item_first[k + 1] = (uint32_t)items.size();
+    }
+    const uint32_t n_items = (uint32_t)items.size();
+    if ((rc = ensure(h, h->sp_chain, sizeof(uint32_t) * (chain_all.size() + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_chainoff, sizeof(uint32_t) * chain_off.size()))) return -1;
+    if ((rc = ensure(h, h->sp_items, sizeof(fl_fix_item) * ((size_t)n_items + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_part, sizeof(uint32_t) * 2 * ((size_t)n_items + 1)))) return -1;
+    if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (n_items && hipMemcpyAsync(h->sp_items.p, items.data(), sizeof(fl_fix_item) * n_items, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     {
         ProfScope ps(h, K_INFLATE_SPAN);
         if (uses_hist) {
-            hipLaunchKernelGGL(k_inflate_span<1>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+            hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                                (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                               (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u);
+                               (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool);
             hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
                                (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
         }
-        hipLaunchKernelGGL(k_inflate_span<2>, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
-                           (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u);
+        if (n_items)
+            hipLaunchKernelGGL(k_span_fix, dim3(n_items), dim3(64), 0, st, (const fl_fix_item*)h->sp_items.p, pool,
+                               (const uint8_t*)h->sp_tails.p, d_out, container, h->crc, (uint32_t*)h->sp_part.p);
     }
-    if (hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    std::vector<uint32_t> part(2 * (size_t)n_items);
+    if (uses_hist && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (n_items && hipMemcpyAsync(part.data(), h->sp_part.p, sizeof(uint32_t) * 2 * n_items, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
-    // ---- every tail as in pass 1, the checksum, the footer
+    // ---- run B as run A, the checksum, the footer
+    const uint32_t pow_piece = fl_crc_xpow8n(h->crc.xpow8, FP_PIECE);
     int done = 0;
     for (size_t k = 0; k < elig.size(); k++) {
         StreamPlan& pl = plans[k];
         if (!pl.ok) continue;
         fl_chunk& c = chunks[elig[k]];
         bool ok = true;
-        uint32_t crc = 0;
-        uint64_t adA = 0, adB = 0;
-        for (size_t j = 0; j < pl.chain.size() && ok; j++) {
+        for (size_t j = 0; j < pl.chain.size() && ok && uses_hist; j++) {
             const uint32_t si = pl.chain[j];
+            if (spans[si].first) continue;  // (run A was final)
             const fl_span_res &a = r1[si], &b = r2[si];
             if (b.status != 0 || b.out_len != a.out_len || b.end_bit != a.end_bit) ok = false;
-            if (j + 1 < pl.chain.size() && !b.tail_same) ok = false;
-            if (dbg && !ok) fprintf(stderr, "[spans] span %u (chain %zu): pass 2 status %u len %llu/%llu end %llu/%llu tail_same %u\n", si, j, b.status, (unsigned long long)b.out_len, (unsigned long long)a.out_len, (unsigned long long)b.end_bit, (unsigned long long)a.end_bit, b.tail_same);  // (nobody decodes with the last span's tail)
-            const uint64_t after = pl.total - (spans[si].wp + a.out_len);
-            crc ^= fl_crc_mulmod(b.crc, fl_crc_xpow8n(h->crc.xpow8, after));
-            adA += b.adA;
-            adB += b.adB % 65521u + (uint64_t)(b.adA % 65521u) * (after % 65521u) % 65521u;
+            if (dbg && !ok) fprintf(stderr, "[spans] span %u (chain %zu): run B status %u len %llu/%llu end %llu/%llu\n", si, j, b.status, (unsigned long long)b.out_len, (unsigned long long)a.out_len, (unsigned long long)b.end_bit, (unsigned long long)a.end_bit);
+        }
+        uint32_t crc = 0;
+        uint64_t adA = 0, adB = 0;  // Adler-32 with a = b = 0 start
+        for (uint32_t q = item_first[k]; q < item_first[k + 1] && ok; q++) {
+            const uint32_t pc = part[2 * (size_t)q], plen = part[2 * (size_t)q + 1];
+            if (container == 1) {
+                crc = fl_crc_mulmod(crc, plen == FP_PIECE ? pow_piece : fl_crc_xpow8n(h->crc.xpow8, plen)) ^ pc;
+            } else if (container == 2) {
+                adB = (adB + adA * plen + (pc >> 16)) % 65521u;
+                adA = (adA + (pc & 0xffff)) % 65521u;
+            }
         }
         const uint64_t fb = (pl.end_bit + 7) >> 3;
         const uint32_t flen = container == 1 ? 8u : container == 2 ? 4u : 0u;
@@ -790,14 +854,14 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
                 const uint32_t fsz = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
                 ok = fcrc == crc && fsz == (uint32_t)pl.total;
             } else {
-                const uint32_t a = (uint32_t)((1 + adA % 65521u) % 65521u);
-                const uint32_t b = (uint32_t)((pl.total % 65521u + adB % 65521u) % 65521u);
+                const uint32_t a = (uint32_t)((1 + adA) % 65521u);
+                const uint32_t b = (uint32_t)((pl.total % 65521u + adB) % 65521u);
                 const uint32_t fad = ((uint32_t)f[0] << 24) | ((uint32_t)f[1] << 16) | ((uint32_t)f[2] << 8) | (uint32_t)f[3];
                 ok = fad == ((b << 16) | a);
             }
         }
-        if (dbg) fprintf(stderr, "[spans] stream %u after pass 2: ok=%d crc %08x\n", elig[k], (int)ok, crc);
-        if (!ok) continue;  // (the bytes pass 2 wrote are written again by the kernels that follow)
+        if (dbg) fprintf(stderr, "[spans] stream %u after k_span_fix: ok=%d crc %08x\n", elig[k], (int)ok, crc);
+        if (!ok) continue;  // (the bytes written so far are written again by the kernels that follow)
         const uint32_t ci = elig[k];
         const int32_t zero = 0;
         const uint64_t total = pl.total, used = fb + flen;
@@ -867,7 +931,8 @@ int flate_hip_destroy(flate_hip_handle h) {
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
-                      &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff})
+                      &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff, &h->sp_pool, &h->sp_pooltab, &h->sp_poolctl, &h->sp_items,
+                      &h->sp_part})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->cflag, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,

@@ -107,6 +107,7 @@ struct fp_shared {
     fp_long lit_long, dst_long;
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
     uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
+    uint32_t n_pieces, piece_id[2];  // spans, run A: pieces of the pool this span has taken; the last two of them
     uint32_t nblk, stop, uses_hist;  // spans: blocks decoded so far; the span ends here; a copy reached before its start
     uint32_t err_far;  // a copy of this round reaches before the start of the output (set in step 6, read after its barrier)
     uint32_t st_len;  // stored block: bytes
@@ -243,50 +244,62 @@ __device__ __forceinline__ uint32_t fp_tok_len(uint32_t t) { return (t >> 31) ? 
 // a span is decoded by one workgroup from its block start until it lands on the start of another span or behind
 // the final block.  What a span cannot know is the 32 KiB of output before it, and how far into the output it
 // starts:
-//   pass 1 (MODE 1)  every span at once, nothing written: where the span ends, how many bytes it makes, and the
-//                    last 32 KiB of them (its TAIL).  Run twice, with two fillings of the unknown history:
-//                    byte h of it is A[h] = h & 255 in run A and B[h] = A[h] ^ ((h >> 8) + 1) in run B.  A tail
-//                    byte that comes out the same in both runs does not depend on the history; one that differs
-//                    is a copy (of a copy ...) of history byte h = ((a ^ b) - 1) << 8 | a -- the same h in both
-//                    runs, because where a byte is copied from is decided by the tokens, not by the bytes;
-//   host             follows the chain of spans from the stream start (a span that is not landed on is dead),
-//                    adds up the output offsets;
+//   runs A and B (MODE 1)  every span at once: where the span ends, how many bytes it makes, the last 32 KiB of them
+//                    (its TAIL), and the bytes themselves -- with two fillings of the unknown history: byte h of
+//                    it is A[h] = h & 255 in run A and B[h] = A[h] ^ ((h >> 8) + 1) in run B.  A byte that comes
+//                    out the same in both runs does not depend on the history; one that differs is a copy (of a
+//                    copy ...) of history byte h = ((a ^ b) - 1) << 8 | a -- the same h in both runs, because
+//                    where a byte is copied from is decided by the tokens, not by the bytes.  Run A does not know
+//                    where its bytes belong (pieces of a pool); before run B
+//   the host         follows the chain of spans from the stream start (a span that is not landed on is dead) and
+//                    adds up the output offsets: run B writes in place;
 //   k_span_resolve   the true tails, span after span along the chain: a byte that depends on the history is
 //                    byte h of the (already true) tail before it;
-//   pass 2 (MODE 2)  every live span again, with its true history, the bytes written to their place; its tail
-//                    must come out as resolved (checked).
-// Checksum pieces are folded and the footer is checked by the host.  Anything irregular: the stream is decoded
-// again by the kernels below, as before.  inflate.zig:220-239 is serial per stream; this is the same function,
-// with the one thing a span cannot know kept symbolic until it is known.
+//   k_span_fix       every byte of every live span once: a == b: final; else byte h of the true tail before the
+//                    span; and the checksum pieces.
+// The pieces are folded and the footer is checked by the host.  Anything irregular: the stream is decoded again by
+// k_inflate_par / k_inflate, as before.  inflate.zig:220-239 is serial per stream; this is the same function, with
+// the one thing a span cannot know kept symbolic until it is known.
 struct fl_span {
     uint64_t start_bit;  // of its first block header, from the first byte of the stream (first span: unused)
-    uint64_t wp;         // pass 2: offset of its first output byte in the stream's output
+    uint64_t wp;         // run B: offset of its first output byte in the stream's output (run A: 0)
     uint32_t stream;     // chunk index
     uint32_t first;      // 1: starts at the stream's first byte (container header)
-    uint32_t prev;       // pass 2: the span before it in the chain (its tail is this span's history), ~0u: none
-    uint32_t live;       // pass 2: on the chain
+    uint32_t prev;       // the span before it in the chain (its tail is this span's history), ~0u: none
+    uint32_t live;       // run B: on the chain
 };
 struct fl_span_res {
     uint64_t end_bit;  // where it stopped: the start of another span, or the bit behind the final block
     uint64_t out_len;
     uint32_t status;      // 0: decoded; anything else: the stream goes the old way
     uint32_t final_seen;  // stopped behind the final block
-    uint32_t crc, adA, adB;  // pass 2: checksum pieces of its output (adB counts from the end of the span)
-    uint32_t tail_same;      // pass 2: the tail equals the resolved one
-    uint32_t uses_hist;      // pass 1: a copy reaches before the span's first byte
-    uint32_t pad;
+    uint32_t uses_hist;   // a copy reaches before the span's first byte
+    uint32_t n_pieces;    // run A: pieces of the pool taken
 };
 #define FP_TAIL 32768u
 #define FP_NO_SPAN 0xffffffffu
+// Run A of a span that is not the first of its stream does not know where its bytes belong: they go to PIECES of a
+// pool, taken as the span grows (one atomic per 64 KiB); k_span_fix moves them to their place.
+#define FP_PIECE_LOG 16u
+#define FP_PIECE (1u << FP_PIECE_LOG)
+#define FP_MAX_PIECES 2048u  // per span: 128 MiB of output
+struct fl_span_pool {
+    uint8_t* base;    // pieces of FP_PIECE bytes
+    uint32_t* next;   // [0]: pieces handed out so far
+    uint32_t* tab;    // [span][FP_MAX_PIECES]: a span's pieces in order
+    uint32_t pieces;  // in the pool
+    uint32_t pad;
+};
 
-// MODE 0: the whole stream (k_inflate_par); 1 / 2: a span, passes 1 and 2 (k_inflate_span)
+// MODE 0: the whole stream (k_inflate_par); 1: a span, run A (fill 0) or B (fill 1) (k_inflate_span)
 template <int MODE>
 __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks, int container,
                                         int flags, uint32_t min_bytes, fl_crc_consts cc, uint8_t* __restrict__ out,
                                         uint64_t* __restrict__ out_len, int32_t* __restrict__ status,
                                         uint64_t* __restrict__ consumed, const fl_span* __restrict__ spans,
                                         fl_span_res* __restrict__ sres, const uint64_t* __restrict__ cand,
-                                        const uint32_t* __restrict__ cand_off, uint8_t* __restrict__ tails, uint32_t fill) {
+                                        const uint32_t* __restrict__ cand_off, uint8_t* __restrict__ tails, uint32_t fill,
+                                        fl_span_pool pool) {
     __shared__ fp_shared sh_mem;
     FL_LDS fp_shared* sh = (FL_LDS fp_shared*)&sh_mem;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
@@ -298,7 +311,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     sp.prev = FP_NO_SPAN;
     sp.live = 1;
     if (MODE != 0) sp = spans[blockIdx.x];
-    if ((MODE == 2 || (MODE == 1 && fill)) && !sp.live) return;  // (run A of pass 1 finds out which spans are live)
+    if (MODE == 1 && fill && (!sp.live || sp.first)) return;  // (run A finds out which spans are live; a first span's run A is final)
     const uint32_t c = sp.stream;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
@@ -309,9 +322,11 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     }
     const uint8_t* src = in + ck.in_off;
     uint8_t* dst = out + ck.out_off + sp.wp;  // (sh->wp counts from the span's first output byte)
-    const uint64_t out_room = MODE == 1 ? ~0ull : (ck.out_cap > sp.wp ? ck.out_cap - sp.wp : 0ull);
+    // run A of a span that does not know its place (sp.wp is 0 in run A, the host sets it before run B)
+    const bool to_pool = MODE == 1 && !fill && !sp.first;
+    const uint64_t out_room = to_pool ? ~0ull : (ck.out_cap > sp.wp ? ck.out_cap - sp.wp : 0ull);
     // output bytes that exist before the span's first: a distance may reach that far back
-    const uint64_t hist_avail = MODE == 0 ? 0ull : MODE == 1 ? (sp.first ? 0ull : (uint64_t)FP_TAIL) : min((uint64_t)FP_TAIL, sp.wp);
+    const uint64_t hist_avail = MODE == 0 || sp.first ? 0ull : fill ? min((uint64_t)FP_TAIL, sp.wp) : (uint64_t)FP_TAIL;
     const uint64_t total_bits = (uint64_t)ck.in_len * 8;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
@@ -332,6 +347,27 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
         }
     };
     auto reader_pos = [&]() -> uint64_t { return total_bits - (uint64_t)r.left; };
+    // where output byte o of the span goes
+    auto out_at = [&](uint64_t o) -> uint8_t* {
+        if (MODE == 1 && to_pool)
+            return pool.base + (uint64_t)sh->piece_id[(uint32_t)(o >> FP_PIECE_LOG) & 1u] * FP_PIECE + ((uint32_t)o & (FP_PIECE - 1u));
+        return dst + o;
+    };
+    // (thread 0) pieces for the span's bytes below `end`; the bytes about to be written lie in the last two
+    auto pieces_to = [&](uint64_t end) -> bool {
+        const uint64_t need = (end + FP_PIECE - 1u) >> FP_PIECE_LOG;
+        uint32_t n = sh->n_pieces;
+        while (n < need) {
+            if (n >= FP_MAX_PIECES) return false;
+            const uint32_t id = atomicAdd(pool.next, 1u);
+            if (id >= pool.pieces) return false;
+            pool.tab[(uint64_t)blockIdx.x * FP_MAX_PIECES + n] = id;
+            sh->piece_id[n & 1u] = id;
+            n++;
+        }
+        sh->n_pieces = n;
+        return true;
+    };
 
     if (tid == 0) {
         sh->redo = 0;
@@ -351,23 +387,18 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
         }
     }
     if (MODE != 0) {
-        // the 32 KiB before the span: pass 1: filling A or B (see above); pass 2: its predecessor's true tail
-        const uint8_t* hist = (MODE == 2 && sp.prev != FP_NO_SPAN) ? tails + (uint64_t)sp.prev * FP_TAIL : nullptr;
+        // the 32 KiB before the span: filling A or B (see above)
         for (uint32_t i = tid; i < FP_TAIL / 4; i += FP_THREADS) {
-            uint32_t v = 0;
-            if (hist) {
-                v = ((const uint32_t*)hist)[i];
-            } else if (MODE == 1) {
-                // bytes 4 i .. 4 i + 3: A = low byte of the index, B = A ^ (high byte of the index + 1)
-                const uint32_t lowb = ((4 * i) & 0xff) * 0x01010101u + 0x03020100u;
-                const uint32_t hib = ((4 * i) >> 8) + 1u;
-                v = fill ? (lowb ^ (hib * 0x01010101u)) : lowb;
-            }
+            // bytes 4 i .. 4 i + 3: A = low byte of the index, B = A ^ (high byte of the index + 1)
+            const uint32_t lowb = ((4 * i) & 0xff) * 0x01010101u + 0x03020100u;
+            const uint32_t hib = ((4 * i) >> 8) + 1u;
+            const uint32_t v = fill ? (lowb ^ (hib * 0x01010101u)) : lowb;
             ((FL_LDS uint32_t*)&sh->ring[FP_RING - FP_TAIL])[i] = v;
         }
         if (tid == 0) {
             sh->nblk = 0;
             sh->uses_hist = 0;
+            sh->n_pieces = 0;
         }
     }
     __syncthreads();
@@ -465,9 +496,13 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             const uint32_t from = (uint32_t)(sh->bitpos >> 3);
             if (wp + len > out_room) {
                 bail = true;  // (the same in every thread) OutputTooSmall is k_inflate's to report
-            } else {
-                if (MODE != 1)
-                    for (uint32_t i = tid; i < len; i += FP_THREADS) dst[wp + i] = src[from + i];
+            } else if (MODE == 1 && to_pool) {
+                if (tid == 0 && !pieces_to(wp + len)) sh->redo = FP_WHY(9);
+                __syncthreads();
+                bail = sh->redo != 0;
+            }
+            if (!bail) {
+                for (uint32_t i = tid; i < len; i += FP_THREADS) *out_at(wp + i) = src[from + i];
                 const uint32_t tail = min(len, FP_RING);
                 for (uint32_t i = tid; i < tail; i += FP_THREADS) {
                     const uint64_t o = wp + len - tail + i;
@@ -668,6 +703,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                     sh->r_cutwave = 0xffffffffu;
                     if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
                     sh->err_far = 0;
+                    if (MODE == 1 && to_pool && !pieces_to(wp + FP_OUT_CAP)) sh->redo = FP_WHY(9);
                     uint32_t run = 0;
                     for (uint32_t w = 0; w < nvalid; w++) {
                         sh->w_base[w] = run;
@@ -808,8 +844,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 }
                 FP_T(39);
                 // (8) the window's bytes leave
-                if (MODE != 1)
-                    for (uint32_t j = tid; j < nout; j += FP_THREADS) dst[wp + j] = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
+                for (uint32_t j = tid; j < nout; j += FP_THREADS) *out_at(wp + j) = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
                 __syncthreads();
                 if (tid == 0) {
                     const uint64_t nb = bitpos + sh->r_next;  // r_next counts from the window's first bit
@@ -848,25 +883,17 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
         // the span's tail: the last 32 KiB of the output up to its end (what was there before it included)
         const uint32_t wb = (uint32_t)(n_out % FP_RING);
         uint8_t* tl = tails + (uint64_t)blockIdx.x * FP_TAIL;
-        bool differs = false;
-        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) {
-            const uint8_t v = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
-            if (MODE == 1)
-                tl[i] = v;
-            else
-                differs = differs || tl[i] != v;
-        }
-        const int any_diff = __syncthreads_or(differs ? 1 : 0);
+        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) tl[i] = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
         if (tid == 0) {
             fl_span_res* rr = &sres[blockIdx.x];
             rr->end_bit = sh->bitpos;
             rr->out_len = n_out;
             rr->final_seen = final_seen ? 1u : 0u;
-            rr->tail_same = any_diff ? 0u : 1u;
             rr->uses_hist = sh->uses_hist;
+            rr->n_pieces = sh->n_pieces;
             rr->status = 0;
         }
-        if (MODE == 1) return;
+        return;  // (checksums: k_span_fix; the footer: the host)
     }
     if (container != 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -914,15 +941,6 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             }
         }
         __syncthreads();
-    }
-    if (MODE == 2) {
-        if (tid == 0) {
-            fl_span_res* rr = &sres[blockIdx.x];
-            rr->crc = sh->crc;
-            rr->adA = sh->adA;
-            rr->adB = sh->adB;
-        }
-        return;
     }
     if (wave == 0) {
         reader_at(sh->bitpos);
@@ -1238,11 +1256,10 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                                                                int32_t* __restrict__ status,
                                                                uint64_t* __restrict__ consumed) {
     fp_body<0>(in, chunks, container, flags, min_bytes, cc, out, out_len, status, consumed, nullptr, nullptr, nullptr,
-               nullptr, nullptr, 0u);
+               nullptr, nullptr, 0u, fl_span_pool{nullptr, nullptr, nullptr, 0u, 0u});
 }
 
-// One workgroup per span (see above); PASS 1 or 2.
-template <int PASS>
+// One workgroup per span (see above); fill 0: run A, 1: run B.
 __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* __restrict__ in,
                                                                 const fl_chunk* __restrict__ chunks, int container,
                                                                 int flags, fl_crc_consts cc, uint8_t* __restrict__ out,
@@ -1250,9 +1267,157 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
                                                                 fl_span_res* __restrict__ sres,
                                                                 const uint64_t* __restrict__ cand,
                                                                 const uint32_t* __restrict__ cand_off,
-                                                                uint8_t* __restrict__ tails, uint32_t fill) {
-    fp_body<PASS>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails,
-                  fill);
+                                                                uint8_t* __restrict__ tails, uint32_t fill,
+                                                                fl_span_pool pool) {
+    fp_body<1>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails, fill,
+               pool);
+}
+
+// The bytes of the live spans, 64 KiB (an ITEM) per wave, a lane per 1024 of them: moved from the pool to their place
+// where run A could not know it, made true where they depend on the history (a != b: byte ((a ^ b) - 1) << 8 | a of
+// the true tail before the span), and their CRC-32 / Adler-32 piece (folded by the host in stream order).
+//   kind 0  a first span: the bytes are in place and final
+//   kind 1  no span of the batch copies from before its start (run B was skipped): run A's bytes are final
+//   kind 2  run A's bytes in the pool, run B's in place
+struct __attribute__((aligned(4))) fl_u4a {  // four words at a word-aligned address
+    uint32_t x[4];
+};
+struct fl_fix_item {
+    uint64_t dst;    // of the item's first byte in the output buffer
+    uint32_t span;   // whose pieces
+    uint32_t local;  // offset of the item in the span's output (a multiple of FP_PIECE)
+    uint32_t len;    // <= FP_PIECE
+    uint32_t kind;
+    uint32_t prev;   // kind 2: the span before it in the chain
+    uint32_t pad;
+};
+__global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__ items, fl_span_pool pool,
+                                                 const uint8_t* __restrict__ tails, uint8_t* out, int container,
+                                                 fl_crc_consts cc, uint32_t* __restrict__ part /* [n_items][2] */) {
+    __shared__ uint32_t tab[4][256];
+    const fl_fix_item it = items[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    if (container == 1) {
+        for (uint32_t t = lane; t < 256; t += 64) {
+            uint32_t c = t;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (FL_CRC_POLY ^ (c >> 1)) : (c >> 1);
+            tab[0][t] = c;
+        }
+        fl_wave_lds_sync();
+        for (int k = 1; k < 4; k++) {
+            for (uint32_t t = lane; t < 256; t += 64) {
+                const uint32_t c = tab[k - 1][t];
+                tab[k][t] = tab[0][c & 0xff] ^ (c >> 8);
+            }
+            fl_wave_lds_sync();
+        }
+    }
+    const uint32_t lo = min(it.len, lane * 1024u), hi = min(it.len, lane * 1024u + 1024u);
+    uint8_t* D = out + it.dst;
+    const uint8_t* A = it.kind ? pool.base + (uint64_t)pool.tab[(uint64_t)it.span * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE : D;
+    const uint8_t* T = it.kind == 2 ? tails + (uint64_t)it.prev * FP_TAIL : tails;
+    uint32_t c = 0xffffffffu, adA = 0, adB = 0;
+    auto one = [&](uint32_t i) {  // byte i of the item
+        uint32_t v = A[i];
+        if (it.kind == 2) {
+            const uint32_t x = v ^ D[i];
+            if (x) v = T[(((x - 1u) << 8) | v) & (FP_TAIL - 1u)];
+        }
+        if (it.kind) D[i] = (uint8_t)v;
+        if (container == 1) c = tab[0][(c ^ v) & 0xff] ^ (c >> 8);
+        adA += v;
+        adB += adA;
+    };
+    uint32_t i = lo;
+    while (i < hi && (((uintptr_t)(D + i)) & 3)) one(i++);
+    // (pieces are aligned, the output is where the caller put it: the pool is read through aligned words, one more
+    // than the output has.)  A lane takes 128 bytes at a time: every cache line is requested once, not once per word.
+    const uint32_t sa = (uint32_t)(((uintptr_t)(A + i)) & 3) * 8;
+    auto word = [&](uint32_t v, uint32_t b) -> uint32_t {  // the true bytes of one word; into the checksum
+        if (it.kind == 2) {
+            const uint32_t x = v ^ b;
+            if (x) {
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const uint32_t xa = (v >> (8 * y)) & 0xff, xd = (x >> (8 * y)) & 0xff;
+                    if (xd) v = (v & ~(0xffu << (8 * y))) | ((uint32_t)T[(((xd - 1u) << 8) | xa) & (FP_TAIL - 1u)] << (8 * y));
+                }
+            }
+        }
+        if (container == 1) {
+            c ^= v;
+            c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+        } else if (container == 2) {
+            adA += v & 0xff; adB += adA;
+            adA += (v >> 8) & 0xff; adB += adA;
+            adA += (v >> 16) & 0xff; adB += adA;
+            adA += v >> 24; adB += adA;
+        }
+        return v;
+    };
+    for (; i + 128 <= hi; i += 128) {
+        fl_u4a bq[8], aq[8];
+        uint32_t a8 = 0;
+        if (it.kind != 1)
+#pragma unroll
+            for (int q = 0; q < 8; q++) bq[q] = ((const fl_u4a*)(D + i))[q];
+        if (it.kind) {
+            const fl_u4a* Aq = (const fl_u4a*)(((uintptr_t)(A + i)) & ~(uintptr_t)3);
+#pragma unroll
+            for (int q = 0; q < 8; q++) aq[q] = Aq[q];
+            if (sa) a8 = ((const uint32_t*)Aq)[32];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            fl_u4a o;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t v, b = 0;
+                if (it.kind != 1) b = bq[q].x[w];
+                if (it.kind) {
+                    const uint32_t a0 = aq[q].x[w];
+                    const uint32_t a1 = w < 3 ? aq[q].x[(w + 1) & 3] : q < 7 ? aq[(q + 1) & 7].x[0] : a8;
+                    v = sa ? __builtin_amdgcn_alignbit(a1, a0, sa) : a0;
+                } else {
+                    v = b;
+                }
+                o.x[w] = word(v, b);
+            }
+            if (it.kind) ((fl_u4a*)(D + i))[q] = o;
+        }
+    }
+    for (; i + 4 <= hi; i += 4) {
+        uint32_t v, b = 0;
+        if (it.kind != 1) b = *(const uint32_t*)(D + i);
+        if (it.kind) {
+            const uint32_t* Aw = (const uint32_t*)(((uintptr_t)(A + i)) & ~(uintptr_t)3);
+            const uint32_t a0 = Aw[0], a1 = sa ? Aw[1] : 0u;
+            v = sa ? __builtin_amdgcn_alignbit(a1, a0, sa) : a0;
+        } else {
+            v = b;
+        }
+        v = word(v, b);
+        if (it.kind) *(uint32_t*)(D + i) = v;
+    }
+    for (; i < hi; i++) one(i);
+    const uint32_t after = it.len - hi;
+    if (container == 1) {
+        c = (hi > lo) ? ~c : 0u;  // crc of an empty slice is 0
+        const uint32_t full = after >> 10, tail = after & 1023u;
+        uint32_t tpow = 0x80000000u;
+        for (int j = 0; j < 10; j++)
+            if (tail & (1u << j)) tpow = fl_crc_mulmod(cc.xpow8[j], tpow);
+        c = fl_crc_mulmod(fl_crc_mulmod(c, cc.pow1024[full]), tpow);
+        c = fl_wave_xor(c);
+        if (lane == 0) part[2 * (uint64_t)blockIdx.x] = c;
+    } else if (container == 2) {
+        // (<= 1024 bytes per lane: adB < 2^28) pieces with a = b = 0 start, lanes combined in order
+        const uint32_t Bm = (uint32_t)(((uint64_t)adB + (uint64_t)adA * after) % 65521u);
+        const uint32_t Am = fl_wave_sum(adA) % 65521u;  // <= 65536 * 255
+        const uint32_t Bs = fl_wave_sum(Bm) % 65521u;
+        if (lane == 0) part[2 * (uint64_t)blockIdx.x] = Am | (Bs << 16);
+    }
+    if (lane == 0) part[2 * (uint64_t)blockIdx.x + 1] = it.len;
 }
 
 // The true tails of a stream's spans, in chain order (one workgroup per stream; see above).  tails_a is resolved in
@@ -1271,13 +1436,26 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_resolve(const uint32_t* __r
     }
     __syncthreads();
     uint32_t cur = 0;
+    // (the two fillings of the next span's tail are requested while the current one is resolved)
+    uint4 na[2], nb[2];
+    if (j0 + 1 < j1) {
+        const uint4* pa = (const uint4*)(tails_a + (uint64_t)chain[j0 + 1] * FP_TAIL);
+        const uint4* pb = (const uint4*)(tails_b + (uint64_t)chain[j0 + 1] * FP_TAIL);
+        na[0] = pa[2 * tid]; na[1] = pa[2 * tid + 1];
+        nb[0] = pb[2 * tid]; nb[1] = pb[2 * tid + 1];
+    }
     for (uint32_t j = j0 + 1; j < j1; j++) {
         uint4* ta = (uint4*)(tails_a + (uint64_t)chain[j] * FP_TAIL);
-        const uint4* tb = (const uint4*)(tails_b + (uint64_t)chain[j] * FP_TAIL);
         const uint8_t* prev = (const uint8_t*)tl[cur];
         uint32_t* mine = tl[cur ^ 1];
-        uint4 a[2] = {ta[2 * tid], ta[2 * tid + 1]};
-        const uint4 b[2] = {tb[2 * tid], tb[2 * tid + 1]};
+        uint4 a[2] = {na[0], na[1]};
+        const uint4 b[2] = {nb[0], nb[1]};
+        if (j + 1 < j1) {
+            const uint4* pa = (const uint4*)(tails_a + (uint64_t)chain[j + 1] * FP_TAIL);
+            const uint4* pb = (const uint4*)(tails_b + (uint64_t)chain[j + 1] * FP_TAIL);
+            na[0] = pa[2 * tid]; na[1] = pa[2 * tid + 1];
+            nb[0] = pb[2 * tid]; nb[1] = pb[2 * tid + 1];
+        }
         bool changed = false;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
