@@ -585,6 +585,9 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
 #define FL_SPAN_MIN_BYTES (512u * 1024u)   // streams shorter than this are not cut
 #define FL_SPAN_BYTES (64u * 1024u)        // compressed bytes per span, at least
 #define FL_SPAN_MAX 1024u                  // spans per call
+#ifndef FL_SPAN_STREAMS
+#define FL_SPAN_STREAMS 32u
+#endif
 int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std::vector<fl_chunk>& chunks, int container,
                      int flags, uint8_t* d_out, uint64_t* d_outlen, int32_t* d_status, uint64_t* d_consumed) {
     const uint32_t n_chunks = (uint32_t)chunks.size();
@@ -592,15 +595,15 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     const uint64_t min_bytes = e ? (uint64_t)atoll(e) : FL_SPAN_MIN_BYTES;
     if (!min_bytes || (flags & 1)) return 0;
     const bool dbg = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
-    // Worth it (every span is decoded two or three times) when the long streams of the batch are too few to fill
-    // the chip with a workgroup each: at most 32 of them
+    // Worth it (every span is decoded twice) when the long streams of the batch are too few to fill the chip with
+    // a workgroup each: at most FL_SPAN_STREAMS of them (-DFL_SPAN_STREAMS: tuning)
     std::vector<uint32_t> elig;
     uint32_t n_long = 0;
     for (uint32_t i = 0; i < n_chunks; i++) {
         n_long += chunks[i].in_len >= 32768u ? 1u : 0u;
         if (chunks[i].in_len >= min_bytes) elig.push_back(i);
     }
-    if (elig.empty() || n_long > 32 || elig.size() > 256) return 0;
+    if (elig.empty() || n_long > FL_SPAN_STREAMS || elig.size() > 256) return 0;
     int rc;
     // ---- where spans may start
     std::vector<fl_scan_point> points;
@@ -614,14 +617,18 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
         h->n_cu = (uint32_t)v;
     }
-    uint64_t elig_bytes = 0;
-    for (uint32_t ci : elig) elig_bytes += chunks[ci].in_len;
-    const uint64_t rounds = std::min<uint64_t>(4, std::max<uint64_t>(1, (elig_bytes + h->n_cu * 131072ull) / (h->n_cu * 262144ull)));
-    const uint64_t want = std::min<uint64_t>({(uint64_t)FL_SPAN_MAX, rounds * h->n_cu - std::min<uint32_t>(8u, h->n_cu / 2), std::max<uint64_t>(2, elig_bytes / FL_SPAN_BYTES)});
+    // What a span costs goes with the bytes it makes; a stream's share of the spans goes with the room its caller
+    // gave it (exact for gzip members whose ISIZE was read; 32 bytes per compressed byte at most), a span has at
+    // least FL_SPAN_BYTES / 4 compressed bytes.
+    auto weight = [&](const fl_chunk& c) { return std::max<uint64_t>(c.in_len, std::min<uint64_t>(c.out_cap, 32ull * c.in_len)); };
+    uint64_t elig_w = 0;
+    for (uint32_t ci : elig) elig_w += weight(chunks[ci]);
+    const uint64_t rounds = std::min<uint64_t>(4, std::max<uint64_t>(1, (elig_w + h->n_cu * 393216ull) / (h->n_cu * 786432ull)));
+    const uint64_t want = std::min<uint64_t>({(uint64_t)FL_SPAN_MAX, rounds * h->n_cu - std::min<uint32_t>(8u, h->n_cu / 2), std::max<uint64_t>(2, elig_w / (3 * FL_SPAN_BYTES))});
     for (size_t k = 0; k < elig.size(); k++) {
         const fl_chunk& c = chunks[elig[k]];
         const uint64_t bits = (uint64_t)c.in_len * 8;
-        const uint32_t P = (uint32_t)std::max<uint64_t>(2, want * c.in_len / elig_bytes);
+        const uint32_t P = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
             pt.from_bit = bits / P * j;
