@@ -974,7 +974,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
 // Where can a span start?  At the first bit position at or behind a target position at which a dynamic block
 // header parses (inflate.zig:137-218: type bits 10, HLIT / HDIST in range, a complete code-length code, code
 // lengths that decode without overrun into a complete literal / length code with an end-of-block symbol and a
-// usable distance code).  One workgroup per target, windows of 64 Kibit:
+// usable distance code), or at a stored block that follows a stored block.  One workgroup per target, windows of 128 Kibit:
 //   1. every lane tests bit positions against what costs a few instructions (type, HLIT, HDIST, the Kraft sum of
 //      the code-length code): about 1 in 250 survives;
 //   2. every survivor gets a LANE that decodes its code lengths on its own (canonical code-length code held in
@@ -987,9 +987,11 @@ struct fl_scan_point {
     uint64_t from_bit, limit_bit;  // search [from_bit, limit_bit)
     uint32_t stream, pad;
 };
-#define FP_SCAN_WIN_BITS 65536u
+#ifndef FP_SCAN_WIN_BITS
+#define FP_SCAN_WIN_BITS 131072u  // (64 / 128 / 256 Kibit: 170 MiB of text 1.04 / 0.73 / 0.82 ms, config #4's stream 2.5 / 1.85 / 1.4: step 2 costs its slowest lane once per window)
+#endif
 #define FP_SCAN_STAGE_DW (FP_SCAN_WIN_BITS / 32 + 8 + 80)  // + what a header at the end of the window reaches into (at most 17 + 57 + 316 * 14 bits ... the lane gives up beyond the stage)
-#define FP_SCAN_CAP 2048u
+#define FP_SCAN_CAP (FP_SCAN_WIN_BITS / 32u)
 #define FP_SCAN_LANES 256u  // lanes that validate at a time (128 bytes of LDS each)
 struct fp_scan_shared {
     fl_inflate_ws ws;
@@ -1000,6 +1002,7 @@ struct fp_scan_shared {
     uint32_t nsurv, npass;
     uint32_t passed[64];         // ... of step 2
     uint32_t found;
+    uint32_t st_found;           // lowest window bit of a stored block's header (0xffffffff: none)
 };
 
 // 64 bits of the stream from bit position `bit` (zero beyond the end)
@@ -1146,6 +1149,44 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
     r.inring = (FL_LDS uint32_t*)sh->inring;
     r.left = (int64_t)total_bits;
     uint64_t found_bit = ~0ull;
+    // ---- a target inside a stored block (store-only streams, incompressible stretches): nothing parses there, and
+    // the windows below would take their time to find that out.  The first stored header behind the target that is
+    // followed by another one (at most 65540 bytes on), then the stored header before it whose LEN ends there: if that
+    // block holds the target, the header behind it is the place.
+    {
+        auto stored_at = [&](uint64_t q, uint32_t low_mask) -> uint32_t {  // LEN of a stored header at byte q, or ~0u
+            if (q + 5 > ck.in_len) return 0xffffffffu;
+            const uint32_t w0 = fl_load_u32_clamped(src, (uint32_t)q, ck.in_len), w1 = fl_load_u32_clamped(src, (uint32_t)q + 4, ck.in_len);
+            const uint32_t len = (w0 >> 8) & 0xffff, nlen = (w0 >> 24) | ((w1 & 0xff) << 8);
+            return ((w0 & low_mask) == 0 && (len ^ nlen) == 0xffff) ? len : 0xffffffffu;
+        };
+        if (tid == 0) {
+            sh->st_found = 0xffffffffu;
+            sh->found = 0;
+        }
+        __syncthreads();
+        const uint64_t q0 = (pt.from_bit + 7) >> 3, q1 = min((pt.limit_bit + 7) >> 3, q0 + 65541u);
+        for (uint64_t q = q0 + tid; q < q1; q += FP_THREADS) {
+            const uint32_t len = stored_at(q, 7u);
+            if (len != 0xffffffffu && stored_at(q + 5 + len, 6u) != 0xffffffffu) atomicMin(&sm.st_found, (uint32_t)(q - q0));
+        }
+        __syncthreads();
+        const uint32_t sf = sh->st_found;
+        if (sf != 0xffffffffu) {
+            const uint64_t s = q0 + sf;
+            for (uint32_t len = tid; len < 65536u && len + 5 <= s; len += FP_THREADS) {
+                const uint64_t q = s - 5 - len;
+                if (q * 8 + 3 <= pt.from_bit + 7 && stored_at(q, 6u) == len) sh->found = 1;  // (header bits at or before the target)
+            }
+        }
+        __syncthreads();
+        const bool inside = sf != 0xffffffffu && sh->found != 0;
+        __syncthreads();
+        if (inside) {
+            if (tid == 0) found_out[blockIdx.x] = (q0 + sf) * 8;
+            return;
+        }
+    }
     for (uint64_t base = pt.from_bit; base < pt.limit_bit; base += FP_SCAN_WIN_BITS) {
         const uint32_t byte0 = (uint32_t)(base >> 3), bsh = (uint32_t)base & 7;
         for (uint32_t i = tid; i < FP_SCAN_STAGE_DW; i += FP_THREADS) sh->stage[i] = fl_load_u32_clamped(src, byte0 + 4 * i, ck.in_len);
@@ -1153,14 +1194,47 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
             sh->nsurv = 0;
             sh->npass = 0;
             sh->found = 0;
+            sh->st_found = 0xffffffffu;
         }
         __syncthreads();
+#ifdef FP_SCAN_PROF
+        uint64_t tp_ = __builtin_readcyclecounter();
+#define FP_SCAN_T(slot) do { const uint64_t n_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[slot], (unsigned long long)(n_ - tp_)); tp_ = n_; } while (0)
+#else
+#define FP_SCAN_T(slot)
+#endif
+        // ---- 0: stored blocks in a row.  Behind a stored block the next header starts a byte: BFINAL 0, BTYPE 00 in
+        // its low three bits, then LEN and its complement (inflate.zig:89-102); taken when the block behind it starts
+        // the same way (one in 2^38 bytes does by accident).  A run of stored blocks has no other place to cut at.
+        {
+            const uint32_t first_byte = (uint32_t)((base + 7) >> 3);  // the window's byte positions
+            for (uint32_t j = tid; j < FP_SCAN_WIN_BITS / 8; j += FP_THREADS) {
+                const uint32_t q = first_byte + j;
+                const uint64_t bit = (uint64_t)q * 8;
+                if (bit >= pt.limit_bit || (uint64_t)q + 5 > ck.in_len) break;
+                const uint32_t rel = q - byte0;  // in the stage
+                const uint32_t d0 = sh->stage[rel >> 2], d1 = sh->stage[(rel >> 2) + 1], d2 = sh->stage[(rel >> 2) + 2];
+                const uint32_t sft = (rel & 3) * 8;
+                const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sft), w1 = __builtin_amdgcn_alignbit(d2, d1, sft);
+                const uint32_t len = (w0 >> 8) & 0xffff, nlen = (w0 >> 24) | ((w1 & 0xff) << 8);
+                if ((w0 & 7) == 0 && (len ^ nlen) == 0xffff) {
+                    const uint64_t nq = (uint64_t)q + 5 + len;  // the header behind it
+                    if (nq + 5 <= ck.in_len) {
+                        const uint32_t n0 = src[nq], nl = (uint32_t)src[nq + 1] | ((uint32_t)src[nq + 2] << 8);
+                        const uint32_t nn = (uint32_t)src[nq + 3] | ((uint32_t)src[nq + 4] << 8);
+                        if ((n0 & 6) == 0 && (nl ^ nn) == 0xffff) atomicMin(&sm.st_found, (uint32_t)(bit - base));
+                    }
+                }
+            }
+        }
+        FP_SCAN_T(13);
         // ---- 1: first what costs a handful of instructions (type bits, HLIT, HDIST: 1 position in 4.5 passes), for all
         // 64 positions of the lane; then the Kraft sum of the code-length code for those that passed
+        for (uint32_t g = 0; g < FP_SCAN_WIN_BITS / FP_THREADS; g += 64) {
         uint64_t cheap = 0;
 #pragma unroll 4
-        for (uint32_t jj = 0; jj < FP_SCAN_WIN_BITS / FP_THREADS; jj++) {
-            const uint32_t wb = jj * FP_THREADS + tid;
+        for (uint32_t jj = 0; jj < 64; jj++) {
+            const uint32_t wb = (g + jj) * FP_THREADS + tid;
             const uint64_t bit = base + wb;
             const uint32_t di = (bsh + wb) >> 5, shf = (bsh + wb) & 31;
             const uint32_t lo = __builtin_amdgcn_alignbit(sh->stage[di + 1], sh->stage[di], shf);  // 32 bits from that position
@@ -1170,7 +1244,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
         while (cheap) {
             const uint32_t jj = (uint32_t)__builtin_ctzll(cheap);
             cheap &= cheap - 1;
-            const uint32_t wb = jj * FP_THREADS + tid;
+            const uint32_t wb = (g + jj) * FP_THREADS + tid;
             const uint64_t bit = base + wb;
             uint32_t lo, hi, lo2, hi2;
             fp_fetch64(sh->stage, bsh + wb, lo, hi);
@@ -1191,7 +1265,9 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
                 if (k < FP_SCAN_CAP) sh->surv[k] = wb;
             }
         }
+        }
         __syncthreads();
+        FP_SCAN_T(14);
         // ---- 2
         const uint32_t ns = min(sh->nsurv, FP_SCAN_CAP);
 #ifdef FP_SCAN_PROF
@@ -1205,6 +1281,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
             }
         }
         __syncthreads();
+        FP_SCAN_T(15);
         // ---- 3
 #ifdef FP_SCAN_PROF
         if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[12], (unsigned long long)sh->npass);
@@ -1239,9 +1316,13 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_scan(const uint8_t* __restr
             }
         }
         __syncthreads();
-        if (sh->found) {
-            found_bit = base + (sh->found - 1u);
-            break;
+        FP_SCAN_T(16);
+        {
+            const uint32_t f = min(sh->found ? sh->found - 1u : 0xffffffffu, sh->st_found);
+            if (f != 0xffffffffu) {
+                found_bit = base + f;
+                break;
+            }
         }
         __syncthreads();  // (the lists are rewritten by the next window)
     }
