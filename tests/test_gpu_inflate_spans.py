@@ -28,7 +28,7 @@ def _kernels(eng, fn):
 
 
 @pytest.mark.parametrize("container", [0, 1, 2])
-@pytest.mark.parametrize("mode", [6, 4, 9, O.HUFFMAN])
+@pytest.mark.parametrize("mode", [6, 4, 9, O.HUFFMAN, O.STORE])
 def test_one_long_stream_takes_the_span_path(container, mode):
     """The reference's own stream (oracle-made, 6 MiB of the Silesia-like mix): decoded by spans -- the profile shows
     the kernels -- byte for byte, with the container's checksum and the consumed count."""
@@ -119,6 +119,25 @@ def test_differential_fuzz_through_the_span_path(monkeypatch):
                 assert O.STATUS[s_] == name, (container, len(b), O.STATUS[s_], name)
                 if name == "Ok":
                     assert o == want and u == wused
+
+
+def test_runs_of_stored_blocks_are_cut_at_stored_headers():
+    """Incompressible stretches between text (zlib and the oracle store them): the only places to cut at inside a run
+    of stored blocks are the stored headers; targets inside a stored block, before a run, behind its last block."""
+    from flate_amd import synth
+    eng = engine()
+    rng = np.random.default_rng(17)
+    text = synth.text(synth.SEED_TEXT + 31, 3 << 20).tobytes()
+    noise = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    datas = [text[:1 << 20] + noise(2 << 20) + text[1 << 20:2 << 20] + noise(70000) + text[2 << 20:] + noise(1 << 20),
+             noise(3 << 20) + text[:300000] + noise(3 << 20),
+             noise(5 << 20)]
+    for data in datas:
+        for comp, container in ((pyzlib.compress(data, 6), 2), (O.compress(data, 1, 6), 1), (O.compress(data, 0, O.STORE), 0)):
+            assert len(comp) >= 600 * 1024
+            (outs, st, used), prof = _kernels(eng, lambda: eng.decompress_many([comp], container, caps=[len(data)]))
+            assert st == [0] and used == [len(comp)] and outs[0] == data
+            assert "k_inflate_span" in prof and prof.get("k_inflate_par", (0.0, 0))[0] < 1.0, prof
 
 
 def test_a_batch_of_long_and_short_streams():
