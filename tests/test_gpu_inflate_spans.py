@@ -2,7 +2,7 @@
 kernels_inflate_par.h "spans", k_span_scan / k_inflate_span / k_span_resolve): bytes, consumed counts and the
 reference's error names (inflate.zig:487-527) against the oracle, through the C ABI.
 
-The library takes the path for streams of at least FLATE_HIP_INFLATE_SPANS compressed bytes (default 512 KiB);
+The library takes the path for streams of at least FLATE_HIP_INFLATE_SPANS compressed bytes (default 128 KiB);
 most tests here lower that bound so that ordinary test-sized streams -- and every damaged one -- go through it."""
 import zlib as pyzlib
 
@@ -36,7 +36,7 @@ def test_one_long_stream_takes_the_span_path(container, mode):
     eng = engine()
     data = synth.silesia_like(synth.SEED_SILESIA + 11 + mode, 6 * 1024 * 1024 + 4321).tobytes()
     comp = O.compress(data, container, mode)
-    assert len(comp) >= 600 * 1024  # (the library cuts streams of at least 512 KiB)
+    assert len(comp) >= 600 * 1024  # (the library cuts streams of at least 128 KiB)
     (outs, st, used), prof = _kernels(eng, lambda: eng.decompress_many([comp], container, caps=[len(data)]))
     assert st == [0] and used == [len(comp)]
     assert outs[0] == data
