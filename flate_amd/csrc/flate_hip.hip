@@ -385,8 +385,9 @@ dim3 gather_grid(uint32_t n) { return dim3(n, std::max(1u, std::min(1024u, 4096u
 // Host-buffer calls: bring back only what was produced.  The slots are sized for the worst case (an
 // inflate caller may reserve 1000x the input); when the produced bytes are a small part of the slot
 // range they are packed on the device first (k_scan_lens + k_gather_copy), cross PCIe once, and are put
-// into their slots by the host; otherwise the range is copied as it is.  Bytes of a slot beyond
-// out_len[i] are never written in the caller's buffer.
+// into their slots by the host; otherwise the range up to the last produced byte is copied as it is:
+// bytes of a slot beyond out_len[i] are then whatever the staging buffer held there (the callers clear it:
+// zeros), in the packed case they are not touched.
 int copy_out_host(flate_hip_ctx* h, const uint8_t* d_out, const uint64_t* d_outlen, uint32_t n,
                   const std::vector<uint64_t>& hout, uint64_t out_shift, uint8_t* out, const uint64_t* out_len) {
     hipStream_t st = h->stream;
@@ -1376,7 +1377,7 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         // the sizes): sub-batches with the copies on their own streams, as in compress_impl.  Otherwise one
         // staged copy in, and only the produced bytes come back (copy_out_host).
         pin_io = is_pinned_host(in + in_lo) && is_pinned_host(out + out_lo) &&
-                 (out_hi - out_lo) <= 64 * (in_hi - in_lo) + (1ull << 20) && n_chunks > 4 * host_pass_chunk_limit();
+                 (out_hi - out_lo) <= 8 * (in_hi - in_lo) + (1ull << 20) && n_chunks > 4 * host_pass_chunk_limit();
         if (pin_io && ((!h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) ||
                        (!h->s_out && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess)))
             return FLATE_HIP_E_ALLOC;
@@ -1406,6 +1407,9 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * n_chunks))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->chunks.p, chunks.data(), sizeof(fl_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     HIP_OK(h, hipStreamSynchronize(st));
+    // (what goes back to the caller beyond out_len[i] is zeros, never bytes of an earlier call; the copies of the
+    // call before are done: it waited for them)
+    if (memkind == FLATE_HIP_MEM_HOST && out_hi > out_lo) HIP_OK(h, hipMemsetAsync(h->st_out.p, 0, out_hi - out_lo, st));
     // A few long streams: each by many workgroups at once (spans); what comes out whole is skipped below.
     if (!pin_io) {
         const int done = try_span_inflate(h, st, d_in, chunks, container, flags, d_out, d_outlen, d_status, d_consumed);

@@ -314,3 +314,34 @@ def test_cli_gzip_gunzip_round_trip(tmp_path):
     assert load("gunzip").main([str(tmp_path / "b.gz")]) == 0
     assert (tmp_path / "b").read_bytes() == data + b"second member"
     assert load("gunzip").main([str(f)]) == 1  # not a .gz name
+
+
+def test_host_buffers_get_nothing_of_an_earlier_call_beyond_out_len():
+    """Host-buffer calls stage the output slots on the device: what comes back beyond out_len[i] (the copy takes whole
+    ranges of slots) is zeros or the caller's own bytes, never what an earlier call left in the staging buffer."""
+    eng = engine()
+    L, h = eng._L, eng._h
+    rng = np.random.default_rng(3)
+    first = [bytes([0x5A]) * 50000 for _ in range(12)]           # an earlier call fills the staging buffer with 0x5A
+    outs, st, _ = eng.decompress_many([pyzlib.compress(d, 6) for d in first], 2, caps=[50000] * 12)
+    assert st == [0] * 12 and outs == first
+    datas = [bytes(rng.integers(1, 90, int(n), dtype=np.uint8)) for n in (3000, 17, 12000, 1, 700, 9000, 40, 2500)]
+    streams = [pyzlib.compress(d, 6) for d in datas]
+    n = len(streams)
+    for slot in (16384, 400000):  # (dense: the range is copied as it is; sparse: packed on the device first)
+        in_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in streams], out=in_off[1:])
+        blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
+        out_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(slot)).astype(np.uint64)
+        out = np.full(n * slot + 8, 0xAA, dtype=np.uint8)
+        out_len = np.zeros(n, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        consumed = np.zeros(n, dtype=np.uint64)
+        rc = L.flate_hip_decompress_batch(h, blob.ctypes.data, in_off.ctypes.data, n, 2, 0, out.ctypes.data, out_off.ctypes.data,
+                                          out_len.ctypes.data, status.ctypes.data, consumed.ctypes.data, 0)
+        assert rc == 0 and list(status) == [0] * n
+        for i, d in enumerate(datas):
+            got = out[i * slot:(i + 1) * slot]
+            assert int(out_len[i]) == len(d) and got[:len(d)].tobytes() == d
+            rest = np.unique(got[len(d):])
+            assert set(int(v) for v in rest) <= {0x00, 0xAA}, (slot, i, rest[:8])
