@@ -704,8 +704,13 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     {
         uint64_t bytes = 0;
         for (uint32_t ci : elig) bytes += std::min<uint64_t>(chunks[ci].out_cap, 32ull * chunks[ci].in_len);
-        const uint64_t pieces = std::min<uint64_t>((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1, 0xffffff00ull);
-        if ((rc = ensure(h, h->sp_pool, (size_t)(pieces * FP_PIECE + 16)))) return -1;
+        const uint64_t pieces = (bytes >> FP_PIECE_LOG) + 2ull * nsp + 1;
+        // (a pool the device cannot give -- callers who reserve the worst case for gigabytes of input: the old way)
+        if (pieces * FP_PIECE > (16ull << 30)) return 0;
+        if (ensure(h, h->sp_pool, (size_t)(pieces * FP_PIECE + 16))) {
+            (void)hipGetLastError();  // (not this call's failure)
+            return 0;
+        }
         if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp))) return -1;
         if ((rc = ensure(h, h->sp_poolctl, 16))) return -1;
         if (hipMemsetAsync(h->sp_poolctl.p, 0, 16, st) != hipSuccess) return -1;
