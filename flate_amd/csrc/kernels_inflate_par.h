@@ -685,41 +685,49 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 }
                 __syncthreads();
                 FP_T(36);
-                if (tid == 0) {
+                if (wave == 0) {
+                    // (lane w speaks for wave w: where the window ends, the output offsets of the waves before that)
+                    const bool in = lane < FP_WAVES;
+                    const uint32_t endk = in ? sh->w_endk[lane] : (uint32_t)FP_X_NORMAL;
+                    const uint32_t valid = in ? sh->w_valid[lane] : 0u, endp = in ? sh->w_endp[lane] : 0u;
+                    const uint32_t total = in ? sh->w_total[lane] : 0u;
                     uint32_t nvalid = FP_WAVES, kind = FP_X_NORMAL, next = FP_WAVES * wbits + (sh->w_xpos[FP_WAVES - 1] - wbits);
-                    for (uint32_t w = 0; w < FP_WAVES; w++) {
-                        const uint32_t endk = sh->w_endk[w];
-                        if (endk != FP_X_NORMAL) {
-                            nvalid = w + (sh->w_valid[w] ? 1u : 0u);
-                            kind = endk;
-                            next = w * wbits + sh->w_endp[w];
-                            break;
-                        }
+                    const uint64_t enders = __ballot(in && endk != FP_X_NORMAL);
+                    if (enders) {
+                        const int fw = __builtin_ctzll(enders);
+                        kind = (uint32_t)__builtin_amdgcn_readlane((int)endk, fw);
+                        nvalid = (uint32_t)fw + (__builtin_amdgcn_readlane((int)valid, fw) ? 1u : 0u);
+                        next = (uint32_t)fw * wbits + (uint32_t)__builtin_amdgcn_readlane((int)endp, fw);
                     }
-                    FP_CNT(52 + kind, 1);
-                    FP_CNT(49, nvalid);
-                    sh->r_kind = kind;
-                    sh->r_next = next;  // window bit where the next round / block starts
-                    sh->r_cutwave = 0xffffffffu;
-                    if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
-                    sh->err_far = 0;
-                    if (MODE == 1 && to_pool && !pieces_to(wp + FP_OUT_CAP)) sh->redo = FP_WHY(9);
-                    uint32_t run = 0;
-                    for (uint32_t w = 0; w < nvalid; w++) {
-                        sh->w_base[w] = run;
-                        if (run + sh->w_total[w] > FP_OUT_CAP) {
-                            sh->r_cutwave = w;  // the window is cut at a token of this wave
-                            sh->r_cutbudget = FP_OUT_CAP - run;
-                            nvalid = w + 1;
-                            break;
-                        }
-                        run += sh->w_total[w];
+                    const uint32_t mine = lane < nvalid ? total : 0u;
+                    const uint32_t incl = fl_wave_incl_scan(mine, lane);
+                    const uint32_t base = incl - mine;
+                    uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), cutwave = 0xffffffffu, cutbudget = 0;
+                    const uint64_t over = __ballot(lane < nvalid && base + total > FP_OUT_CAP);
+                    if (over) {  // the window is cut at a token of this wave (which adds what fits)
+                        const int cw = __builtin_ctzll(over);
+                        run = (uint32_t)__builtin_amdgcn_readlane((int)base, cw);
+                        cutwave = (uint32_t)cw;
+                        cutbudget = FP_OUT_CAP - run;
+                        nvalid = (uint32_t)cw + 1u;
                     }
-                    sh->r_nvalid = nvalid;
-                    sh->r_nout = run;  // (the cut wave adds what fits)
-                    sh->unresolved[0] = 0;
-                    sh->unresolved[1] = 0;
-                    sh->unresolved[2] = 0;
+                    if (lane < nvalid) sh->w_base[lane] = base;
+                    if (lane == 0) {
+                        FP_CNT(52 + kind, 1);
+                        FP_CNT(49, nvalid);
+                        sh->r_kind = kind;
+                        sh->r_next = next;  // window bit where the next round / block starts
+                        sh->r_cutwave = cutwave;
+                        sh->r_cutbudget = cutbudget;
+                        if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
+                        sh->err_far = 0;
+                        if (MODE == 1 && to_pool && !pieces_to(wp + FP_OUT_CAP)) sh->redo = FP_WHY(9);
+                        sh->r_nvalid = nvalid;
+                        sh->r_nout = run;
+                        sh->unresolved[0] = 0;
+                        sh->unresolved[1] = 0;
+                        sh->unresolved[2] = 0;
+                    }
                 }
                 __syncthreads();
                 bail = sh->redo != 0;  // (step 6 below does not write it)
