@@ -818,9 +818,16 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 if (bail) break;
                 FP_CNT(50, nout);
                 // (7) resolve the copies inside the window by pointer jumping over byte positions
+                // (a thread's positions tid + 1024 k that are not final yet: one bit each, so that the later rounds look
+                // at those only)
+                uint32_t pend = nout > tid ? (1u << ((nout - tid + FP_THREADS - 1) / FP_THREADS)) - 1u : 0u;
                 for (uint32_t rr = 0;;) {
-                    bool mine = false;
-                    for (uint32_t j = tid; j < nout; j += FP_THREADS) {
+                    uint32_t todo = pend;
+                    pend = 0;
+                    while (todo) {
+                        const uint32_t kb = (uint32_t)__builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const uint32_t j = tid + kb * FP_THREADS;
                         const uint32_t v = sh->ptr[j];
                         if (v != FP_RES) {
                             if (v < 32768u) {  // the source lies before the window: final
@@ -836,11 +843,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                                     sh->ptr[j] = (uint16_t)FP_RES;
                                 } else {
                                     sh->ptr[j] = (uint16_t)pv;  // the source's source
-                                    mine = true;
+                                    pend |= 1u << kb;
                                 }
                             }
                         }
                     }
+                    const bool mine = pend != 0;
                     FP_CNT(51, 1);
                     // round r's flag is read after this barrier by everyone and cleared two rounds later,
                     // before the barrier of round r + 2: every wave has read it by then
