@@ -519,8 +519,16 @@ __device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws
 }
 
 // inflate.zig:144-184.  flags bit0: reference-strict Q6 (two separate length lists).
+#ifdef FL_PAR_PROF
+#define FL_HDR_T(slot) do { const uint64_t n_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] += n_ - th_; th_ = n_; } while (0)
+#else
+#define FL_HDR_T(slot)
+#endif
 __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_inflate_ws* ws, int flags, uint32_t lane) {
     uint32_t v;
+#ifdef FL_PAR_PROF
+    uint64_t th_ = __builtin_readcyclecounter();
+#endif
     FL_TRY(fl_br_read(r, 5, v));
     const uint32_t hlit = v + 257;
     FL_TRY(fl_br_read(r, 5, v));
@@ -537,12 +545,14 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
         if (lane == 0) ws->cl_lens[fl_codegen_order(i)] = (uint8_t)v;
     }
     fl_wave_lds_sync();
+    FL_HDR_T(20);
     FL_TRY(fl_hdec_generate(&ws->cl, ws->cl_lens, ws->offs, 19, 19, 7, lane));
     for (uint32_t i = lane; i < 128; i += 64) {  // every 7-bit window decoded once, by the same walk
         uint32_t sy, cb;
         ws->cl_lut[i] = fl_hdec_find(&ws->cl, i, 7, sy, cb) == 0 ? (uint16_t)(sy | (cb << 8) | 0x8000u) : (uint16_t)0;
     }
     fl_wave_lds_sync();
+    FL_HDR_T(21);
     bool crossed = false;
     int rc;
     if (flags & 1) {
@@ -559,6 +569,7 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
     rc = fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane);
     if (rc) return crossed ? 14 : rc;
     fl_wave_lds_sync();
+    FL_HDR_T(22);
     // split the single list: the literal decoder must see zeros in [hlit, 286)
     uint8_t dl = 0;
     if (lane < 30) dl = lane < hdist ? ws->lens[hlit + lane] : 0;
@@ -571,8 +582,10 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
     if (rc) return crossed ? 14 : rc;
     rc = fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane);
     if (rc) return crossed ? 14 : rc;
+    FL_HDR_T(23);
     fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
     fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+    FL_HDR_T(24);
     return 0;
 }
 

@@ -48,6 +48,6 @@ if os.environ.get("FL_PAR_PROF"):
     tz = eng.phase_cycles().astype(np.int64)
     eng.decompress_many([only[0][2]], 0, 0, caps=[len(only[0][1]) + 64])
     t = eng.phase_cycles().astype(np.int64) - tz
-    for k, nm in {32: "loop top", 33: "block header", 34: "stage", 41: "decode (wave 0)", 35: "join + wait", 36: "stitch", 37: "layout", 38: "fill", 39: "resolve",
+    for k, nm in {20: "hdr: counts + precode lens", 21: "hdr: precode tables", 22: "hdr: code lengths", 23: "hdr: generate x2", 24: "hdr: luts", 32: "loop top", 33: "block header", 34: "stage", 41: "decode (wave 0)", 35: "join + wait", 36: "stitch", 37: "layout", 38: "fill", 39: "resolve",
                   40: "flush+update", 48: "# rounds", 49: "# valid waves", 50: "# out bytes", 51: "# resolve rounds", 52: "end normal", 53: "end eob", 54: "end bail", 55: "end full", 56: "end cut", 57: "nojoin", 61: "decode passes (wave 0)", 62: "... with a long lit code", 63: "... with a long dist code", 58: "nojoin: sum xkind", 59: "nojoin: sum xpos"}.items():
         print("%-16s %12d" % (nm, t[k]))
