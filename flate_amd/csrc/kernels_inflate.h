@@ -251,27 +251,47 @@ __device__ __forceinline__ int fl_hdec_find(const FL_LDS H* d, uint32_t peek, in
 template <bool DIST, class H>
 __device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS uint32_t* lut, int bits,
                                                   uint32_t lane) {
-    for (uint32_t i = lane; i < (1u << bits); i += 64) {
-        uint32_t sym, cb;
-        uint32_t e = 0;
-        if (fl_hdec_find(d, i, bits, sym, cb) == 0) {
-            uint32_t eb, val;
-            if (DIST) {
-                eb = sym <= 29 ? fl_dist_extra_bits(sym) : 15u;
-                val = sym <= 29 ? fl_dist_base_scaled(sym) + 1 : 0u;
-            } else if (sym < 256) {
-                eb = 0;
-                val = sym;
-            } else if (sym == 256) {
-                eb = 0;
-                val = 0;
-            } else {
-                eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
-                val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
+    // Every symbol with a code of at most `bits` bits writes the entries whose low bits are its code (first bit of the
+    // code = lowest bit of the index): a lane per symbol in (length, symbol) order, which is the order of the codes
+    // (huffman_decoder.zig:62-117).  What no code covers stays 0 (a longer code, or none: InvalidCode).
+    for (uint32_t i = lane; i < (1u << bits); i += 64) lut[i] = 0;
+    uint32_t cnt[16];
+    uint32_t upto = 0;  // symbols with a code of at most `bits` bits
+#pragma unroll
+    for (int len = 1; len < 16; len++) {
+        cnt[len] = d->count[len];
+        if (len <= bits) upto += cnt[len];
+    }
+    fl_wave_lds_sync();
+    for (uint32_t j = lane; j < upto; j += 64) {
+        uint32_t code = 0, idx = 0, my_len = 0, my_code = 0;
+#pragma unroll
+        for (int len = 1; len < 16; len++) {
+            if (j >= idx && j < idx + cnt[len]) {
+                my_len = (uint32_t)len;
+                my_code = code + (j - idx);
             }
-            e = sym | (cb << 9) | (eb << 13) | (val << 17);
+            code = (code + cnt[len]) << 1;
+            idx += cnt[len];
         }
-        lut[i] = e;
+        const uint32_t sym = d->symbol[j], cb = my_len;
+        uint32_t eb, val;
+        if (DIST) {
+            eb = sym <= 29 ? fl_dist_extra_bits(sym) : 15u;
+            val = sym <= 29 ? fl_dist_base_scaled(sym) + 1 : 0u;
+        } else if (sym < 256) {
+            eb = 0;
+            val = sym;
+        } else if (sym == 256) {
+            eb = 0;
+            val = 0;
+        } else {
+            eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
+            val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
+        }
+        const uint32_t e = sym | (cb << 9) | (eb << 13) | (val << 17);
+        const uint32_t rev = __brev(my_code) >> (32 - my_len);
+        for (uint32_t t = rev; t < (1u << bits); t += 1u << my_len) lut[t] = e;
     }
     fl_wave_lds_sync();
 }
