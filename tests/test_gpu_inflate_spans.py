@@ -140,6 +140,25 @@ def test_runs_of_stored_blocks_are_cut_at_stored_headers():
             assert "k_inflate_span" in prof and prof.get("k_inflate_par", (0.0, 0))[0] < 1.0, prof
 
 
+def test_a_pool_that_runs_out_leaves_the_stream_to_the_old_path(monkeypatch):
+    """More than 32 output bytes per compressed byte: run A's pool (sized by the compressed bytes) runs out, the spans
+    report it, the stream is decoded by k_inflate_par / k_inflate as before -- same bytes, same status."""
+    monkeypatch.setenv("FLATE_HIP_INFLATE_SPANS", "2000")
+    eng = engine()
+    rng = np.random.default_rng(23)
+    # long runs between short noisy stretches: about 300:1, several blocks
+    parts = []
+    for i in range(40):
+        parts.append(bytes([i & 255]) * 250_000)
+        parts.append(rng.integers(0, 256, 600, dtype=np.uint8).tobytes())
+    data = b"".join(parts)
+    for container, comp in ((2, pyzlib.compress(data, 6)), (1, O.compress(data, 1, 6))):
+        assert 2000 <= len(comp) * 32 < len(data)
+        (outs, st, used), prof = _kernels(eng, lambda: eng.decompress_many([comp], container, caps=[len(data)]))
+        assert st == [0] and used == [len(comp)] and outs[0] == data
+        assert "k_span_scan" in prof  # (the path was tried)
+
+
 def test_a_batch_of_long_and_short_streams():
     from flate_amd import synth
     eng = engine()
