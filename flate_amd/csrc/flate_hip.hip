@@ -91,7 +91,7 @@ struct flate_hip_ctx {
     size_t pin_in_cap = 0, pin_out_cap = 0;
     uint32_t n_cu = 0;  // of the device (spans)
     DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff,
-        sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part;  // inflate of long streams by spans
+        sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part, sp_footoff, sp_foot, sp_fin;  // inflate of long streams by spans
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
@@ -600,11 +600,24 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // a workgroup each: at most FL_SPAN_STREAMS of them (-DFL_SPAN_STREAMS: tuning)
     std::vector<uint32_t> elig;
     uint32_t n_long = 0;
-    for (uint32_t i = 0; i < n_chunks; i++) {
-        n_long += chunks[i].in_len >= 32768u ? 1u : 0u;
-        if (chunks[i].in_len >= min_bytes) elig.push_back(i);
+    for (uint32_t i = 0; i < n_chunks; i++) n_long += chunks[i].in_len >= 32768u ? 1u : 0u;
+    if (h->n_cu == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
+        h->n_cu = (uint32_t)v;
     }
-    if (elig.empty() || n_long > FL_SPAN_STREAMS || elig.size() > 256) return 0;
+    // More long streams than that, but fewer than CUs (config #5: 128 members on 256 CUs): every long stream is cut
+    // ONCE, where about f = 2 S / (CUs + S) of it lies before the cut, and both runs of the second spans go in one launch
+    // with the first spans (TWIN): the CUs the first spans leave free decode the second spans twice in the time the
+    // first spans take.  (Cut in two by the rule above, the second run would have half the chip to itself.)  A stream
+    // without a place to cut at is one span, decoded in place by run A: as before, but in the same launch.
+    const char* etw = getenv("FLATE_HIP_SPAN_TWIN");  // 0: never (tuning)
+    const bool twin = n_long > FL_SPAN_STREAMS && !(etw && atoi(etw) == 0) && (size_t)n_long * 5 <= (size_t)h->n_cu * 4;
+    if (n_long > FL_SPAN_STREAMS && !twin) return 0;
+    const uint64_t elig_bytes = twin ? std::min<uint64_t>(min_bytes, 32768u) : min_bytes;
+    for (uint32_t i = 0; i < n_chunks; i++)
+        if (chunks[i].in_len >= elig_bytes) elig.push_back(i);
+    if (elig.empty() || elig.size() > 256) return 0;
     int rc;
     // ---- where spans may start
     std::vector<fl_scan_point> points;
@@ -613,11 +626,6 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // a multiple of that for long inputs -- 313 spans on 256 CUs take as long as 499 (measured: 170 MiB of text as
     // 249 / 313 / 374 / 499 / 703 spans: 12.3 / 17.5 / 16.2 / 14.3 / 16.3 ms), and every span costs k_span_scan and
     // k_span_resolve a step.
-    if (h->n_cu == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
-        h->n_cu = (uint32_t)v;
-    }
     // What a span costs goes with the bytes it makes; a stream's share of the spans goes with the room its caller
     // gave it (exact for gzip members whose ISIZE was read; 32 bytes per compressed byte at most), a span has at
     // least FL_SPAN_BYTES / 4 compressed bytes.
@@ -629,10 +637,10 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     for (size_t k = 0; k < elig.size(); k++) {
         const fl_chunk& c = chunks[elig[k]];
         const uint64_t bits = (uint64_t)c.in_len * 8;
-        const uint32_t P = (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
+        const uint32_t P = twin ? 2u : (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
-            pt.from_bit = bits / P * j;
+            pt.from_bit = twin ? bits / 1000 * std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()))) : bits / P * j;
             pt.limit_bit = j + 1 < P ? bits / P * (j + 1) : bits;
             pt.stream = elig[k];
             pt.pad = 0;
@@ -690,7 +698,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (dbg) fprintf(stderr, "[spans] %zu streams, %u scan points, %u spans\n", elig.size(), npts, nsp);
     if (nsp == (uint32_t)elig.size()) return 0;  // nothing to cut
     if ((rc = ensure(h, h->sp_spans, sizeof(fl_span) * nsp))) return -1;
-    if ((rc = ensure(h, h->sp_res, sizeof(fl_span_res) * nsp))) return -1;
+    if ((rc = ensure(h, h->sp_res, sizeof(fl_span_res) * 2 * nsp))) return -1;
     if ((rc = ensure(h, h->sp_cand, sizeof(uint64_t) * (cand.size() + 1)))) return -1;
     if ((rc = ensure(h, h->sp_candoff, sizeof(uint32_t) * (n_chunks + 1)))) return -1;
     if ((rc = ensure(h, h->sp_tails, (size_t)FP_TAIL * nsp))) return -1;
@@ -704,14 +712,14 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     {
         uint64_t bytes = 0;
         for (uint32_t ci : elig) bytes += std::min<uint64_t>(chunks[ci].out_cap, 32ull * chunks[ci].in_len);
-        const uint64_t pieces = (bytes >> FP_PIECE_LOG) + 2ull * nsp + 1;
+        const uint64_t pieces = ((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1) * (twin ? 2 : 1);
         // (a pool the device cannot give -- callers who reserve the worst case for gigabytes of input: the old way)
         if (pieces * FP_PIECE > (16ull << 30)) return 0;
         if (ensure(h, h->sp_pool, (size_t)(pieces * FP_PIECE + 16))) {
             (void)hipGetLastError();  // (not this call's failure)
             return 0;
         }
-        if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp))) return -1;
+        if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp * 2))) return -1;
         if ((rc = ensure(h, h->sp_poolctl, 16))) return -1;
         if (hipMemsetAsync(h->sp_poolctl.p, 0, 16, st) != hipSuccess) return -1;
         pool.base = (uint8_t*)h->sp_pool.p;
@@ -723,12 +731,14 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // ---- run A
     {
         ProfScope ps(h, K_INFLATE_SPAN);
-        hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+        hipLaunchKernelGGL(k_inflate_span, dim3(twin ? 2 * nsp : nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                            (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u, pool);
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u, pool, twin ? nsp : 0u,
+                           (uint8_t*)h->sp_tails_b.p);
     }
     std::vector<fl_span_res> r1(nsp), r2(nsp);
     if (hipMemcpyAsync(r1.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (twin && hipMemcpyAsync(r2.data(), (const fl_span_res*)h->sp_res.p + nsp, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     // ---- the chain of every stream
     struct StreamPlan {
@@ -748,6 +758,9 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
             const fl_span_res& r = r1[cur];
             if (dbg && guard < 6) fprintf(stderr, "[spans] pass 1 span %u: start %llu status %u end %llu out %llu final %u\n", cur, (unsigned long long)spans[cur].start_bit, r.status, (unsigned long long)r.end_bit, (unsigned long long)r.out_len, r.final_seen);
             if (r.status != 0) { ok = false; break; }
+            // (run B of a twin launch does not know where its span starts: a distance that reaches before the start of
+            // the OUTPUT -- possible in the first 32 KiB only -- is the old path's to find)
+            if (twin && !spans[cur].first && r.uses_hist && acc < FP_TAIL) { ok = false; break; }
             spans[cur].live = 1;
             spans[cur].wp = acc;
             spans[cur].prev = pl.chain.empty() ? FP_NO_SPAN : pl.chain.back();
@@ -795,9 +808,9 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
                     it.span = si;
                     it.local = (uint32_t)o;
                     it.len = (uint32_t)std::min<uint64_t>(FP_PIECE, n - o);
-                    it.kind = spans[si].first ? 0u : uses_hist ? 2u : 1u;
+                    it.kind = spans[si].first ? 0u : uses_hist ? (twin ? 3u : 2u) : 1u;
                     it.prev = spans[si].prev;
-                    it.pad = 0;
+                    it.pad = twin ? nsp : 0u;
                     items.push_back(it);
                 }
             }
@@ -816,9 +829,10 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     {
         ProfScope ps(h, K_INFLATE_SPAN);
         if (uses_hist) {
-            hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
-                               (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                               (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool);
+            if (!twin)
+                hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+                                   (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
+                                   (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool, 0u, (uint8_t*)nullptr);
             hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
                                (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
         }
@@ -826,13 +840,32 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
             hipLaunchKernelGGL(k_span_fix, dim3(n_items), dim3(64), 0, st, (const fl_fix_item*)h->sp_items.p, pool,
                                (const uint8_t*)h->sp_tails.p, d_out, container, h->crc, (uint32_t*)h->sp_part.p);
     }
+    // the footers of the streams whose chain is whole (one small gather instead of a copy per stream)
+    const uint32_t flen = container == 1 ? 8u : container == 2 ? 4u : 0u;
+    const uint32_t nel = (uint32_t)elig.size();
+    std::vector<uint64_t> foot_off(nel, ~0ull);
+    std::vector<uint8_t> foot(8 * (size_t)nel, 0);
+    if (flen) {
+        for (size_t k = 0; k < elig.size(); k++) {
+            const fl_chunk& c = chunks[elig[k]];
+            const uint64_t fb = (plans[k].end_bit + 7) >> 3;
+            if (plans[k].ok && fb + flen <= c.in_len) foot_off[k] = c.in_off + fb;
+        }
+        if ((rc = ensure(h, h->sp_footoff, sizeof(uint64_t) * nel))) return -1;
+        if ((rc = ensure(h, h->sp_foot, 8 * (size_t)nel))) return -1;
+        if (hipMemcpyAsync(h->sp_footoff.p, foot_off.data(), sizeof(uint64_t) * nel, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_span_footers, dim3((nel + 63) / 64), dim3(64), 0, st, d_in, (const uint64_t*)h->sp_footoff.p, nel, flen,
+                           (uint8_t*)h->sp_foot.p);
+        if (hipMemcpyAsync(foot.data(), h->sp_foot.p, 8 * (size_t)nel, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    }
     std::vector<uint32_t> part(2 * (size_t)n_items);
-    if (uses_hist && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (uses_hist && !twin && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (n_items && hipMemcpyAsync(part.data(), h->sp_part.p, sizeof(uint32_t) * 2 * n_items, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     // ---- run B as run A, the checksum, the footer
     const uint32_t pow_piece = fl_crc_xpow8n(h->crc.xpow8, FP_PIECE);
     int done = 0;
+    std::vector<fl_span_fin> fin;
     for (size_t k = 0; k < elig.size(); k++) {
         StreamPlan& pl = plans[k];
         if (!pl.ok) continue;
@@ -857,11 +890,9 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
             }
         }
         const uint64_t fb = (pl.end_bit + 7) >> 3;
-        const uint32_t flen = container == 1 ? 8u : container == 2 ? 4u : 0u;
         if (ok && fb + flen > c.in_len) ok = false;  // truncated: the old way names it
         if (ok && flen) {
-            uint8_t f[8] = {0};
-            if (hipMemcpy(f, d_in + c.in_off + fb, flen, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            const uint8_t* f = &foot[8 * k];
             if (container == 1) {
                 const uint32_t fcrc = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
                 const uint32_t fsz = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
@@ -875,15 +906,21 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         }
         if (dbg) fprintf(stderr, "[spans] stream %u after k_span_fix: ok=%d crc %08x\n", elig[k], (int)ok, crc);
         if (!ok) continue;  // (the bytes written so far are written again by the kernels that follow)
-        const uint32_t ci = elig[k];
-        const int32_t zero = 0;
-        const uint64_t total = pl.total, used = fb + flen;
-        if (hipMemcpyAsync(d_status + ci, &zero, sizeof(zero), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-        if (hipMemcpyAsync(d_outlen + ci, &total, sizeof(total), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-        if (d_consumed && hipMemcpyAsync(d_consumed + ci, &used, sizeof(used), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-        if (hipStreamSynchronize(st) != hipSuccess) return -1;  // (the sources are on this stack)
+        fl_span_fin fi;
+        fi.total = pl.total;
+        fi.used = fb + flen;
+        fi.chunk = elig[k];
+        fi.pad = 0;
+        fin.push_back(fi);
         c.skip = 1;
         done++;
+    }
+    if (done) {
+        if ((rc = ensure(h, h->sp_fin, sizeof(fl_span_fin) * fin.size()))) return -1;
+        if (hipMemcpyAsync(h->sp_fin.p, fin.data(), sizeof(fl_span_fin) * fin.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_span_finish, dim3(((uint32_t)fin.size() + 63) / 64), dim3(64), 0, st, (const fl_span_fin*)h->sp_fin.p,
+                           (uint32_t)fin.size(), d_status, d_outlen, d_consumed);
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;  // (the source is on this stack)
     }
     return done;
 }
@@ -945,7 +982,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
                       &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff, &h->sp_pool, &h->sp_pooltab, &h->sp_poolctl, &h->sp_items,
-                      &h->sp_part})
+                      &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->cflag, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,

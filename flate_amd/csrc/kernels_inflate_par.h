@@ -299,19 +299,20 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                                         uint64_t* __restrict__ consumed, const fl_span* __restrict__ spans,
                                         fl_span_res* __restrict__ sres, const uint64_t* __restrict__ cand,
                                         const uint32_t* __restrict__ cand_off, uint8_t* __restrict__ tails, uint32_t fill,
-                                        fl_span_pool pool) {
+                                        fl_span_pool pool, uint32_t unit, bool b_pool) {
+    // unit: the stream (MODE 0) / the span (MODE 1); b_pool: run B at the same time as run A, its bytes to the pool as well
     __shared__ fp_shared sh_mem;
     FL_LDS fp_shared* sh = (FL_LDS fp_shared*)&sh_mem;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
     fl_span sp;
     sp.start_bit = 0;
     sp.wp = 0;
-    sp.stream = blockIdx.x;
+    sp.stream = unit;
     sp.first = 1;
     sp.prev = FP_NO_SPAN;
     sp.live = 1;
-    if (MODE != 0) sp = spans[blockIdx.x];
-    if (MODE == 1 && fill && (!sp.live || sp.first)) return;  // (run A finds out which spans are live; a first span's run A is final)
+    if (MODE != 0) sp = spans[unit];
+    if (MODE == 1 && fill && ((!b_pool && !sp.live) || sp.first)) return;  // (run A finds out which spans are live; a first span's run A is final)
     const uint32_t c = sp.stream;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
@@ -323,10 +324,10 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     const uint8_t* src = in + ck.in_off;
     uint8_t* dst = out + ck.out_off + sp.wp;  // (sh->wp counts from the span's first output byte)
     // run A of a span that does not know its place (sp.wp is 0 in run A, the host sets it before run B)
-    const bool to_pool = MODE == 1 && !fill && !sp.first;
+    const bool to_pool = MODE == 1 && (!fill || b_pool) && !sp.first;
     const uint64_t out_room = to_pool ? ~0ull : (ck.out_cap > sp.wp ? ck.out_cap - sp.wp : 0ull);
     // output bytes that exist before the span's first: a distance may reach that far back
-    const uint64_t hist_avail = MODE == 0 || sp.first ? 0ull : fill ? min((uint64_t)FP_TAIL, sp.wp) : (uint64_t)FP_TAIL;
+    const uint64_t hist_avail = MODE == 0 || sp.first ? 0ull : (fill && !b_pool) ? min((uint64_t)FP_TAIL, sp.wp) : (uint64_t)FP_TAIL;
     const uint64_t total_bits = (uint64_t)ck.in_len * 8;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
@@ -361,7 +362,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             if (n >= FP_MAX_PIECES) return false;
             const uint32_t id = atomicAdd(pool.next, 1u);
             if (id >= pool.pieces) return false;
-            pool.tab[(uint64_t)blockIdx.x * FP_MAX_PIECES + n] = id;
+            pool.tab[(uint64_t)unit * FP_MAX_PIECES + n] = id;
             sh->piece_id[n & 1u] = id;
             n++;
         }
@@ -888,7 +889,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             if (MODE == 0)
                 status[c] = FL_PAR_REDO;
             else
-                sres[blockIdx.x].status = 1;
+                sres[unit].status = 1;
         }
         return;
     }
@@ -898,10 +899,10 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     if (MODE != 0) {
         // the span's tail: the last 32 KiB of the output up to its end (what was there before it included)
         const uint32_t wb = (uint32_t)(n_out % FP_RING);
-        uint8_t* tl = tails + (uint64_t)blockIdx.x * FP_TAIL;
+        uint8_t* tl = tails + (uint64_t)unit * FP_TAIL;
         for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) tl[i] = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
         if (tid == 0) {
-            fl_span_res* rr = &sres[blockIdx.x];
+            fl_span_res* rr = &sres[unit];
             rr->end_bit = sh->bitpos;
             rr->out_len = n_out;
             rr->final_seen = final_seen ? 1u : 0u;
@@ -1353,7 +1354,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                                                                int32_t* __restrict__ status,
                                                                uint64_t* __restrict__ consumed) {
     fp_body<0>(in, chunks, container, flags, min_bytes, cc, out, out_len, status, consumed, nullptr, nullptr, nullptr,
-               nullptr, nullptr, 0u, fl_span_pool{nullptr, nullptr, nullptr, 0u, 0u});
+               nullptr, nullptr, 0u, fl_span_pool{nullptr, nullptr, nullptr, 0u, 0u}, blockIdx.x, false);
 }
 
 // One workgroup per span (see above); fill 0: run A, 1: run B.
@@ -1365,9 +1366,22 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
                                                                 const uint64_t* __restrict__ cand,
                                                                 const uint32_t* __restrict__ cand_off,
                                                                 uint8_t* __restrict__ tails, uint32_t fill,
-                                                                fl_span_pool pool) {
+                                                                fl_span_pool pool, uint32_t twin_nsp,
+                                                                uint8_t* __restrict__ tails_b) {
+    // twin_nsp != 0: both runs in one launch -- workgroups [0, twin_nsp) are run A of the spans, [twin_nsp, 2 twin_nsp)
+    // run B of the same spans, with its results, tails and pieces behind run A's
+    uint32_t unit = blockIdx.x;
+    bool b_pool = false;
+    if (twin_nsp && unit >= twin_nsp) {
+        unit -= twin_nsp;
+        fill = 1;
+        b_pool = true;
+        sres += twin_nsp;
+        tails = tails_b;
+        pool.tab += (uint64_t)twin_nsp * FP_MAX_PIECES;
+    }
     fp_body<1>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails, fill,
-               pool);
+               pool, unit, b_pool);
 }
 
 // The bytes of the live spans, 64 KiB (an ITEM) per wave, a lane per 1024 of them: moved from the pool to their place
@@ -1376,6 +1390,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
 //   kind 0  a first span: the bytes are in place and final
 //   kind 1  no span of the batch copies from before its start (run B was skipped): run A's bytes are final
 //   kind 2  run A's bytes in the pool, run B's in place
+//   kind 3  both in the pool (the runs were one launch: pad = the number of spans, run B's pieces follow run A's)
 struct __attribute__((aligned(4))) fl_u4a {  // four words at a word-aligned address
     uint32_t x[4];
 };
@@ -1412,12 +1427,14 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
     const uint32_t lo = min(it.len, lane * 1024u), hi = min(it.len, lane * 1024u + 1024u);
     uint8_t* D = out + it.dst;
     const uint8_t* A = it.kind ? pool.base + (uint64_t)pool.tab[(uint64_t)it.span * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE : D;
-    const uint8_t* T = it.kind == 2 ? tails + (uint64_t)it.prev * FP_TAIL : tails;
+    const uint8_t* T = it.kind >= 2 ? tails + (uint64_t)it.prev * FP_TAIL : tails;
+    // run B's bytes: in place, or in its pieces (which lie as run A's do: the same shift brings both to the output's words)
+    const uint8_t* Bp = it.kind == 3 ? pool.base + (uint64_t)pool.tab[(uint64_t)(it.pad + it.span) * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE : D;
     uint32_t c = 0xffffffffu, adA = 0, adB = 0;
     auto one = [&](uint32_t i) {  // byte i of the item
         uint32_t v = A[i];
-        if (it.kind == 2) {
-            const uint32_t x = v ^ D[i];
+        if (it.kind >= 2) {
+            const uint32_t x = v ^ Bp[i];
             if (x) v = T[(((x - 1u) << 8) | v) & (FP_TAIL - 1u)];
         }
         if (it.kind) D[i] = (uint8_t)v;
@@ -1431,7 +1448,7 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
     // than the output has.)  A lane takes 128 bytes at a time: every cache line is requested once, not once per word.
     const uint32_t sa = (uint32_t)(((uintptr_t)(A + i)) & 3) * 8;
     auto word = [&](uint32_t v, uint32_t b) -> uint32_t {  // the true bytes of one word; into the checksum
-        if (it.kind == 2) {
+        if (it.kind >= 2) {
             const uint32_t x = v ^ b;
             if (x) {
 #pragma unroll
@@ -1454,10 +1471,16 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
     };
     for (; i + 128 <= hi; i += 128) {
         fl_u4a bq[8], aq[8];
-        uint32_t a8 = 0;
-        if (it.kind != 1)
+        uint32_t a8 = 0, b8 = 0;
+        if (it.kind == 3) {
+            const fl_u4a* Bq = (const fl_u4a*)(((uintptr_t)(Bp + i)) & ~(uintptr_t)3);
+#pragma unroll
+            for (int q = 0; q < 8; q++) bq[q] = Bq[q];
+            if (sa) b8 = ((const uint32_t*)Bq)[32];
+        } else if (it.kind != 1) {
 #pragma unroll
             for (int q = 0; q < 8; q++) bq[q] = ((const fl_u4a*)(D + i))[q];
+        }
         if (it.kind) {
             const fl_u4a* Aq = (const fl_u4a*)(((uintptr_t)(A + i)) & ~(uintptr_t)3);
 #pragma unroll
@@ -1471,6 +1494,7 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
             for (int w = 0; w < 4; w++) {
                 uint32_t v, b = 0;
                 if (it.kind != 1) b = bq[q].x[w];
+                if (it.kind == 3 && sa) b = __builtin_amdgcn_alignbit(w < 3 ? bq[q].x[(w + 1) & 3] : q < 7 ? bq[(q + 1) & 7].x[0] : b8, b, sa);
                 if (it.kind) {
                     const uint32_t a0 = aq[q].x[w];
                     const uint32_t a1 = w < 3 ? aq[q].x[(w + 1) & 3] : q < 7 ? aq[(q + 1) & 7].x[0] : a8;
@@ -1485,7 +1509,12 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
     }
     for (; i + 4 <= hi; i += 4) {
         uint32_t v, b = 0;
-        if (it.kind != 1) b = *(const uint32_t*)(D + i);
+        if (it.kind == 3) {
+            const uint32_t* Bw = (const uint32_t*)(((uintptr_t)(Bp + i)) & ~(uintptr_t)3);
+            b = sa ? __builtin_amdgcn_alignbit(Bw[1], Bw[0], sa) : Bw[0];
+        } else if (it.kind != 1) {
+            b = *(const uint32_t*)(D + i);
+        }
         if (it.kind) {
             const uint32_t* Aw = (const uint32_t*)(((uintptr_t)(A + i)) & ~(uintptr_t)3);
             const uint32_t a0 = Aw[0], a1 = sa ? Aw[1] : 0u;
@@ -1515,6 +1544,29 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
         if (lane == 0) part[2 * (uint64_t)blockIdx.x] = Am | (Bs << 16);
     }
     if (lane == 0) part[2 * (uint64_t)blockIdx.x + 1] = it.len;
+}
+
+// The footers of the streams that came out of the spans (one thread each; off = ~0: none), and what the host found:
+// status 0, the length, the consumed count.
+__global__ __launch_bounds__(64) void k_span_footers(const uint8_t* __restrict__ in, const uint64_t* __restrict__ off,
+                                                     uint32_t n, uint32_t flen, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n || off[i] == ~0ull) return;
+    for (uint32_t b = 0; b < flen; b++) out[8 * (uint64_t)i + b] = in[off[i] + b];
+}
+struct fl_span_fin {
+    uint64_t total, used;
+    uint32_t chunk, pad;
+};
+__global__ __launch_bounds__(64) void k_span_finish(const fl_span_fin* __restrict__ fin, uint32_t n,
+                                                    int32_t* __restrict__ status, uint64_t* __restrict__ out_len,
+                                                    uint64_t* __restrict__ consumed) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const fl_span_fin f = fin[i];
+    status[f.chunk] = 0;
+    out_len[f.chunk] = f.total;
+    if (consumed) consumed[f.chunk] = f.used;
 }
 
 // The true tails of a stream's spans, in chain order (one workgroup per stream; see above).  tails_a is resolved in

@@ -159,6 +159,50 @@ def test_a_pool_that_runs_out_leaves_the_stream_to_the_old_path(monkeypatch):
         assert "k_span_scan" in prof  # (the path was tried)
 
 
+@pytest.mark.parametrize("container", [0, 1, 2])
+def test_more_long_streams_than_the_first_rule_takes_are_cut_once_each(container, monkeypatch):
+    """33 to about 200 long streams (config #5's shape): every stream is cut once and both runs of the second spans go
+    in one launch with the first spans (run B's bytes in the pool as well: k_span_fix kind 3); damaged streams among
+    them come out of the old path with the reference's names."""
+    from flate_amd import synth
+    monkeypatch.setenv("FLATE_HIP_INFLATE_SPANS", "60000")
+    eng = engine()
+    rng = np.random.default_rng(41 + container)
+    text = synth.text(synth.SEED_TEXT + 51, 6 << 20).tobytes()
+    sil = synth.silesia_like(synth.SEED_SILESIA + 51, 6 << 20).tobytes()
+    datas, streams = [], []
+    wb = {0: -15, 1: 31, 2: 15}[container]
+    for i in range(56):
+        src = text if i % 3 else sil
+        n = int(rng.integers(300_000, 700_000))
+        o = int(rng.integers(0, len(src) - n))
+        d = src[o:o + n]
+        if i % 4 == 0:
+            c = O.compress(d, container, [6, 9, O.HUFFMAN, 4][(i // 4) % 4])
+        else:
+            co = pyzlib.compressobj(int(rng.integers(1, 10)), pyzlib.DEFLATED, wb)
+            c = co.compress(d) + co.flush()
+        datas.append(d)
+        streams.append(c)
+    assert 32 < sum(len(c) >= 32768 for c in streams) <= 200  # (more than 32: the twin launch)
+    (outs, st, used), prof = _kernels(eng, lambda: eng.decompress_many(streams, container, caps=[len(d) for d in datas]))
+    assert st == [0] * len(streams) and outs == datas and used == [len(c) for c in streams]
+    assert "k_inflate_span" in prof, prof
+    # the same batch with damage: a flipped bit, a truncation, a slot too small, two members back to back
+    bad = list(streams)
+    caps = [len(d) + 8 for d in datas]
+    m = bytearray(bad[5]); m[len(m) // 3] ^= 0x10; bad[5] = bytes(m)
+    bad[9] = bad[9][:len(bad[9]) // 2]
+    caps[13] = (len(datas[13]) // 8) * 8 - 8
+    bad[17] = bad[17] + bad[18]
+    outs, st, used = eng.decompress_many(bad, container, caps=caps)
+    for i, (b, cap) in enumerate(zip(bad, caps)):
+        name, want, wused = O.decompress(b, container, 0, cap=(cap + 7) & ~7)
+        assert O.STATUS[st[i]] == name, (i, O.STATUS[st[i]], name)
+        if name == "Ok":
+            assert outs[i] == want and used[i] == wused, i
+
+
 def test_a_batch_of_long_and_short_streams():
     from flate_amd import synth
     eng = engine()

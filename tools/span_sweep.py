@@ -3,7 +3,8 @@
 stretches (text, noise, runs, records), from zlib at random levels / strategies and from the library's own compressor;
 decoded with the span path on at a random lower bound and with it off: both must agree in status, bytes and consumed
 count -- for damaged streams as well -- and undamaged ones must give the input back.
-usage: python tools/span_sweep.py [seed=1] [rounds=20] [big]   (big: stretches of up to 8 MiB instead of 1 MiB)"""
+usage: python tools/span_sweep.py [seed=1] [rounds=20] [big|many]   (big: stretches of up to 8 MiB instead of 1 MiB;
+many: batches of 34-70 streams -- every stream cut once, both runs in one launch)"""
 import os, sys, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +12,8 @@ from flate_amd import Engine, synth
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-big = len(sys.argv) > 3
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+many = len(sys.argv) > 3 and sys.argv[3] == "many"
 rng = np.random.default_rng(seed)
 eng = Engine(0)
 text = synth.text(synth.SEED_TEXT + seed, 8 << 20).tobytes()
@@ -36,7 +38,7 @@ def stretch():
 
 
 def make():
-    data = b"".join(stretch() for _ in range(int(rng.integers(1, 12))))
+    data = b"".join(stretch() for _ in range(int(rng.integers(1, 5 if many else 12))))
     container = int(rng.integers(0, 3))
     if rng.random() < 0.5:
         wb = {0: -15, 1: 31, 2: 15}[container]
@@ -58,7 +60,8 @@ bad = 0
 for rd in range(rounds):
     container = None
     batch = []
-    while len(batch) < int(rng.integers(1, 7)):
+    want_n = int(rng.integers(34, 71)) if many else int(rng.integers(1, 7))
+    while len(batch) < want_n:
         d, c, k = make()
         if container is None:
             container = k
@@ -89,5 +92,5 @@ for rd in range(rounds):
         if not (same and right):
             bad += 1
             print("MISMATCH round %d stream %d bound %s container %d: status %d / %d, %d bytes in" % (rd, i, bound, container, got[1][i], ref[1][i], len(streams[i])))
-    print("round %d: %d streams (%s bytes), bound %s, statuses %s" % (rd, len(streams), [len(s) for s in streams], bound, got[1]), flush=True)
+    print("round %d: %d streams (%s bytes), bound %s, statuses %s" % (rd, len(streams), [len(s) for s in streams][:8], bound, got[1][:16]), flush=True)
 print("mismatches", bad)
