@@ -610,9 +610,11 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // ONCE, where about f = 2 S / (CUs + S) of it lies before the cut, and both runs of the second spans go in one launch
     // with the first spans (TWIN): the CUs the first spans leave free decode the second spans twice in the time the
     // first spans take.  (Cut in two by the rule above, the second run would have half the chip to itself.)  A stream
-    // without a place to cut at is one span, decoded in place by run A: as before, but in the same launch.
-    const char* etw = getenv("FLATE_HIP_SPAN_TWIN");  // 0: never (tuning)
-    const bool twin = n_long > FL_SPAN_STREAMS && !(etw && atoi(etw) == 0) && (size_t)n_long * 5 <= (size_t)h->n_cu * 4;
+    // without a place to cut at is one span, decoded in place by run A: as before, but in the same launch.  Config #5,
+    // cut at 56 / 62 / 66.6 / 72 / 78 % of the compressed bytes: 11.7 / 7.9 / 6.3 / 6.9 / 7.1 ms -- second spans that
+    // are too long cost more than first spans that are: 1.5 % are added to f.
+    const char* etw = getenv("FLATE_HIP_SPAN_TWIN");  // 0: never; 2..950: where to cut, in thousandths of the stream (tuning)
+    const bool twin = n_long > FL_SPAN_STREAMS && !(etw && atoi(etw) == 0) && (size_t)n_long * 20 <= (size_t)h->n_cu * 11;  // (40 / 64 / 96 / 160 / 200 one-MiB members: 7.9 / 7.9 / 13.0 / 13.0 / 13.0 ms a workgroup each, 6.1 / 6.1 / 9.1 / 13.3 / 13.4 this way)
     if (n_long > FL_SPAN_STREAMS && !twin) return 0;
     const uint64_t elig_bytes = twin ? std::min<uint64_t>(min_bytes, 32768u) : min_bytes;
     for (uint32_t i = 0; i < n_chunks; i++)
@@ -640,7 +642,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         const uint32_t P = twin ? 2u : (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
-            pt.from_bit = twin ? bits / 1000 * std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()))) : bits / P * j;
+            pt.from_bit = twin ? bits / 1000 * ((etw && atoi(etw) > 1) ? (uint64_t)std::min(950, atoi(etw)) : std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()) + 15))) : bits / P * j;
             pt.limit_bit = j + 1 < P ? bits / P * (j + 1) : bits;
             pt.stream = elig[k];
             pt.pad = 0;

@@ -161,7 +161,7 @@ def test_a_pool_that_runs_out_leaves_the_stream_to_the_old_path(monkeypatch):
 
 @pytest.mark.parametrize("container", [0, 1, 2])
 def test_more_long_streams_than_the_first_rule_takes_are_cut_once_each(container, monkeypatch):
-    """33 to about 200 long streams (config #5's shape): every stream is cut once and both runs of the second spans go
+    """33 to about 140 long streams (config #5's shape): every stream is cut once and both runs of the second spans go
     in one launch with the first spans (run B's bytes in the pool as well: k_span_fix kind 3); damaged streams among
     them come out of the old path with the reference's names."""
     from flate_amd import synth
@@ -184,7 +184,7 @@ def test_more_long_streams_than_the_first_rule_takes_are_cut_once_each(container
             c = co.compress(d) + co.flush()
         datas.append(d)
         streams.append(c)
-    assert 32 < sum(len(c) >= 32768 for c in streams) <= 200  # (more than 32: the twin launch)
+    assert 32 < sum(len(c) >= 32768 for c in streams) <= 140  # (more than 32, at most 0.55 x the CUs: the twin launch)
     (outs, st, used), prof = _kernels(eng, lambda: eng.decompress_many(streams, container, caps=[len(d) for d in datas]))
     assert st == [0] * len(streams) and outs == datas and used == [len(c) for c in streams]
     assert "k_inflate_span" in prof, prof
