@@ -73,6 +73,7 @@
 #define FP_OUT_CAP 16384u                        // output bytes per round
 #define FP_RING (32768u + FP_OUT_CAP)            // history + window
 #define FP_RES 0xffffu                           // ptr value: byte is final
+#define FP_DST_BITS 10                           // bits of the distance table
 #define FP_NOJOIN 0xffffu
 #define FP_JTERM 0x8000u
 
@@ -98,6 +99,7 @@ struct fp_shared {
     uint16_t fixpos[FP_WAVES][FP_MAX_FIX];
     uint8_t ring[FP_RING];
     uint16_t ptr[FP_OUT_CAP];
+    uint32_t dst_big[1u << FP_DST_BITS];  // this kernel's distance table (k_inflate's has 8 bits: one pass in six met a longer code)
     // per wave
     uint32_t w_ntok[FP_WAVES], w_xkind[FP_WAVES], w_xpos[FP_WAVES];
     uint32_t w_valid[FP_WAVES], w_entry[FP_WAVES], w_fv[FP_WAVES], w_nfix[FP_WAVES], w_nown[FP_WAVES];
@@ -165,7 +167,8 @@ __device__ __forceinline__ uint32_t fp_dst_entry(uint32_t sym, uint32_t cb) {
     return cb | (fl_dist_extra_bits(sym) << 4) | ((fl_dist_base_scaled(sym) + 1) << 8);
 }
 // k_inflate's entry (symbol | code_bits << 9 | ...) -> this kernel's
-__device__ __noinline__ void fp_convert_luts(FL_LDS fl_inflate_ws* ws, uint32_t lane) {
+__device__ __noinline__ void fp_convert_luts(FL_LDS fl_inflate_ws* ws, FL_LDS uint32_t* big, uint32_t lane) {
+    fl_hdec_build_lut<true>(&ws->dst, big, FP_DST_BITS, lane);  // (k_inflate's entries, FP_DST_BITS of them)
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (uint32_t i = lane; i < (1u << FL_INF_LIT_BITS); i += 64) {
         const uint32_t e = ws->lit_lut[i];
@@ -174,11 +177,11 @@ __device__ __noinline__ void fp_convert_luts(FL_LDS fl_inflate_ws* ws, uint32_t 
         ws->lit_lut[i] = v;
     }
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (uint32_t i = lane; i < (1u << FL_INF_DST_BITS); i += 64) {
-        const uint32_t e = ws->dst_lut[i];
+    for (uint32_t i = lane; i < (1u << FP_DST_BITS); i += 64) {
+        const uint32_t e = big[i];
         uint32_t v = 0;
         if (e != 0) v = fp_dst_entry(e & 511, (e >> 9) & 15);
-        ws->dst_lut[i] = v;
+        big[i] = v;
     }
     fl_wave_lds_sync();
 }
@@ -202,13 +205,13 @@ __device__ __forceinline__ void fp_decode_at(const FL_LDS fp_shared* sh, uint32_
     const uint32_t length = val + ((lo >> cb) & ((1u << eb) - 1u));
     const uint32_t lb = cb + eb;  // <= 20
     const uint32_t dw = lb ? ((lo >> lb) | (hi << (32 - lb))) : lo;  // lb <= 20
-    uint32_t de = ws->dst_lut[dw & ((1u << FL_INF_DST_BITS) - 1)];
+    uint32_t de = sh->dst_big[dw & ((1u << FP_DST_BITS) - 1)];
     const bool is_len = (le >> 31) != 0;
     if (__any(is_len && de == 0)) {
         FP_CNT(63, 1);
         if (is_len && de == 0) {
             uint32_t dsym, dcb;
-            de = fp_find_long<FL_INF_DST_BITS>(&ws->dst, &sh->dst_long, dw & 0x7fffu, dsym, dcb) ? FP_E_BAD : fp_dst_entry(dsym, dcb);
+            de = fp_find_long<FP_DST_BITS>(&ws->dst, &sh->dst_long, dw & 0x7fffu, dsym, dcb) ? FP_E_BAD : fp_dst_entry(dsym, dcb);
         }
     }
     const uint32_t dcb = de & 15, deb = (de >> 4) & 15, dval = (de >> 8) & 0xffff;
@@ -446,7 +449,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 if (!rc) {
                     fp_long_build(&ws->lit, &sh->lit_long, lane);
                     fp_long_build(&ws->dst, &sh->dst_long, lane);
-                    fp_convert_luts(ws, lane);
+                    fp_convert_luts(ws, (FL_LDS uint32_t*)sh->dst_big, lane);
                 }
             } else if (!rc && btype == 1) {
                 // fixed codes (RFC 1951 3.2.6, inflate.zig:104-121) through the same tables: lengths 8/9/7/8
@@ -462,7 +465,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                     fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
                     fp_long_build(&ws->lit, &sh->lit_long, lane);
                     fp_long_build(&ws->dst, &sh->dst_long, lane);
-                    fp_convert_luts(ws, lane);
+                    fp_convert_luts(ws, (FL_LDS uint32_t*)sh->dst_big, lane);
                 }
             } else if (!rc && btype == 0) {
                 fl_br_align(r);
