@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 #include <thread>
 #include <functional>
@@ -596,6 +597,8 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     const uint64_t min_bytes = e ? (uint64_t)atoll(e) : FL_SPAN_MIN_BYTES;
     if (!min_bytes || (flags & 1)) return 0;
     const bool dbg = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     // Worth it (every span is decoded twice) when the long streams of the batch are too few to fill the chip with
     // a workgroup each: at most FL_SPAN_STREAMS of them (-DFL_SPAN_STREAMS: tuning)
     std::vector<uint32_t> elig;
@@ -663,6 +666,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     std::vector<uint64_t> found(npts);
     if (hipMemcpyAsync(found.data(), h->sp_found.p, sizeof(uint64_t) * npts, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 1 done\n", since());
     // ---- the spans: the stream start, then every distinct position found
     std::vector<fl_span> spans;
     std::vector<uint64_t> cand;
@@ -742,6 +746,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (hipMemcpyAsync(r1.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (twin && hipMemcpyAsync(r2.data(), (const fl_span_res*)h->sp_res.p + nsp, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 2 done\n", since());
     // ---- the chain of every stream
     struct StreamPlan {
         bool ok = false;
@@ -864,6 +869,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (uses_hist && !twin && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (n_items && hipMemcpyAsync(part.data(), h->sp_part.p, sizeof(uint32_t) * 2 * n_items, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 3 done\n", since());
     // ---- run B as run A, the checksum, the footer
     const uint32_t pow_piece = fl_crc_xpow8n(h->crc.xpow8, FP_PIECE);
     int done = 0;
@@ -924,6 +930,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
                            (uint32_t)fin.size(), d_status, d_outlen, d_consumed);
         if (hipStreamSynchronize(st) != hipSuccess) return -1;  // (the source is on this stack)
     }
+    if (dbg) fprintf(stderr, "[spans] %.3f ms: return\n", since());
     return done;
 }
 
