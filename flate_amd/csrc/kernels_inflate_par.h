@@ -1103,47 +1103,32 @@ __device__ bool fp_scan_header_lane(const FL_LDS uint32_t* stage, uint32_t rel0,
     }
     uint32_t kl = 0, kd = 0, nd = 0, prev = 0, eob = 0;  // Kraft sums (in units of 2^-15), distance codes, last length
     uint32_t i = 0;
-    uint32_t have = 0;
-    b = 0;
+    // One symbol per turn, without branches on the symbol (the lanes of a wave are at different symbols: every branch
+    // taken by one lane is paid by all; with them a turn cost 850 cycles, most of step 2 of the scan).
     while (i < ntot) {
-        if (have < 16) {
-            if (pos >= total_bits || rel0 + (uint32_t)(pos - bit) > rel_end) return false;  // (beyond the stage: given up)
-            b = bits_at(pos);
-            have = 64;
-        }
+        if (pos >= total_bits || rel0 + (uint32_t)(pos - bit) > rel_end) return false;  // (beyond the stage: given up)
+        b = bits_at(pos);
         const uint32_t e = tab[(uint32_t)b & 127u];
         const uint32_t used = e & 7, sym = e >> 3;
         if (!used) return false;
-        b >>= used;
-        have -= used;
-        pos += used;
-        uint32_t rep = 1, len = sym;
-        if (sym == 16) {
-            if (i == 0) return false;
-            rep = 3 + ((uint32_t)b & 3);
-            len = prev;
-            b >>= 2; have -= 2; pos += 2;
-        } else if (sym == 17) {
-            rep = 3 + ((uint32_t)b & 7);
-            len = 0;
-            b >>= 3; have -= 3; pos += 3;
-        } else if (sym == 18) {
-            rep = 11 + ((uint32_t)b & 127);
-            len = 0;
-            b >>= 7; have -= 7; pos += 7;
-        }
+        const bool is16 = sym == 16, is17 = sym == 17, is18 = sym == 18;
+        const uint32_t xb = is16 ? 2u : is17 ? 3u : is18 ? 7u : 0u;
+        const uint32_t xv = ((uint32_t)(b >> used)) & ((1u << xb) - 1u);
+        const uint32_t rep = is18 ? 11u + xv : (is16 || is17) ? 3u + xv : 1u;
+        const uint32_t len = sym < 16 ? sym : is16 ? prev : 0u;
+        if (is16 && i == 0) return false;
+        pos += used + xb;
         if (i + rep > ntot) return false;
-        if (len) {
-            // (a run may cross from the literal / length lengths into the distance lengths)
-            const uint32_t nl = i < nlit ? min(rep, nlit - i) : 0u;
-            kl += nl * (32768u >> len);
-            kd += (rep - nl) * (32768u >> len);
-            nd += rep - nl;
-            if (i <= 256 && i + rep > 256) eob = 1;
-            // (an oversubscribed code cannot become complete again: what is not a header is given up here, after a few
-            // dozen symbols, long before its lengths have all been decoded)
-            if (kl > 32768u || kd > 32768u) return false;
-        }
+        // (a run may cross from the literal / length lengths into the distance lengths)
+        const uint32_t nl = i < nlit ? min(rep, nlit - i) : 0u;
+        const uint32_t w = len ? (32768u >> len) : 0u;
+        kl += nl * w;
+        kd += (rep - nl) * w;
+        nd += len ? rep - nl : 0u;
+        eob |= (len && i <= 256 && i + rep > 256) ? 1u : 0u;
+        // (an oversubscribed code cannot become complete again: what is not a header is given up here, after a few
+        // dozen symbols, long before its lengths have all been decoded)
+        if (kl > 32768u || kd > 32768u) return false;
         prev = len;
         i += rep;
     }
