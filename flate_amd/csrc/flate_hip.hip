@@ -23,6 +23,7 @@
 #include "kernels_inflate_par.h"
 #include "kernels_lz.h"
 #include "kernels_parse.h"
+#include "kernels_walk.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -36,6 +37,8 @@ enum KernelId {
     K_LZ_MATCH,
     K_LZ_CHAIN,
     K_LZ_PARSE,
+    K_LZ_LINKS,
+    K_LZ_WALK,
     K_LZ_EMIT,
     K_LZ_TOK,
     K_ST_PARSE,
@@ -51,7 +54,7 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_chain", "k_lz_parse", "k_lz_emit",
+                                           "k_lz_chain", "k_lz_parse", "k_lz_links", "k_lz_walk", "k_lz_emit",
                                            "k_lz_tok", "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_span_scan", "k_inflate_span",
                                            "k_gather"};
@@ -86,7 +89,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links;
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -448,6 +451,7 @@ int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind
 int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
     int rc;
     const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
+#ifdef FL_OLD_TOKENIZER
     if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;      // chain links / sorted positions
     if (chain >= FL_BULK_MIN_CHAIN) {
         if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
@@ -456,6 +460,12 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
         if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
         if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
     }
+#else
+    (void)chain;
+    if ((rc = ensure(h, h->links, per * 4 * sizeof(uint16_t)))) return rc;  // per chunk [L4 | L6 | L8 | RK] (kernels_walk.h)
+    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;       // anchor descriptors
+    if ((rc = ensure(h, h->marks, per / 8))) return rc;                     // true anchors, one bit per position
+#endif
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
     if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nc))) return rc;
@@ -520,6 +530,35 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     }
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
+#ifndef FL_OLD_TOKENIZER
+        {
+            // levels 4..9: the reference's chain and two sparser ones, the reference's automaton per segment over them,
+            // tokens (kernels_walk.h, kernels_parse.h)
+            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));
+            {
+                ProfScope ps(h, K_LZ_LINKS);
+                hipLaunchKernelGGL(k_lz_links<0>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->links.p,
+                                   (uint32_t*)h->cflag.p);
+                hipLaunchKernelGGL(k_lz_links<1>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->links.p,
+                                   (uint32_t*)h->cflag.p);
+                hipLaunchKernelGGL(k_lz_links<2>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->links.p,
+                                   (uint32_t*)h->cflag.p);
+                hipLaunchKernelGGL(k_lz_links<3>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->links.p,
+                                   (uint32_t*)h->cflag.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_WALK);
+                hipLaunchKernelGGL(k_lz_walk, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+            }
+            {
+                ProfScope ps(h, K_LZ_EMIT);
+                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
+                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
+                                   dpl, (uint32_t*)h->ntok.p);
+            }
+        }
+#else
         if (prm.chain >= FL_BULK_MIN_CHAIN) {
             // levels 8 and 9 (chains of 1024 / 4096 candidates): the match finder that evaluates every position in
             // hash order, 64 positions of a bucket at a time (kernels_lz.h) -- a lane walking 4096 links on its
@@ -567,6 +606,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                                    dpl, (uint32_t*)h->ntok.p);
             }
         }
+#endif
         h->dbg_pass_chunks = nc;
         h->dbg_first_chunk = c0;
         h->dbg_pos_off.resize(nc);
@@ -994,7 +1034,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})

@@ -1,0 +1,624 @@
+// kernels_walk.h -- the LZ77 match finder + lazy-matching automaton of the chunk path (levels 4..9, inputs of at most
+// 65535 bytes), round 4: SPARSE CHAINS.
+//
+// The reference's findMatch (deflate.zig:233-266) walks the chain of the positions that share a 15-bit hash of four
+// bytes with p, nearest first, at most `chain` of them, and keeps a candidate only if it is LONGER than the match in
+// hand.  On text 95 % of its steps happen with a match of 4 bytes or more in hand and 99 % of those candidates fail the
+// reference's one-compare reject (SlidingWindow.zig:91-98): measured 5.1 steps per input byte at level 6, 14 at level 9.
+// A candidate that can still change the result agrees with p on MORE bytes than the match in hand.  So with a match of
+// `len` bytes in hand the walk may follow any chain that holds every earlier position agreeing with p on len + 1
+// bytes, in the same (descending) order -- the result is the same, candidate for candidate:
+//
+//   len < 5        the reference's chain                     L4   (k_lz_links<0>: Lookup.zig:23-51)
+//   len 5 or 6     positions with the same hash of 6 bytes   L6   (k_lz_links<2>)
+//   len >= 7       positions with the same hash of 8 bytes   L8   (k_lz_links<3>)
+//
+// What the reference counts down per candidate (`chain`, a quarter of it from `good` on: deflate.zig:241-245) is
+// counted as before while the walk is on L4; on L6 / L8 it is checked per ACCEPTED candidate with
+// RK[p] = number of earlier positions in p's L4 bucket (k_lz_links<1>): candidate q of p is the (RK[p] - RK[q])-th of
+// the reference's walk, and the first one beyond the budget ends the call (everything behind it is farther still).
+// Steps per input byte on the benchmark text: 5.1 -> 1.2 at level 6, 14.4 -> 1.4 at level 9; CPU model with the same
+// walk, checked token for token against the oracle: tools/multilevel_model.c.
+//
+//   k_lz_links<W>  one hash table in LDS per launch (as k_lz_chain: DS_MSKOR_RTN exchange of the bucket's head, or
+//                  DS_ADD_RTN for the count), 16-bit links to global memory.
+//   k_lz_walk      one workgroup per chunk, the whole chunk's bytes in LDS (66 KiB: two workgroups per CU), one LANE per
+//                  64-byte segment running the reference's automaton speculatively, stitched as in round 3
+//                  (kernels_parse.h).  The links stay in global memory (L2): a step is a 2-byte gather -- measured 0.7-1.5
+//                  cycles per lane and CU (tools/ubench/gather.hip), a sixth of the steps of round 3.
+//
+// No MFMA: pointer hops and byte compares.
+#pragma once
+#include "kernels_parse.h"
+
+// hashes of the upper levels (any function would do: the chains only have to CONTAIN what matches)
+__device__ __forceinline__ uint32_t fl_hash6(uint32_t w0, uint32_t w1) {
+    return ((w0 * 0x9E3779B1u) ^ ((w1 & 0xffffu) * 0x85EBCA6Bu)) >> 17;
+}
+__device__ __forceinline__ uint32_t fl_hash8(uint32_t w0, uint32_t w1) {
+    return ((w0 * 0x9E3779B1u) ^ (w1 * 0x85EBCA6Bu)) >> 17;
+}
+
+__device__ __forceinline__ uint32_t fl_lds_add_rtn(uint32_t* lds_word, uint32_t value) {
+    uint32_t old;
+    fl_lds_u32* a = (fl_lds_u32*)lds_word;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(old) : "v"(a), "v"(value) : "memory");
+    return old;
+}
+
+// ------------------------------------------------------------------ k_lz_links
+// WHICH 0: L4 (the reference's chain; also recognises a chunk of one repeated byte: cflag), 1: RK, 2: L6, 3: L8.
+// Same structure as k_lz_chain (kernels_parse.h): FL_CHAIN_WAVES waves prepare a block of 1024 positions each and
+// take turns with the table, so that it sees the positions in ascending order; a lane that was overtaken (a head
+// above its own position, a count that is not the number of earlier bucket members) sends the chunk to the
+// one-position-at-a-time path.
+template <int WHICH>
+__global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t* __restrict__ in,
+                                                                   const fl_chunk* __restrict__ chunks,
+                                                                   uint16_t* __restrict__ out_all,
+                                                                   uint32_t* __restrict__ cflag) {
+    __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
+    __shared__ uint32_t stg_all[FL_CHAIN_WAVES][FL_CHAIN_STG_DW];
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* sb = stg_all[wave];
+    const uint32_t N = ck.in_len;
+    const uint32_t Mpos = N >= 4 ? N - 3 : 0u;  // positions with 4 bytes left (Lookup.zig:24)
+    if (WHICH == 0 && threadIdx.x == 0) cflag[c] = 0u;
+    if (Mpos == 0) return;
+    const uint8_t* src = in + ck.in_off;
+    // a chunk's four arrays are one block of 4 x 65536 entries: [L4 | L6 | L8 | RK]
+    uint16_t* pv = out_all + (uint64_t)c * (4u * FL_CHUNK_STRIDE) + (WHICH == 0 ? 0u : WHICH == 1 ? 3u : WHICH == 2 ? 1u : 2u) * FL_CHUNK_STRIDE;
+    const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
+    const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
+    const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
+    if (WHICH == 0) {
+        // A chunk of ONE repeated byte needs no chains: k_lz_walk writes its anchors directly.
+        if (N >= 64) {
+            const uint32_t b0 = src[0] * 0x01010101u;
+            bool same = true;
+            for (uint32_t g0 = 0; g0 < n_gran; g0 += 64 * FL_CHAIN_WAVES) {
+                const uint32_t g = g0 + threadIdx.x;
+                if (g < n_gran) {
+                    uint4 v = src16[g];
+                    const int32_t first = (int32_t)(16 * g) - (int32_t)sh;  // chunk offset of the granule's byte 0
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t m = 0;
+#pragma unroll
+                        for (int bb = 0; bb < 4; bb++) {
+                            const int32_t o = first + 4 * k + bb;
+                            if (o >= 0 && o < (int32_t)N) m |= 0xffu << (8 * bb);
+                        }
+                        same = same && ((w[k] ^ b0) & m) == 0;
+                    }
+                }
+                if (__syncthreads_or(same ? 0 : 1)) {
+                    same = false;
+                    break;
+                }
+            }
+            if (same) {  // (the same verdict in every thread)
+                if (threadIdx.x == 0) cflag[c] = 1u;
+                return;
+            }
+        }
+    } else {
+        if (cflag[c] == 1u) return;  // (written by the <0> launch before this one on the stream)
+    }
+    {
+        uint4* h4 = (uint4*)head32;
+        for (uint32_t i = threadIdx.x; i < 4096; i += 64 * FL_CHAIN_WAVES) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs (7 bytes more for the 8-byte
+    // hash): granules 64 b .. 64 b + 65 (sh + 1023 + 7 < 1056 = 66 granules); lane l loads granule 64 b + l, lanes 0..1 two more
+    auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {
+        const uint32_t ga = 64 * b + lane, gb = 64 * b + 64 + lane;
+        g0 = ga < n_gran ? src16[ga] : make_uint4(0, 0, 0, 0);
+        g1 = (lane < 2 && gb < n_gran) ? src16[gb] : make_uint4(0, 0, 0, 0);
+    };
+    const uint32_t n_blocks = (Mpos + 1023) >> 10;
+    uint4 ga0, ga1;  // the wave's next block, in flight
+    load_block(wave, ga0, ga1);
+    bool overtaken = false;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += FL_CHAIN_WAVES) {  // (uniform trip count: every wave meets every barrier)
+        const uint32_t b = b0 + wave;
+        ((uint4*)sb)[lane] = ga0;
+        if (lane < 2) ((uint4*)sb)[64 + lane] = ga1;
+        if (b + FL_CHAIN_WAVES < n_blocks) load_block(b + FL_CHAIN_WAVES, ga0, ga1);
+        fl_lds_order();
+        uint32_t hw[16];   // word of the table, or the lane's dummy word for a position past the end
+        uint32_t odd = 0;  // bit s: the hash of step s is odd (its entry is the upper half of the word)
+        uint32_t val = 0;  // bit s: position of step s exists
+#pragma unroll
+        for (uint32_t s = 0; s < 16; s++) {
+            const uint32_t p = (b << 10) + (s << 6) + lane;
+            const uint32_t off = (s << 6) + lane + sh;
+            const uint32_t d0 = sb[off >> 2], d1 = sb[(off >> 2) + 1];
+            const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, off & 3);
+            uint32_t h;
+            if (WHICH <= 1) {
+                h = fl_hash_le(v);
+            } else {
+                const uint32_t d2 = sb[(off >> 2) + 2];
+                const uint32_t v1 = __builtin_amdgcn_alignbyte(d2, d1, off & 3);
+                h = WHICH == 2 ? fl_hash6(v, v1) : fl_hash8(v, v1);
+            }
+            const bool valid = p < Mpos;
+            odd |= (h & 1u) << s;
+            val |= (valid ? 1u : 0u) << s;
+            hw[s] = valid ? (h >> 1) : 16384u + lane;
+        }
+        uint32_t old[16];
+#pragma unroll 1
+        for (uint32_t t = 0; t < FL_CHAIN_WAVES; t++) {
+            if (t == wave) {
+                // all exchanges are issued before the first result is looked at (no branch around the instruction)
+#pragma unroll
+                for (uint32_t s = 0; s < 16; s++) {
+                    const uint32_t p = (b << 10) + (s << 6) + lane;
+                    const uint32_t hs = ((odd >> s) & 1u) << 4;
+                    const bool valid = (val >> s) & 1u;
+                    if (WHICH == 1)
+                        old[s] = fl_lds_add_rtn(&head32[hw[s]], valid ? (1u << hs) : 0u);
+                    else
+                        old[s] = fl_lds_mskor_rtn(&head32[hw[s]], valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]),
+                               "+v"(old[6]), "+v"(old[7]), "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]),
+                               "+v"(old[12]), "+v"(old[13]), "+v"(old[14]), "+v"(old[15])
+                             :
+                             : "memory");
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (uint32_t s = 0; s < 16; s++) {
+            const uint32_t p = (b << 10) + (s << 6) + lane;
+            if ((val >> s) & 1u) {
+                const uint32_t o = ((odd >> s) & 1u) ? (old[s] >> 16) : (old[s] & 0xffffu);
+                overtaken = overtaken || o > p;  // (a head above the position; a count above the number of positions before it)
+                pv[p] = (uint16_t)o;             // 0 = none: position 0 is the chain's null (deflate.zig:248)
+            }
+        }
+    }
+#ifdef FL_CHAIN_FORCE_SLOW
+    overtaken = true;  // (test builds: exercise the fallback)
+#endif
+    if (__syncthreads_or(overtaken ? 1 : 0)) {
+        // never seen on gfx950: one position at a time, by one lane (Lookup.zig:35-40 as written)
+        uint16_t* head16 = (uint16_t*)head32;
+        for (uint32_t i = threadIdx.x; i < 16384; i += 64 * FL_CHAIN_WAVES) head32[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t p = 0; p < Mpos; p++) {
+                const uint32_t v = fl_load_u32_clamped(src, p, N);
+                uint32_t h;
+                if (WHICH <= 1) {
+                    h = fl_hash_le(v);
+                } else {
+                    const uint32_t v1 = fl_load_u32_clamped(src, p + 4, N);
+                    h = WHICH == 2 ? fl_hash6(v, v1) : fl_hash8(v, v1);
+                }
+                pv[p] = head16[h];
+                head16[h] = WHICH == 1 ? (uint16_t)(head16[h] + 1u) : (uint16_t)p;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_lz_walk
+#define WK_THREADS 1024
+#define WK_SEG 64u
+#define WK_WIN_DW ((65536u + 320u) / 4u)  // the chunk's bytes, zero padded (a compare reads up to 258 + 8 + 3 bytes past a position)
+#define WK_L4 0u
+#define WK_L6 1u
+#define WK_L8 2u
+
+#ifdef WK_PROF
+#define WK_CNT(var, v) (var) += (v)
+#else
+#define WK_CNT(var, v)
+#endif
+
+// lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
+__global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const uint8_t* __restrict__ in,
+                                                                           const fl_chunk* __restrict__ chunks, fl_params prm,
+                                                                           const uint16_t* __restrict__ lnk,
+                                                                           const uint32_t* __restrict__ cflag,
+                                                                           uint32_t* __restrict__ desc_all,
+                                                                           uint32_t* __restrict__ true_all) {
+    __shared__ uint32_t win32[WK_WIN_DW];
+    __shared__ uint16_t tX[WK_THREADS];       // exit of a lane's own parse, as soon as it is known
+    __shared__ uint16_t tExg[WK_THREADS];     // exit the path is assumed to take out of a segment
+    __shared__ uint16_t tNxt[2][WK_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
+    __shared__ uint16_t tEnt[WK_THREADS];     // position at which the path enters a segment
+    __shared__ uint16_t tMark[WK_THREADS];    // segment is on the path
+    const uint32_t c = blockIdx.x;
+    const fl_chunk ck = chunks[c];
+    if (ck.skip) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = ck.in_len;
+    const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
+    const uint8_t* src = in + ck.in_off;
+    uint32_t* descg = desc_all + ck.pos_off;
+    uint32_t* trueg = true_all + (ck.pos_off >> 5);
+    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    if (N == 0) return;
+    if (cflag[c] == 1u) {
+        // The chunk is one repeated byte (k_lz_links<0> saw it and built no chains): see k_lz_parse.
+        for (uint32_t k = tid; 2 + FL_MAX_MATCH * k < N || k < 1; k += WK_THREADS) {
+            if (k == 0) {
+                uint32_t w = 0;
+                for (uint32_t p = 0; p < min(N, 2u); p++) {
+                    descg[p] = PZ_DESC_LIT;
+                    w |= 1u << p;
+                }
+                if (w) atomicOr(&trueg[0], w);
+            }
+            const uint32_t a = 2 + FL_MAX_MATCH * k;
+            if (a >= N) continue;
+            if (N - a >= FL_MIN_MATCH) {
+                const uint32_t len = min(N - a, (uint32_t)FL_MAX_MATCH);
+                descg[a] = 0x80000000u | ((len - 3u) << 15);  // j = 0, distance 1
+                atomicOr(&trueg[a >> 5], 1u << (a & 31u));
+            } else {
+                for (uint32_t p = a; p < N; p++) {
+                    descg[p] = PZ_DESC_LIT;
+                    atomicOr(&trueg[p >> 5], 1u << (p & 31u));
+                }
+            }
+        }
+        return;
+    }
+    const uint16_t* lk = lnk + (uint64_t)c * (4u * FL_CHUNK_STRIDE);  // level K: lk[(K << 16) + position]; RK: lk[(3 << 16) + position]
+#ifdef WK_PROF
+    uint32_t c_iter = 0, c_gath = 0, c_judge = 0, c_meas = 0, c_move = 0, c_rank = 0;
+    const uint64_t c_t0 = __builtin_readcyclecounter();
+#endif
+    // ---- the chunk's bytes, zero padded
+    {
+        const uint32_t ash = (uint32_t)((uintptr_t)src & 3);
+        const uint32_t* a32 = (const uint32_t*)(src - ash);
+        const uint32_t ndw = (N + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
+        constexpr uint32_t WB = (WK_WIN_DW + WK_THREADS - 1) / WK_THREADS;
+        uint32_t lo[WB], hi[WB];
+#pragma unroll
+        for (uint32_t u = 0; u < WB; u++) {
+            const uint32_t i = u * WK_THREADS + tid;
+            lo[u] = i < ndw ? a32[i] : 0u;
+            hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < WB; u++) {
+            const uint32_t i = u * WK_THREADS + tid;
+            uint32_t v = __builtin_amdgcn_alignbyte(hi[u], lo[u], ash);
+            if (4 * i + 4 > N) v = 4 * i < N ? (v & ((1u << (8 * (N - 4 * i))) - 1u)) : 0u;
+            if (i < WK_WIN_DW) win32[i] = v;
+        }
+    }
+    const uint32_t nseg = (N + WK_SEG - 1) >> 6;
+    const uint32_t m = tid;  // this lane's segment
+    const uint32_t seg0 = m * WK_SEG;
+    const uint32_t seg_end = min(seg0 + WK_SEG, N);
+    uint64_t A = 0, F = 0;  // anchors of the lane's own parse; of the parse from the entry
+    uint32_t X = seg_end;   // exit of the lane's own parse
+    uint32_t res_entry = PZ_NONE, res_exit = 0, Z = PZ_NONE;
+    bool marked = false;
+    tX[m] = (uint16_t)PZ_NONE;
+    __syncthreads();
+
+    enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
+    for (uint32_t round = 0;; round++) {
+        uint32_t st = ST_DONE;
+        uint32_t a = 0;
+        uint64_t stopmask = 0;
+        uint32_t y_in = PZ_NONE;
+        bool fixing = false;   // this lane parses its segment again in this round ...
+        uint32_t ex_used = 0;  // ... and this is the exit the round's path assumed for it
+        if (round == 0) {
+            if (m < nseg) {
+                st = ST_SPEC;
+                a = seg0;
+            }
+        } else {
+            // the path, assuming every segment not resolved yet leaves through its own exit
+            if (m < nseg) {
+                const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
+                ex_used = ex;
+                tExg[m] = (uint16_t)ex;
+                tNxt[0][m] = (uint16_t)(ex >= N ? nseg : (ex >> 6));
+                tMark[m] = m == 0 ? 1 : 0;
+                tEnt[m] = m == 0 ? (uint16_t)0 : (uint16_t)PZ_NONE;
+            }
+            __syncthreads();
+            uint32_t cur = 0;
+            for (uint32_t step = 0; (1u << step) < nseg; step++) {
+                if (m < nseg) {
+                    const uint32_t n = tNxt[cur][m];
+                    if (n < nseg) {
+                        if (tMark[m]) tMark[n] = 1;
+                        tNxt[cur ^ 1][m] = tNxt[cur][n];
+                    } else {
+                        tNxt[cur ^ 1][m] = (uint16_t)nseg;
+                    }
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            marked = m < nseg && tMark[m] != 0;
+            if (marked) {
+                const uint32_t ex = tExg[m];
+                if (ex < N) tEnt[ex >> 6] = (uint16_t)ex;
+            }
+            __syncthreads();
+            if (marked) y_in = tEnt[m];
+            const bool work = marked && y_in != res_entry;
+            if (!__syncthreads_or(work ? 1 : 0)) break;
+            if (work) {
+                st = ST_FIX;
+                a = y_in;
+                stopmask = A;
+                fixing = true;
+            }
+        }
+        // ---- the automaton (deflate.zig:154-205) over calls of the match finder
+        uint64_t amask = 0;
+        uint32_t j = 0, plen = 0, pdist = 0;
+        // the call in progress: position p, best = match in hand (bdist its distance, 0: none accepted in this call),
+        // K = level walked, q = candidate to judge (when cs == CS_CAND) or candidate whose link is in flight
+        uint32_t p = 0, best = 0, bdist = 0, maxlen = 0, lo = 1, last = 0, K = WK_L4, cnt = 0, budget = 0, q = 0, pref = 0, fo = 0;
+        uint32_t pend_l = 0;   // an accepted-if-within-budget candidate q of L6 / L8 waits for RK[p], RK[q]
+        enum { CS_NONE = 0, CS_LINK = 1, CS_RANK = 2 };
+        uint32_t cs = CS_NONE;
+        uint32_t g_link = 0, g_rp = 0, g_rq = 0;  // values of the gathers in flight
+        // a parse that starts on a position where it has to stop already (FIX only)
+        if (st == ST_FIX && ((stopmask >> ((a - seg0) & 63u)) & 1ull)) {
+            F = 0;
+            res_entry = y_in;
+            Z = a;
+            res_exit = X;
+            st = ST_DONE;
+        }
+        bool need_move = st != ST_DONE;  // the lane is between calls: the automaton's next move is due
+        bool first_call = need_move;     // ... and that move is the first call of the parse (at a, nothing pending)
+        for (;;) {
+            const uint64_t alive = __ballot(st != ST_DONE);
+            if (alive == 0) break;
+            if (__ballot(st == ST_WAIT) == alive) __builtin_amdgcn_s_sleep(8);  // nothing to do but wait for another wave
+            WK_CNT(c_iter, 1);
+            // ---- (A) a candidate has arrived (cs == CS_LINK: g_link holds it), or the ranks have (CS_RANK)
+            bool call_done = false;
+            bool want_link = false;  // the walk goes on behind q: its link is needed
+            if (cs == CS_RANK) {
+                WK_CNT(c_rank, 1);
+                cs = CS_NONE;
+                if (g_rp - g_rq > budget) {
+                    call_done = true;  // beyond what the reference looks at: so is everything behind it
+                } else {
+                    best = pend_l;
+                    bdist = p - q;
+                    last = q;
+                    if (best >= nice || best >= maxlen) {
+                        call_done = true;
+                    } else {
+                        fo = best - 3u;
+                        pref = pz_lds4(win32, p + fo);
+                        const uint32_t K2 = best < 7u ? WK_L6 : WK_L8;
+                        if (K2 != K) {  // the walk moves to the sparser chain: from its top, skipping what is done
+                            K = K2;
+                            q = p;
+                        }
+                        want_link = true;
+                    }
+                }
+            } else if (cs == CS_LINK) {
+                cs = CS_NONE;
+                q = g_link;
+                const bool in_budget = K != WK_L4 || cnt != 0;
+                if (q < lo || !in_budget) {
+                    call_done = true;
+                } else if (q >= last) {
+                    want_link = true;  // (after a change of level: already looked at)
+                } else {
+                    WK_CNT(c_judge, 1);
+                    if (K == WK_L4) {
+                        cnt--;
+                        last = q;
+                    }
+                    want_link = true;
+                    if (pz_lds4(win32, q + fo) == pref) {
+                        // the candidate agrees where it must: its exact common prefix with p
+                        uint32_t l = 0;
+                        for (;;) {
+                            WK_CNT(c_meas, 1);
+                            uint32_t a0, a1, b0, b1;
+                            fl_lds_load8(win32, p + l, a0, a1);
+                            fl_lds_load8(win32, q + l, b0, b1);
+                            const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                            if (x) {
+                                l += (uint32_t)__builtin_ctzll(x) >> 3;
+                                break;
+                            }
+                            l += 8;
+                            if (l >= maxlen) break;
+                        }
+                        l = min(l, maxlen);
+                        if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
+                            if (K != WK_L4) {
+                                pend_l = l;  // is it within the reference's budget?
+                                cs = CS_RANK;
+                                want_link = false;
+                            } else {
+                                best = l;
+                                bdist = p - q;
+                                if (l >= nice || l >= maxlen) {
+                                    call_done = true;
+                                    want_link = false;
+                                } else {
+                                    fo = l - 3u;
+                                    pref = pz_lds4(win32, p + fo);
+                                    if (l >= 5u) {  // on to a sparser chain, from its top
+                                        K = l < 7u ? WK_L6 : WK_L8;
+                                        q = p;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (call_done) need_move = true;
+            // ---- (B) the automaton's move: one per lane and iteration; every path through it ends in at most one new call
+            if (need_move && st != ST_DONE) {
+                WK_CNT(c_move, 1);
+                need_move = false;
+                bool start = false;
+                uint32_t sp = 0, sl = 0;
+                if (st == ST_WAIT) {
+                    // the lane before has finished its own parse: where does that leave this segment?
+                    const uint32_t v = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    need_move = true;  // (polled again in the next iteration)
+                    if (v != PZ_NONE) {
+                        st = ST_DONE;
+                        need_move = false;
+                        if (v >= seg0 && v < seg_end) {
+                            y_in = v;
+                            if ((A >> (v - seg0)) & 1ull) {  // on an anchor of the own parse
+                                F = 0;
+                                res_entry = v;
+                                Z = v;
+                                res_exit = X;
+                            } else {
+                                st = ST_FIX;
+                                a = v;
+                                stopmask = A;
+                                amask = 0;
+                                j = 0;
+                                plen = 0;
+                                start = true;
+                                sp = v;
+                            }
+                        }
+                    }
+                } else if (first_call) {
+                    first_call = false;
+                    start = true;
+                    sp = a;
+                } else {
+                    // the call has ended: the automaton's next move
+                    bool emit = true;  // the pending match goes out (deflate.zig:182-184), or a literal
+                    if (bdist) {       // a match, longer than the pending one if there is one
+                        if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
+                        plen = best;
+                        pdist = bdist;
+                        emit = plen >= lazy;  // deflate.zig:171-173
+                    }
+                    if (emit) {
+                        uint32_t desc = PZ_DESC_LIT, next = a + 1;
+                        if (plen) {
+                            desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
+                            next = a + j + plen;
+                        }
+                        descg[a] = desc;
+                        amask |= 1ull << (a - seg0);
+                        a = next;
+                        j = 0;
+                        plen = 0;
+                        const bool meet = a < seg_end && ((stopmask >> ((a - seg0) & 63u)) & 1ull);
+                        if (a >= seg_end || meet) {
+                            // the parse leaves the segment or steps on an anchor of the lane's own parse
+                            if (st == ST_SPEC) {
+                                A = amask;
+                                X = a;
+                                __hip_atomic_store(&tX[m], (uint16_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                amask = 0;
+                                if (m == 0) {  // the first segment's own parse is the true one
+                                    res_entry = 0;
+                                    res_exit = a;
+                                    Z = 0;
+                                    st = ST_DONE;
+                                } else {
+                                    st = ST_WAIT;
+                                    need_move = true;
+                                }
+                            } else {
+                                F = amask;
+                                res_entry = y_in;
+                                Z = meet ? a : PZ_NONE;
+                                res_exit = meet ? X : a;
+                                st = ST_DONE;
+                            }
+                        } else {
+                            start = true;
+                            sp = a;
+                        }
+                    } else {
+                        // keep the match, look one position further (deflate.zig:174-178)
+                        start = true;
+                        sp = a + j + 1u;
+                        sl = plen;
+                    }
+                }
+                if (start) {
+                    // a call of the match finder at sp with a match of sl bytes in hand (deflate.zig:233-245)
+                    p = sp;
+                    best = sl;
+                    bdist = 0;
+                    maxlen = min(N - p, (uint32_t)FL_MAX_MATCH);
+                    lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
+                    budget = sl >= good ? (chain >> 2) : chain;
+                    cnt = budget;
+                    K = sl < 5u ? WK_L4 : (sl < 7u ? WK_L6 : WK_L8);
+                    last = p;
+                    q = p;  // (the top of the chain is the position's own link)
+                    fo = sl ? sl - 3u : 0u;
+                    if (p < Mpos && maxlen > sl) {
+                        pref = pz_lds4(win32, p + fo);
+                        want_link = true;
+                    } else {
+                        need_move = true;  // no hash entry / nothing longer is possible: the call finds nothing
+                    }
+                }
+            }
+            // ---- (C) the gathers of this iteration
+            if (want_link) {
+                WK_CNT(c_gath, 1);
+                g_link = lk[(K << 16) + q];
+                cs = CS_LINK;
+            }
+            if (cs == CS_RANK) {
+                WK_CNT(c_gath, 2);
+                g_rp = lk[(3u << 16) + p];
+                g_rq = lk[(3u << 16) + q];
+            }
+        }
+        // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with
+        // it the marks and entries found above -- no round to confirm it.
+        if (round >= 1 && !__syncthreads_or((fixing && res_exit != ex_used) ? 1 : 0)) break;
+    }
+    // ---- the true anchors
+    if (m < nseg) {
+        uint64_t T = 0;
+        if (marked) {
+            T = F;
+            if (Z != PZ_NONE) T |= A & (~0ull << (Z - seg0));
+        }
+        // (segments are 64 positions: two whole words of the bitmap the host has cleared)
+        if ((uint32_t)T) trueg[seg0 >> 5] = (uint32_t)T;
+        if ((uint32_t)(T >> 32)) trueg[(seg0 >> 5) + 1] = (uint32_t)(T >> 32);
+    }
+#ifdef WK_PROF
+    if ((tid & 63) == 0) {
+        atomicAdd((unsigned long long*)&g_fl_prof[40], (unsigned long long)c_iter);
+        atomicAdd((unsigned long long*)&g_fl_prof[41], (unsigned long long)(__builtin_readcyclecounter() - c_t0));
+        atomicAdd((unsigned long long*)&g_fl_prof[42], 1ull);
+    }
+    (void)c_gath; (void)c_judge; (void)c_meas; (void)c_move; (void)c_rank;
+#endif
+}
