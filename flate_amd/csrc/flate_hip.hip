@@ -451,21 +451,13 @@ int fetch_offsets(flate_hip_ctx* h, const uint64_t* off, uint32_t n, int memkind
 int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
     int rc;
     const size_t per = (size_t)nc * FL_CHUNK_STRIDE;
-#ifdef FL_OLD_TOKENIZER
-    if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;      // chain links / sorted positions
     if (chain >= FL_BULK_MIN_CHAIN) {
-        if ((rc = ensure(h, h->NC, per * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(h, h->rec, per * 2 * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(h, h->links, per * 4 * sizeof(uint16_t)))) return rc;  // per chunk [L4 | L6 | L8 | RK] (kernels_walk.h)
     } else {
-        if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
-        if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
+        if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;          // chain links (kernels_parse.h)
     }
-#else
-    (void)chain;
-    if ((rc = ensure(h, h->links, per * 4 * sizeof(uint16_t)))) return rc;  // per chunk [L4 | L6 | L8 | RK] (kernels_walk.h)
-    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;       // anchor descriptors
-    if ((rc = ensure(h, h->marks, per / 8))) return rc;                     // true anchors, one bit per position
-#endif
+    if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
+    if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
     if ((rc = ensure(h, h->tokens, per * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * nc))) return rc;
     if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nc))) return rc;
@@ -530,11 +522,10 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     }
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
-#ifndef FL_OLD_TOKENIZER
-        {
-            // levels 4..9: the reference's chain and two sparser ones, the reference's automaton per segment over them,
-            // tokens (kernels_walk.h, kernels_parse.h)
-            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));
+        HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // the parse kernels OR / store the anchors in
+        if (prm.chain >= FL_BULK_MIN_CHAIN) {
+            // levels 8 and 9 (chains of 1024 / 4096 candidates): the reference's chain and two sparser ones in global
+            // memory, the automaton over them (kernels_walk.h): a walk is 1.4 steps per byte instead of 14
             {
                 ProfScope ps(h, K_LZ_LINKS);
                 hipLaunchKernelGGL(k_lz_links<0>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->links.p,
@@ -551,44 +542,8 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 hipLaunchKernelGGL(k_lz_walk, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
             }
-            {
-                ProfScope ps(h, K_LZ_EMIT);
-                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
-                                   dpl, (uint32_t*)h->ntok.p);
-            }
-        }
-#else
-        if (prm.chain >= FL_BULK_MIN_CHAIN) {
-            // levels 8 and 9 (chains of 1024 / 4096 candidates): the match finder that evaluates every position in
-            // hash order, 64 positions of a bucket at a time (kernels_lz.h) -- a lane walking 4096 links on its
-            // own, as the demand-driven parse below would, keeps its whole workgroup waiting
-            {
-                ProfScope ps(h, K_LZ_SORT);
-                hipLaunchKernelGGL(k_lz_sort<false>, dim3(nc), dim3(FL_SORT_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (uint16_t*)h->S.p, (uint32_t*)h->cflag.p);
-            }
-            {
-                ProfScope ps(h, K_LZ_MATCH);
-                const uint32_t* cf = (const uint32_t*)h->cflag.p;
-                hipLaunchKernelGGL((k_lz_match<false, true, false>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in, dch,
-                                   (const fl_tile*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, prm,
-                                   (const uint16_t*)h->S.p, (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
-                // the chunks k_lz_sort marked runny
-                hipLaunchKernelGGL((k_lz_match<false, true, true>), dim3(nc), dim3(FL_MATCH_THREADS), 0, st, d_in,
-                                   dch, (const fl_tile*)nullptr, (const uint32_t*)nullptr,
-                                   (const uint32_t*)nullptr, prm, (const uint16_t*)h->S.p, (uint32_t*)h->NC.p,
-                                   (uint32_t*)h->rec.p, cf);
-            }
-            {
-                ProfScope ps(h, K_LZ_TOK);
-                hipLaunchKernelGGL(k_lz_tok, dim3(nc), dim3(FL_TOK_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint32_t*)h->rec.p, (uint32_t*)h->tokens.p, dhist, dpl, (uint32_t*)h->ntok.p);
-            }
         } else {
-            // levels 4..7: hash chains, the reference's automaton per segment, tokens (kernels_parse.h)
-            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // k_lz_parse ORs the anchors in
+            // levels 4..7: the reference's chain in LDS, the automaton per segment (kernels_parse.h)
             {
                 ProfScope ps(h, K_LZ_CHAIN);
                 hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
@@ -599,14 +554,13 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
             }
-            {
-                ProfScope ps(h, K_LZ_EMIT);
-                hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
-                                   (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
-                                   dpl, (uint32_t*)h->ntok.p);
-            }
         }
-#endif
+        {
+            ProfScope ps(h, K_LZ_EMIT);
+            hipLaunchKernelGGL(k_lz_emit, dim3(nc), dim3(FL_EMITZ_THREADS), 0, st, d_in, dch, prm,
+                               (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p, (uint32_t*)h->tokens.p, dhist,
+                               dpl, (uint32_t*)h->ntok.p);
+        }
         h->dbg_pass_chunks = nc;
         h->dbg_first_chunk = c0;
         h->dbg_pos_off.resize(nc);

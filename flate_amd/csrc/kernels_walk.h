@@ -219,6 +219,15 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #define WK_L4 0u
 #define WK_L6 1u
 #define WK_L8 2u
+#ifndef WK_BURST
+#define WK_BURST 4        // chain steps per trip, at most
+#endif
+#ifndef WK_PROBE
+#define WK_PROBE 8u       // steps on L6 / L8 between two looks at the budget
+#endif
+#ifndef WK_MINWALK
+#define WK_MINWALK 8u     // ... fewer when fewer lanes than this still walk
+#endif
 
 #ifdef WK_PROF
 #define WK_CNT(var, v) (var) += (v)
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                                                                            uint32_t* __restrict__ desc_all,
                                                                            uint32_t* __restrict__ true_all) {
     __shared__ uint32_t win32[WK_WIN_DW];
-    __shared__ uint16_t tX[WK_THREADS];       // exit of a lane's own parse, as soon as it is known
+    __shared__ uint16_t tX[WK_THREADS];       // exit of a lane's own parse as soon as it is known, complemented (0xffff: not yet)
     __shared__ uint16_t tExg[WK_THREADS];     // exit the path is assumed to take out of a segment
     __shared__ uint16_t tNxt[2][WK_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
     __shared__ uint16_t tEnt[WK_THREADS];     // position at which the path enters a segment
@@ -315,6 +324,15 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
 
     enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
     for (uint32_t round = 0;; round++) {
+#ifdef WK_PROF
+        if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[43], 1ull);
+#ifdef WK_ROUND_CAP
+        if (round > WK_ROUND_CAP) {
+            if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[46], 1ull);
+            break;
+        }
+#endif
+#endif
         uint32_t st = ST_DONE;
         uint32_t a = 0;
         uint64_t stopmask = 0;
@@ -371,11 +389,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         uint64_t amask = 0;
         uint32_t j = 0, plen = 0, pdist = 0;
         // the call in progress: position p, best = match in hand (bdist its distance, 0: none accepted in this call),
-        // K = level walked, q = candidate to judge (when cs == CS_CAND) or candidate whose link is in flight
+        // K = level walked, q = the candidate in hand, last = every candidate from here up has been looked at
         uint32_t p = 0, best = 0, bdist = 0, maxlen = 0, lo = 1, last = 0, K = WK_L4, cnt = 0, budget = 0, q = 0, pref = 0, fo = 0;
-        uint32_t pend_l = 0;   // an accepted-if-within-budget candidate q of L6 / L8 waits for RK[p], RK[q]
-        enum { CS_NONE = 0, CS_LINK = 1, CS_RANK = 2 };
-        uint32_t cs = CS_NONE;
+        uint32_t pend_l = 0;  // a candidate q of L6 / L8 that would be accepted waits for RK[p], RK[q]: is it within the budget?
+        // what a lane waits for: MOVE the automaton's next move (between calls), WALK the link in flight = its next
+        // candidate, MEAS the exact length of candidate q (it passed the filter), RANK the two ranks in flight
+        enum { CS_MOVE = 0, CS_WALK = 1, CS_MEAS = 2, CS_RANK = 3, CS_IDLE = 4 };
         uint32_t g_link = 0, g_rp = 0, g_rq = 0;  // values of the gathers in flight
         // a parse that starts on a position where it has to stop already (FIX only)
         if (st == ST_FIX && ((stopmask >> ((a - seg0) & 63u)) & 1ull)) {
@@ -385,108 +404,36 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
             res_exit = X;
             st = ST_DONE;
         }
-        bool need_move = st != ST_DONE;  // the lane is between calls: the automaton's next move is due
-        bool first_call = need_move;     // ... and that move is the first call of the parse (at a, nothing pending)
+        uint32_t cs = st != ST_DONE ? CS_MOVE : CS_IDLE;
+        bool first_call = true;  // the next move is the first call of the parse (at a, nothing pending)
+        // Lanes do the same thing at the same time: a wave's trip through this loop is (M) the automaton's move for the
+        // lanes between calls, (W) up to WK_BURST chain steps for the lanes that walk -- a step is the arrival of a
+        // link, the bounds, the four-byte filter, the request of the next link --, (J) the exact length of the
+        // candidates that passed the filter and what follows from it.  (One loop with every lane's case in every trip
+        // cost 2.2 M vector instructions per chunk: 27.5 ms per GiB.)
         for (;;) {
-            const uint64_t alive = __ballot(st != ST_DONE);
+            const uint64_t alive = __ballot(cs != CS_IDLE);
             if (alive == 0) break;
+#ifdef WK_TRIP_CAP
+            if (c_iter > WK_TRIP_CAP) {  // (debug builds: a parse that does not end is cut off and counted)
+                if ((tid & 63) == 0) atomicAdd((unsigned long long*)&g_fl_prof[45], 1ull);
+                break;
+            }
+#endif
             if (__ballot(st == ST_WAIT) == alive) __builtin_amdgcn_s_sleep(8);  // nothing to do but wait for another wave
             WK_CNT(c_iter, 1);
-            // ---- (A) a candidate has arrived (cs == CS_LINK: g_link holds it), or the ranks have (CS_RANK)
-            bool call_done = false;
-            bool want_link = false;  // the walk goes on behind q: its link is needed
-            if (cs == CS_RANK) {
-                WK_CNT(c_rank, 1);
-                cs = CS_NONE;
-                if (g_rp - g_rq > budget) {
-                    call_done = true;  // beyond what the reference looks at: so is everything behind it
-                } else {
-                    best = pend_l;
-                    bdist = p - q;
-                    last = q;
-                    if (best >= nice || best >= maxlen) {
-                        call_done = true;
-                    } else {
-                        fo = best - 3u;
-                        pref = pz_lds4(win32, p + fo);
-                        const uint32_t K2 = best < 7u ? WK_L6 : WK_L8;
-                        if (K2 != K) {  // the walk moves to the sparser chain: from its top, skipping what is done
-                            K = K2;
-                            q = p;
-                        }
-                        want_link = true;
-                    }
-                }
-            } else if (cs == CS_LINK) {
-                cs = CS_NONE;
-                q = g_link;
-                const bool in_budget = K != WK_L4 || cnt != 0;
-                if (q < lo || !in_budget) {
-                    call_done = true;
-                } else if (q >= last) {
-                    want_link = true;  // (after a change of level: already looked at)
-                } else {
-                    WK_CNT(c_judge, 1);
-                    if (K == WK_L4) {
-                        cnt--;
-                        last = q;
-                    }
-                    want_link = true;
-                    if (pz_lds4(win32, q + fo) == pref) {
-                        // the candidate agrees where it must: its exact common prefix with p
-                        uint32_t l = 0;
-                        for (;;) {
-                            WK_CNT(c_meas, 1);
-                            uint32_t a0, a1, b0, b1;
-                            fl_lds_load8(win32, p + l, a0, a1);
-                            fl_lds_load8(win32, q + l, b0, b1);
-                            const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
-                            if (x) {
-                                l += (uint32_t)__builtin_ctzll(x) >> 3;
-                                break;
-                            }
-                            l += 8;
-                            if (l >= maxlen) break;
-                        }
-                        l = min(l, maxlen);
-                        if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
-                            if (K != WK_L4) {
-                                pend_l = l;  // is it within the reference's budget?
-                                cs = CS_RANK;
-                                want_link = false;
-                            } else {
-                                best = l;
-                                bdist = p - q;
-                                if (l >= nice || l >= maxlen) {
-                                    call_done = true;
-                                    want_link = false;
-                                } else {
-                                    fo = l - 3u;
-                                    pref = pz_lds4(win32, p + fo);
-                                    if (l >= 5u) {  // on to a sparser chain, from its top
-                                        K = l < 7u ? WK_L6 : WK_L8;
-                                        q = p;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            if (call_done) need_move = true;
-            // ---- (B) the automaton's move: one per lane and iteration; every path through it ends in at most one new call
-            if (need_move && st != ST_DONE) {
+            // ---- (M) the automaton's move: one per lane and trip; every path through it ends in at most one new call
+            if (cs == CS_MOVE) {
                 WK_CNT(c_move, 1);
-                need_move = false;
                 bool start = false;
                 uint32_t sp = 0, sl = 0;
                 if (st == ST_WAIT) {
                     // the lane before has finished its own parse: where does that leave this segment?
-                    const uint32_t v = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    need_move = true;  // (polled again in the next iteration)
-                    if (v != PZ_NONE) {
+                    const uint32_t vx = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t v = ~vx & 0xffffu;  // (stored as its complement: an exit is 1 .. 65535, 0xffff says "not yet")
+                    if (vx != PZ_NONE) {
                         st = ST_DONE;
-                        need_move = false;
+                        cs = CS_IDLE;
                         if (v >= seg0 && v < seg_end) {
                             y_in = v;
                             if ((A >> (v - seg0)) & 1ull) {  // on an anchor of the own parse
@@ -536,16 +483,16 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                             if (st == ST_SPEC) {
                                 A = amask;
                                 X = a;
-                                __hip_atomic_store(&tX[m], (uint16_t)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&tX[m], (uint16_t)~a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 amask = 0;
                                 if (m == 0) {  // the first segment's own parse is the true one
                                     res_entry = 0;
                                     res_exit = a;
                                     Z = 0;
                                     st = ST_DONE;
+                                    cs = CS_IDLE;
                                 } else {
                                     st = ST_WAIT;
-                                    need_move = true;
                                 }
                             } else {
                                 F = amask;
@@ -553,6 +500,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                                 Z = meet ? a : PZ_NONE;
                                 res_exit = meet ? X : a;
                                 st = ST_DONE;
+                                cs = CS_IDLE;
                             }
                         } else {
                             start = true;
@@ -573,29 +521,120 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                     maxlen = min(N - p, (uint32_t)FL_MAX_MATCH);
                     lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
                     budget = sl >= good ? (chain >> 2) : chain;
-                    cnt = budget;
                     K = sl < 5u ? WK_L4 : (sl < 7u ? WK_L6 : WK_L8);
+                    cnt = K == WK_L4 ? budget : WK_PROBE;
                     last = p;
-                    q = p;  // (the top of the chain is the position's own link)
                     fo = sl ? sl - 3u : 0u;
+                    cs = CS_MOVE;  // (no hash entry / nothing longer is possible: the call finds nothing)
                     if (p < Mpos && maxlen > sl) {
                         pref = pz_lds4(win32, p + fo);
-                        want_link = true;
-                    } else {
-                        need_move = true;  // no hash entry / nothing longer is possible: the call finds nothing
+                        WK_CNT(c_gath, 1);
+                        g_link = lk[(K << 16) + p];  // the top of the chain is the position's own link
+                        cs = CS_WALK;
                     }
                 }
             }
-            // ---- (C) the gathers of this iteration
-            if (want_link) {
-                WK_CNT(c_gath, 1);
-                g_link = lk[(K << 16) + q];
-                cs = CS_LINK;
+            // ---- (W) chain steps
+#pragma unroll 1
+            for (int it = 0; it < WK_BURST; it++) {
+                const uint64_t walkers = __ballot(cs == CS_WALK);
+                if (walkers == 0) break;
+                if (it != 0 && (uint32_t)__popcll(walkers) < WK_MINWALK) break;  // (the others have waited long enough)
+                if (cs == CS_WALK) {
+                    WK_CNT(c_judge, 1);
+                    q = g_link;
+                    if (q < lo || (K == WK_L4 && cnt == 0)) {
+                        cs = CS_MOVE;  // the call has ended
+                    } else {
+                        bool pass = false;
+                        if (q < last) {  // (else: looked at before the walk changed chains)
+                            if (cnt) cnt--;
+                            if (K == WK_L4) last = q;
+                            pass = pz_lds4(win32, q + fo) == pref;
+                        }
+                        if (pass) {
+                            cs = CS_MEAS;
+                        } else if (K != WK_L4 && cnt == 0 && pz_lds4(win32, q) == pz_lds4(win32, p)) {
+                            // A walk on L6 / L8 is not counted down, and one that finds nothing better would go on to the
+                            // end of the window (runs: thousands of candidates).  Every WK_PROBE steps a candidate of p's
+                            // own L4 bucket (same first four bytes) is asked for its rank: beyond the budget ends the call.
+                            WK_CNT(c_gath, 2);
+                            pend_l = 0;
+                            g_rp = lk[(3u << 16) + p];
+                            g_rq = lk[(3u << 16) + q];
+                            cs = CS_RANK;
+                        } else {
+                            WK_CNT(c_gath, 1);
+                            g_link = lk[(K << 16) + q];
+                        }
+                    }
+                }
             }
-            if (cs == CS_RANK) {
-                WK_CNT(c_gath, 2);
-                g_rp = lk[(3u << 16) + p];
-                g_rq = lk[(3u << 16) + q];
+            // ---- (J) candidates that passed the filter; ranks that have arrived
+            if (cs == CS_RANK || cs == CS_MEAS) {
+                bool accept = false;
+                uint32_t l = pend_l;
+                if (cs == CS_RANK) {
+                    WK_CNT(c_rank, 1);
+                    cs = CS_WALK;
+                    cnt = WK_PROBE;
+                    if (g_rp - g_rq > budget)
+                        cs = CS_MOVE;  // beyond what the reference looks at, and so is everything behind it
+                    else
+                        accept = l != 0;  // (0: a probe)
+                } else {
+                    // the candidate agrees where it must: its exact common prefix with p
+                    l = 0;
+                    for (;;) {
+                        WK_CNT(c_meas, 1);
+                        uint32_t a0, a1, b0, b1;
+                        fl_lds_load8(win32, p + l, a0, a1);
+                        fl_lds_load8(win32, q + l, b0, b1);
+                        const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                        if (x) {
+                            l += (uint32_t)__builtin_ctzll(x) >> 3;
+                            break;
+                        }
+                        l += 8;
+                        if (l >= maxlen) break;
+                    }
+                    l = min(l, maxlen);
+                    if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
+                        if (K == WK_L4) {
+                            accept = true;
+                        } else {
+                            pend_l = l;
+                            WK_CNT(c_gath, 2);
+                            g_rp = lk[(3u << 16) + p];
+                            g_rq = lk[(3u << 16) + q];
+                            cs = CS_RANK;
+                        }
+                    } else {
+                        cs = CS_WALK;  // the walk goes on behind the candidate
+                    }
+                }
+                if (accept) {
+                    best = l;
+                    bdist = p - q;
+                    last = q;
+                    cs = CS_WALK;
+                    if (l >= nice || l >= maxlen) {
+                        cs = CS_MOVE;  // good enough / nothing longer is possible
+                    } else {
+                        fo = l - 3u;
+                        pref = pz_lds4(win32, p + fo);
+                        const uint32_t K2 = l < 5u ? WK_L4 : (l < 7u ? WK_L6 : WK_L8);
+                        if (K2 != K) {  // on to a sparser chain, from its top (what is done is skipped there)
+                            K = K2;
+                            q = p;
+                            cnt = WK_PROBE;
+                        }
+                    }
+                }
+                if (cs == CS_WALK) {
+                    WK_CNT(c_gath, 1);
+                    g_link = lk[(K << 16) + q];
+                }
             }
         }
         // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with

@@ -642,3 +642,19 @@ def test_pageable_host_buffers_go_through_pinned_mirrors(monkeypatch):
         assert outs[i] == O.compress(chunks[i], 1, 6), i
     back, st3, _ = eng.decompress_many(outs, 1, caps=[65536] * len(chunks))
     assert st3 == [0] * len(chunks) and back == chunks
+
+
+def test_link_kernels_fallback_path_matches_oracle():
+    # k_lz_links relies on the LDS serving a wave's exchanges in lane / program order and checks it: a lane that was
+    # overtaken sends the chunk to a one-position-at-a-time path, which gfx950 has never taken.  The build with
+    # -DFL_CHAIN_FORCE_SLOW always takes it; the token lists must be the oracle's all the same (its own process:
+    # the library is chosen at import).
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "flate_amd", "lib", "var", "libflate_hip_slowchain.so")
+    assert os.path.exists(lib), "build() makes it (flate_amd/csrc/Makefile)"
+    env = dict(os.environ, FLATE_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) +
+                        "::test_tokenizer_matches_oracle_tokens"], env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -38,6 +38,7 @@ static void build_links(void) {
     for (int p = 0; p < N; p++) { if (p < Mpos) { const uint32_t h = hash8(buf + p); L8[p] = head[h]; head[h] = (uint16_t)p; } else L8[p] = 0; }
 }
 static int lcp(int q, int p, int maxlen) { int i = 0; while (i < maxlen && buf[q + i] == buf[p + i]) i++; return i; }
+#define PROBE 8
 static int level_of(int len) { return len < 5 ? 4 : (len < 7 ? 6 : 8); }
 
 // deflate.zig:233-266 with the sparser chains; returns len (0 = none)
@@ -48,9 +49,10 @@ static int find_match(int p, int len0, int* dist) {
     if (len0 > 0 && maxlen <= len0) return 0;  // (the reference walks on and finds nothing)
     const int B = len0 >= good ? chainmax >> 2 : chainmax;
     const int lo = p > 32768 ? p - 32768 : 1;
-    int len = len0, found = 0, last = p, K = level_of(len0), cnt = B, off = 0;
+    int len = len0, found = 0, last = p, K = level_of(len0), cnt = B, off = 0, probe = PROBE;
     for (;;) {  // one level (and, in offset mode, one offset) per trip
         off = (offset_mode && K > 4) ? len + 1 - K : 0;
+        probe = PROBE;
         n_top++; n_iter++;
         int q = (K == 4 ? L4 : K == 6 ? L6 : L8)[p + off];
         int switched = 0;
@@ -62,6 +64,7 @@ static int find_match(int p, int len0, int* dist) {
             if (qc >= last) n_skip++;
             else {
                 n_step[K == 4 ? 0 : K == 6 ? 1 : 2]++;
+                if (K != 4 && probe) probe--;
                 const int fo = off ? 0 : (len ? len - 3 : 0);  // filter: four bytes the candidate must share
                 if (ld32(buf + qc + fo) == ld32(buf + p + fo)) {
                     n_meas++;
@@ -72,6 +75,11 @@ static int find_match(int p, int len0, int* dist) {
                         if (l >= nice || l >= maxlen) return found;
                         if (level_of(len) != K || off != ((offset_mode && K > 4) ? len + 1 - K : 0)) { K = level_of(len); switched = 1; break; }
                     }
+                }
+                else if (K != 4 && probe == 0 && ld32(buf + qc) == ld32(buf + p)) {
+                    // a walk on L6 / L8 is not counted down: every PROBE steps a candidate of p's own bucket is asked for its rank
+                    n_rank++; n_iter++; probe = PROBE;
+                    if ((int)RK[p] - (int)RK[qc] > B) return found;
                 }
                 if (K == 4) last = qc;
             }

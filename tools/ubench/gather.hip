@@ -21,15 +21,18 @@ __global__ void k_gather(const uint32_t* __restrict__ links, uint32_t region, in
     const unsigned long long t0 = __builtin_readcyclecounter();
     if ((int)lane < active) {
         for (int it = 0; it < iters; it++) {
+            uint32_t got;
             if (MODE == 0) {
-                idx = base[idx];
+                got = ((const uint16_t*)base)[idx * 2];   // 2-byte loads (the links are 16 bit)
             } else if (MODE == 1) {
                 const uint2 v = *(const uint2*)(base + (idx & ~1u));
-                idx = v.x; acc += v.y;
+                got = v.x; acc += v.y;
             } else {
                 const uint4 v = *(const uint4*)(base + (idx & ~3u));
-                idx = v.x; acc += v.y + v.z + v.w;
+                got = v.x; acc += v.y + v.z + v.w;
             }
+            // the table holds zeros: the next index depends on the loaded value, but is a fresh pseudo-random position
+            idx = ((idx + got) * 1664525u + 1013904223u + (uint32_t)it * 2654435761u) % region;
         }
     }
     __syncthreads();
@@ -68,14 +71,14 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (uint32_t region : {1u << 16, 1u << 17}) {  // 256 KiB, 512 KiB per workgroup
-        for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (uint32_t)(s >> 20) % region; }
+    for (uint32_t region : {1u << 14, 1u << 15, 1u << 16, 1u << 17}) {  // 64 KiB .. 512 KiB per workgroup
+        for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = 0; }
         hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
         for (int wg_per_cu : {1, 2}) {
             for (int threads : {512, 1024}) {
-                for (int active : {8, 16, 32, 64}) {
-                    for (int mode = 0; mode < 3; mode++) {
-                        const int iters = 2000, grid = n_cu * wg_per_cu;
+                for (int active : {8, 32, 64}) {
+                    for (int mode = 0; mode < 2; mode++) {
+                        const int iters = 1000, grid = n_cu * wg_per_cu;
                         hipMemset(cyc, 0, 8);
                         // warm-up brings the regions into L2 / MALL
                         if (mode == 0) k_gather<0><<<grid, threads>>>(d, region, active, 50, out, cyc);
@@ -92,8 +95,8 @@ int main() {
                         hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
                         const double per_wg = (double)c / grid;  // cycles of one workgroup's loop
                         const double lane_loads_per_cu = (double)iters * active * (threads / 64) * wg_per_cu;
-                        printf("region %4u KiB  wg/cu %d  threads %4d  active %2d  %2d B: %7.0f cyc per dependent load (latency), %5.2f cyc per lane-load per CU, %.3f ms\n",
-                               region / 256, wg_per_cu, threads, active, 4 << mode, per_wg / iters, per_wg / lane_loads_per_cu * wg_per_cu / wg_per_cu * 1.0, ms);
+                        printf("total %4u MiB  region %4u KiB  wg/cu %d  threads %4d  active %2d  %2d B: %7.0f cyc per dependent load (latency), %5.2f cyc per lane-load per CU, %.3f ms\n",
+                               (unsigned)((size_t)region * 4 * grid >> 20), region / 256, wg_per_cu, threads, active, mode == 0 ? 2 : 8, per_wg / iters, per_wg / lane_loads_per_cu * wg_per_cu / wg_per_cu * 1.0, ms);
                     }
                 }
             }

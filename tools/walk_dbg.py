@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Debug: one input through compress with the WK_PROF build, counters of k_lz_walk printed.
+usage: FLATE_HIP_LIB=flate_amd/lib/var/lib_wkprof.so python tools/walk_dbg.py level name [size]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import _oracle as O
+from flate_amd import default_engine
+eng = default_engine()
+level = int(sys.argv[1]); name = sys.argv[2]; n = int(sys.argv[3]) if len(sys.argv) > 3 else 65535
+data = {"x_then_zeros": b"x" + bytes(n - 1), "zeros_then_x": bytes(n - 1) + b"x", "zeros_x_zeros": bytes(n // 2) + b"x" + bytes(n - n // 2 - 1)}[name]
+t0 = eng.phase_cycles().astype(np.int64)
+print("level %d %s %d bytes ..." % (level, name, n), end="", flush=True)
+t = time.time()
+outs, st = eng.compress_many([data], O.RAW, level)
+dt = time.time() - t
+c = eng.phase_cycles().astype(np.int64) - t0
+ok = st == [0] and outs[0] == O.compress(data, O.RAW, level)
+print(" %.1f ms %s  waves %d trips/wave %.0f rounds %d trip-cap hits %d round-cap hits %d" % (dt * 1e3, "ok" if ok else "MISMATCH", c[42], c[40] / max(c[42], 1), c[43], c[45], c[46]), flush=True)
