@@ -649,6 +649,81 @@ def other_workloads(args, torch, eng, device):
                      "sampled_chunks_equal_oracle": ok}
         del job, d
     res.update(one_stream_inflate(args, torch, eng, device))
+    res.update(baseline_configs(args, torch, eng, device))
+    return res
+
+
+def _frac(n_bytes, ms):
+    return round(n_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None
+
+
+def _dominant(prof, steps):
+    if not prof:
+        return "none", 0.0
+    k, v = max(prof.items(), key=lambda kv: kv[1][0])
+    return k, v[0] / steps
+
+
+def baseline_configs(args, torch, eng, device):
+    """BASELINE.json configs[2], [3], [4] at their single-GPU sizes, and level 9 on the run-heavy inputs, in the same
+    run as the headline: each with its time, its dominant kernel and that kernel's fraction of the HBM roofline
+    (algorithmic bytes = bytes in + bytes out)."""
+    import numpy as np
+    from flate_amd import synth
+    res = {}
+
+    def compress_case(name, data, chunk, container, mode, steps=2, sample=2):
+        job = CompressJob(torch, eng, data, chunk, container, mode)
+        dt, prof = timed(torch, None, eng, job.step, steps, 1, 1)
+        lens = job.results()
+        n, n_out = data.numel(), int(lens.sum())
+        ok = None
+        if not args.no_verify:
+            verify_sample(argparse.Namespace(container=container, mode=mode), data, job.off_np, job.out, job.out_off_np, lens, sample)
+            ok = True
+        ms = dt / steps * 1e3
+        k, kms = _dominant(prof, steps)
+        res[name] = {"MBps": round(n / ms / 1e3, 1), "ms": round(ms, 3), "ratio": round(n_out / n, 4), "kernel": k,
+                     "kernel_ms": round(kms, 3), "roofline_frac": _frac(n + n_out, kms),
+                     "kernels_ms": {kk: round(v[0] / steps, 3) for kk, v in sorted(prof.items())},
+                     "sampled_chunks_equal_oracle": ok}
+        return job, lens
+
+    # configs[2]: gzip level 9 of the TAR-like buffer (177,244,160 bytes: the size of the reference's ziglang.tar), 65535-byte members
+    tar = torch.from_numpy(synth.tar_like(synth.SEED_TAR, synth.TAR_BYTES)).to(device)
+    compress_case("config3_gzip_l9_tar", tar, CHUNK, 1, 9)
+    del tar
+    # configs[3]: huffman-only, one 128 MiB buffer = one stream (per GPU), and its inflate
+    sil = torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA, 128 << 20)).to(device)
+    job, lens = compress_case("config4_huffman_only_128MiB_stream", sil, 128 << 20, 1, 1, steps=3, sample=1)
+    del job
+    # configs[4]: gunzip of 128 members of 1 MiB (per GPU)
+    mk = CompressJob(torch, eng, sil, 1 << 20, 1, 6)
+    mk.step()
+    torch.cuda.synchronize()
+    lens = mk.results()
+    comp, comp_off, n_comp = mk.packed(lens)
+    inf = InflateJob(torch, eng, comp, comp_off, mk.n_chunks, mk.in_off, sil.numel(), 1)
+    dt, prof = timed(torch, None, eng, inf.step, 3, 1, 1)
+    ok = int(inf.dec_st.abs().sum().item()) == 0 and bool(torch.equal(inf.dec[:sil.numel()], sil))
+    assert ok or args.no_verify, "config 5: gunzip output != input"
+    ms = dt / 3 * 1e3
+    k, kms = _dominant(prof, 3)
+    res["config5_gunzip_128x1MiB_members"] = {"MBps": round(sil.numel() / ms / 1e3, 1), "ms": round(ms, 3), "kernel": k,
+                                              "kernel_ms": round(kms, 3), "roofline_frac": _frac(sil.numel() + n_comp, kms),
+                                              "kernels_ms": {kk: round(v[0] / 3, 3) for kk, v in sorted(prof.items())},
+                                              "output_equals_input": ok}
+    del mk, inf, comp, sil
+    # level 9 on the inputs whose chains are long: binary records, sparse zeros (64 MiB each, 65535-byte chunks)
+    n = 64 << 20
+    z = np.zeros(n, dtype=np.uint8)
+    k_ = n // 97 + 1
+    where = (synth.splitmix64(4242, k_) % np.uint64(n)).astype(np.int64)
+    z[where] = (synth.splitmix64(4243, k_) & np.uint64(0xFF)).astype(np.uint8)
+    for name, arr in (("level9_records_64MiB", synth._records(4242, n)), ("level9_sparse_zeros_64MiB", z)):
+        d = torch.from_numpy(arr).to(device)
+        compress_case(name, d, CHUNK, 0, 9, steps=1, sample=2)
+        del d
     return res
 
 

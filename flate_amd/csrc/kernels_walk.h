@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #ifndef WK_PROBE
 #define WK_PROBE 8u       // steps on L6 / L8 between two looks at the budget
 #endif
+#ifndef WK_RUNSKIP
+#define WK_RUNSKIP 512u   // bytes of a run skipped per trip, at most
+#endif
 #ifndef WK_MINWALK
 #define WK_MINWALK 8u     // ... fewer when fewer lanes than this still walk
 #endif
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
     }
     const uint16_t* lk = lnk + (uint64_t)c * (4u * FL_CHUNK_STRIDE);  // level K: lk[(K << 16) + position]; RK: lk[(3 << 16) + position]
 #ifdef WK_PROF
-    uint32_t c_iter = 0, c_gath = 0, c_judge = 0, c_meas = 0, c_move = 0, c_rank = 0;
+    uint32_t c_iter = 0, c_gath = 0, c_judge = 0, c_meas = 0, c_move = 0, c_rank = 0, c_runs = 0;
     const uint64_t c_t0 = __builtin_readcyclecounter();
 #endif
     // ---- the chunk's bytes, zero padded
@@ -389,13 +392,66 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         uint64_t amask = 0;
         uint32_t j = 0, plen = 0, pdist = 0;
         // the call in progress: position p, best = match in hand (bdist its distance, 0: none accepted in this call),
-        // K = level walked, q = the candidate in hand, last = every candidate from here up has been looked at
+        // K = level walked, q = the chain member in hand (the candidate is q - off), last = every candidate from here up
+        // has been looked at
         uint32_t p = 0, best = 0, bdist = 0, maxlen = 0, lo = 1, last = 0, K = WK_L4, cnt = 0, budget = 0, q = 0, pref = 0, fo = 0;
-        uint32_t pend_l = 0;  // a candidate q of L6 / L8 that would be accepted waits for RK[p], RK[q]: is it within the budget?
+        uint32_t off = 0;     // OFFSET MODE (L8 only): the walk follows the chain of p + off, off = best - 7 -- its members, moved
+                              // back by off, share with p the LAST 8 of the best + 1 bytes a better candidate must share (records,
+                              // markup: the first 8 are shared by thousands); the filter then looks at the first four bytes
+        uint32_t prun = 0;    // bytes equal to the first from p on (capped at maxlen), if at least 4, else 0
+        uint32_t pend_l = 0;  // length of a candidate of L6 / L8 that waits for the ranks (0: a probe; bit 31: a target inside a run)
         // what a lane waits for: MOVE the automaton's next move (between calls), WALK the link in flight = its next
-        // candidate, MEAS the exact length of candidate q (it passed the filter), RANK the two ranks in flight
-        enum { CS_MOVE = 0, CS_WALK = 1, CS_MEAS = 2, CS_RANK = 3, CS_IDLE = 4 };
+        // candidate, MEAS the exact length of the candidate in hand, RANK the two ranks in flight, RUN the candidate
+        // lies, like p, in a run of one repeated byte
+        enum { CS_MOVE = 0, CS_WALK = 1, CS_MEAS = 2, CS_RANK = 3, CS_IDLE = 4, CS_RUN = 5 };
         uint32_t g_link = 0, g_rp = 0, g_rq = 0;  // values of the gathers in flight
+        const uint32_t RUNT = 0x80000000u;
+        auto allsame8 = [&](uint32_t x, uint32_t& pat) {  // the 8 bytes at x are one repeated byte (pat = that byte, four times)
+            uint32_t w0, w1;
+            fl_lds_load8(win32, x, w0, w1);
+            pat = (w0 & 0xffu) * 0x01010101u;
+            return w0 == pat && w1 == pat;
+        };
+        auto offset_of = [&](uint32_t len) -> uint32_t {
+            if (len < 8u || prun != 0) return 0u;
+            uint32_t pat;
+            return allsame8(p + len - 7u, pat) ? 0u : len - 7u;  // (a chain of run positions is the worst there is)
+        };
+        auto measure = [&](uint32_t cand) -> uint32_t {  // exact common prefix of cand and p, capped at maxlen
+            uint32_t l = 0;
+            for (;;) {
+                WK_CNT(c_meas, 1);
+                uint32_t a0, a1, b0, b1;
+                fl_lds_load8(win32, p + l, a0, a1);
+                fl_lds_load8(win32, cand + l, b0, b1);
+                const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                if (x) {
+                    l += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                l += 8;
+                if (l >= maxlen) break;
+            }
+            return min(l, maxlen);
+        };
+        // bytes equal to pattern `bp` right below position `from`, counted down to `floor` at most: the lowest position t >= floor
+        // with [t, from) all that byte
+        auto scan_down = [&](uint32_t from, uint32_t floor, uint32_t bp) -> uint32_t {
+            uint32_t t = from;
+            while (t > floor) {
+                const uint32_t step = min(8u, t - floor);
+                uint32_t w0, w1;
+                fl_lds_load8(win32, t - step, w0, w1);  // bytes t - step .. t - step + 7: the first `step` of them count
+                uint64_t x = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                if (step < 8u) x &= (1ull << (8u * step)) - 1ull;
+                if (x) {
+                    t -= (uint32_t)(__builtin_clzll(x) - (64 - 8 * (int)step)) >> 3;  // the equal bytes right below t
+                    break;
+                }
+                t -= step;
+            }
+            return t;
+        };
         // a parse that starts on a position where it has to stop already (FIX only)
         if (st == ST_FIX && ((stopmask >> ((a - seg0) & 63u)) & 1ull)) {
             F = 0;
@@ -408,9 +464,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         bool first_call = true;  // the next move is the first call of the parse (at a, nothing pending)
         // Lanes do the same thing at the same time: a wave's trip through this loop is (M) the automaton's move for the
         // lanes between calls, (W) up to WK_BURST chain steps for the lanes that walk -- a step is the arrival of a
-        // link, the bounds, the four-byte filter, the request of the next link --, (J) the exact length of the
-        // candidates that passed the filter and what follows from it.  (One loop with every lane's case in every trip
-        // cost 2.2 M vector instructions per chunk: 27.5 ms per GiB.)
+        // link, the bounds, the four-byte filter, the request of the next link --, (R) runs, (J) the exact length of the
+        // candidates that passed the filter and what follows from it.
         for (;;) {
             const uint64_t alive = __ballot(cs != CS_IDLE);
             if (alive == 0) break;
@@ -524,12 +579,35 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                     K = sl < 5u ? WK_L4 : (sl < 7u ? WK_L6 : WK_L8);
                     cnt = K == WK_L4 ? budget : WK_PROBE;
                     last = p;
-                    fo = sl ? sl - 3u : 0u;
+                    prun = 0;
+                    off = 0;
                     cs = CS_MOVE;  // (no hash entry / nothing longer is possible: the call finds nothing)
                     if (p < Mpos && maxlen > sl) {
+                        uint32_t w0, w1;
+                        fl_lds_load8(win32, p, w0, w1);
+                        const uint32_t bp = (w0 & 0xffu) * 0x01010101u;
+                        if (w0 == bp) {  // p starts with four equal bytes: a run of how many?
+                            uint32_t r = 4;
+                            {
+                                const uint32_t x = w1 ^ bp;
+                                r += x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+                            }
+                            while (r >= 8u && r < maxlen) {  // (r < 8: the run has ended; else r is a multiple of 8 here)
+                                fl_lds_load8(win32, p + r, w0, w1);
+                                const uint64_t x = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                                if (x) {
+                                    r += (uint32_t)__builtin_ctzll(x) >> 3;
+                                    break;
+                                }
+                                r += 8;
+                            }
+                            prun = min(r, maxlen);
+                        }
+                        off = offset_of(sl);
+                        fo = off ? 0u : (sl ? sl - 3u : 0u);
                         pref = pz_lds4(win32, p + fo);
                         WK_CNT(c_gath, 1);
-                        g_link = lk[(K << 16) + p];  // the top of the chain is the position's own link
+                        g_link = lk[(K << 16) + p + off];  // the top of the chain is the position's own link
                         cs = CS_WALK;
                     }
                 }
@@ -543,92 +621,179 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                 if (cs == CS_WALK) {
                     WK_CNT(c_judge, 1);
                     q = g_link;
-                    if (q < lo || (K == WK_L4 && cnt == 0)) {
+                    if (q < lo + off || (K == WK_L4 && cnt == 0)) {
                         cs = CS_MOVE;  // the call has ended
                     } else {
-                        bool pass = false;
-                        if (q < last) {  // (else: looked at before the walk changed chains)
+                        const uint32_t qc = q - off;
+                        bool next = true;  // the walk goes on with the link of q
+                        if (qc < last) {   // (else: looked at before the walk changed chains)
                             if (cnt) cnt--;
-                            if (K == WK_L4) last = q;
-                            pass = pz_lds4(win32, q + fo) == pref;
+                            if (K == WK_L4) last = qc;
+                            uint32_t pat;
+                            if (prun != 0 && allsame8(qc, pat) && pat == (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u) {
+                                cs = CS_RUN;
+                                next = false;
+                            } else if (pz_lds4(win32, qc + fo) == pref) {
+                                cs = CS_MEAS;
+                                next = false;
+                            } else if (K != WK_L4 && cnt == 0 && pz_lds4(win32, qc) == pz_lds4(win32, p)) {
+                                // A walk on L6 / L8 is not counted down, and one that finds nothing better would go on to the
+                                // end of the window.  Every WK_PROBE steps a candidate of p's own L4 bucket (same first four
+                                // bytes) is asked for its rank: beyond the budget ends the call.
+                                WK_CNT(c_gath, 2);
+                                pend_l = 0;
+                                g_rp = lk[(3u << 16) + p];
+                                g_rq = lk[(3u << 16) + qc];
+                                cs = CS_RANK;
+                                next = false;
+                            }
                         }
-                        if (pass) {
-                            cs = CS_MEAS;
-                        } else if (K != WK_L4 && cnt == 0 && pz_lds4(win32, q) == pz_lds4(win32, p)) {
-                            // A walk on L6 / L8 is not counted down, and one that finds nothing better would go on to the
-                            // end of the window (runs: thousands of candidates).  Every WK_PROBE steps a candidate of p's
-                            // own L4 bucket (same first four bytes) is asked for its rank: beyond the budget ends the call.
-                            WK_CNT(c_gath, 2);
-                            pend_l = 0;
-                            g_rp = lk[(3u << 16) + p];
-                            g_rq = lk[(3u << 16) + q];
-                            cs = CS_RANK;
-                        } else {
+                        if (next) {
                             WK_CNT(c_gath, 1);
                             g_link = lk[(K << 16) + q];
                         }
                     }
                 }
             }
-            // ---- (J) candidates that passed the filter; ranks that have arrived
+            // ---- (R) runs of one repeated byte (zero padding, sparse data): the reference's own worst case.  p starts with
+            // r = prun bytes b, then another byte (or the end of what can match); the candidate q (off = 0) starts with 8
+            // bytes b and lies in a run [s, E).  A position q' of that run matches p over min(r, E - q') bytes, more only at
+            // q* = E - r, where the match may go on behind the runs.  With c bytes in hand the walk would take, one after
+            // the other, every q' from min(q, max(E - c - 1, q*)) down to max(s, q*) -- each a byte longer than the last --
+            // and nothing else of the run.  So it goes to the LAST of them at once (the first that reaches `nice`, or where
+            // the budget or the distance ends, if that comes before), looks at that one as at any candidate, and below it
+            // skips what is left of the run, WK_RUNSKIP bytes per trip at most.  Everything skipped lies in p's bucket and
+            // counts against the budget as if it had been looked at; on L6 / L8 the ranks say where the budget ends.
+            // CPU model of exactly this, checked against the oracle on run-heavy inputs: tools/multilevel_model.c.
+            if (cs == CS_RUN) {
+                WK_CNT(c_runs, 1);
+                const uint32_t bp = (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u;
+                const uint32_t c = best, r = prun, cap = max(c, r) + 1u;
+                uint32_t d = 8;  // bytes b from q on, counted up to cap + 1
+                while (d <= cap) {
+                    uint32_t w0, w1;
+                    fl_lds_load8(win32, q + d, w0, w1);
+                    const uint64_t x = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                    if (x) {
+                        d += (uint32_t)__builtin_ctzll(x) >> 3;
+                        break;
+                    }
+                    d += 8;
+                }
+                int32_t target = -1, hi = -1;
+                if (d <= cap) {  // the run ends at E = q + d
+                    const int32_t E = (int32_t)(q + d), qstar = E - (int32_t)r;
+                    hi = max(E - (int32_t)c - 1, qstar);
+                    hi = min(hi, (int32_t)q);
+                    if (qstar <= hi) {
+                        const uint32_t lo_u = scan_down(q, (uint32_t)max(qstar, 0), bp);  // max(s, q*)
+                        if (hi >= (int32_t)lo_u) target = max((int32_t)lo_u, min(hi, E - (int32_t)nice));
+                    }
+                }
+                // (below q* every position matches exactly r bytes: the first one met helps if less than that is in hand)
+                if (target < 0 && c < r && d > r) {
+                    target = (int32_t)q;
+                    hi = (int32_t)q;
+                }
+                if (target < 0) {
+                    // nothing here can help: on below what is known to be run; what is skipped counts as looked at
+                    const uint32_t t = scan_down(q, q > WK_RUNSKIP ? q - WK_RUNSKIP : 0u, bp);
+                    cs = CS_WALK;
+                    if (K == WK_L4) {
+                        const uint32_t need = q - t;
+                        if (cnt < need) cs = CS_MOVE;
+                        cnt -= min(cnt, need);
+                        last = t;
+                    } else {
+                        cnt = 0;  // (the next candidate of p's bucket is asked for its rank)
+                    }
+                    if (cs == CS_WALK) {
+                        q = t;
+                        WK_CNT(c_gath, 1);
+                        g_link = lk[(K << 16) + t];
+                    }
+                } else {
+                    if (target < (int32_t)lo) target = (int32_t)lo;  // (beyond the distance nothing is looked at)
+                    if (K == WK_L4) {
+                        if (cnt < q - (uint32_t)target) target = (int32_t)(q - cnt);
+                        cnt -= q - (uint32_t)target;
+                    }
+                    if (target > hi) {
+                        cs = CS_MOVE;  // budget / distance end among positions that cannot help
+                    } else {
+                        if (K == WK_L4) last = (uint32_t)target; else cnt = 0;
+                        q = (uint32_t)target;
+                        g_link = (uint32_t)hi;  // (kept for the case that the budget ends inside the run)
+                        pend_l = RUNT;
+                        cs = CS_MEAS;
+                    }
+                }
+            }
+            // ---- (J) the exact length of the candidates in hand; ranks that have arrived
             if (cs == CS_RANK || cs == CS_MEAS) {
+                const uint32_t qc = q - off;
                 bool accept = false;
-                uint32_t l = pend_l;
+                uint32_t l = pend_l & ~RUNT;
                 if (cs == CS_RANK) {
                     WK_CNT(c_rank, 1);
+                    const uint32_t dt = g_rp - g_rq;
                     cs = CS_WALK;
                     cnt = WK_PROBE;
-                    if (g_rp - g_rq > budget)
-                        cs = CS_MOVE;  // beyond what the reference looks at, and so is everything behind it
-                    else
+                    if (dt <= budget) {
                         accept = l != 0;  // (0: a probe)
-                } else {
-                    // the candidate agrees where it must: its exact common prefix with p
-                    l = 0;
-                    for (;;) {
-                        WK_CNT(c_meas, 1);
-                        uint32_t a0, a1, b0, b1;
-                        fl_lds_load8(win32, p + l, a0, a1);
-                        fl_lds_load8(win32, q + l, b0, b1);
-                        const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
-                        if (x) {
-                            l += (uint32_t)__builtin_ctzll(x) >> 3;
-                            break;
+                    } else {
+                        cs = CS_MOVE;  // beyond what the reference looks at, and so is everything behind it
+                        if (pend_l & RUNT) {
+                            // ... but the budget ends inside this run (its members have consecutive ranks): the last one within
+                            // it is the one the reference ends on
+                            const uint32_t t2 = qc + (dt - budget);
+                            if (t2 <= g_link) {
+                                const uint32_t l2 = measure(t2);
+                                if (l2 > best) {
+                                    best = l2;
+                                    bdist = p - t2;
+                                }
+                            }
                         }
-                        l += 8;
-                        if (l >= maxlen) break;
                     }
-                    l = min(l, maxlen);
+                    pend_l = 0;
+                } else {
+                    const bool runt = (pend_l & RUNT) != 0;
+                    l = measure(qc);
                     if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
                         if (K == WK_L4) {
                             accept = true;
+                            pend_l = 0;
                         } else {
-                            pend_l = l;
+                            pend_l = l | (runt ? RUNT : 0u);
                             WK_CNT(c_gath, 2);
                             g_rp = lk[(3u << 16) + p];
-                            g_rq = lk[(3u << 16) + q];
+                            g_rq = lk[(3u << 16) + qc];
                             cs = CS_RANK;
                         }
                     } else {
+                        pend_l = 0;
                         cs = CS_WALK;  // the walk goes on behind the candidate
                     }
                 }
                 if (accept) {
                     best = l;
-                    bdist = p - q;
-                    last = q;
+                    bdist = p - qc;
+                    last = qc;
                     cs = CS_WALK;
                     if (l >= nice || l >= maxlen) {
                         cs = CS_MOVE;  // good enough / nothing longer is possible
                     } else {
-                        fo = l - 3u;
-                        pref = pz_lds4(win32, p + fo);
                         const uint32_t K2 = l < 5u ? WK_L4 : (l < 7u ? WK_L6 : WK_L8);
-                        if (K2 != K) {  // on to a sparser chain, from its top (what is done is skipped there)
+                        const uint32_t off2 = offset_of(l);
+                        if (K2 != K || off2 != off) {  // on to another chain, from its top (what is done is skipped there)
                             K = K2;
-                            q = p;
-                            cnt = WK_PROBE;
+                            off = off2;
+                            q = p + off;
+                            if (K != WK_L4) cnt = WK_PROBE;
                         }
+                        fo = off ? 0u : l - 3u;
+                        pref = pz_lds4(win32, p + fo);
                     }
                 }
                 if (cs == CS_WALK) {
@@ -657,7 +822,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         atomicAdd((unsigned long long*)&g_fl_prof[40], (unsigned long long)c_iter);
         atomicAdd((unsigned long long*)&g_fl_prof[41], (unsigned long long)(__builtin_readcyclecounter() - c_t0));
         atomicAdd((unsigned long long*)&g_fl_prof[42], 1ull);
+        atomicAdd((unsigned long long*)&g_fl_prof[47], (unsigned long long)c_runs);
+        atomicAdd((unsigned long long*)&g_fl_prof[48], (unsigned long long)c_meas);
+        atomicAdd((unsigned long long*)&g_fl_prof[49], (unsigned long long)c_judge);
+        atomicAdd((unsigned long long*)&g_fl_prof[50], (unsigned long long)c_move);
+        atomicMax((unsigned long long*)&g_fl_prof[51], (unsigned long long)c_iter);
     }
-    (void)c_gath; (void)c_judge; (void)c_meas; (void)c_move; (void)c_rank;
+    (void)c_gath; (void)c_rank;
 #endif
 }

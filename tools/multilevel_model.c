@@ -15,7 +15,7 @@
 #include <stdio.h>
 
 static uint8_t buf[65536 + 600];
-static uint16_t L4[65536], RK[65536], L6[65536], L8[65536];
+static uint16_t L4[65536], RK[65536], L6[65536], L8[65536], RS[65536];
 static int N, Mpos, good, lazy, nice, chainmax, offset_mode;
 static unsigned long long n_calls, n_top, n_step[3], n_skip, n_meas, n_rank, n_iter;
 
@@ -34,15 +34,25 @@ static void build_links(void) {
     }
     memset(head, 0, sizeof head);
     for (int p = 0; p < N; p++) { if (p < Mpos) { const uint32_t h = hash6(buf + p); L6[p] = head[h]; head[h] = (uint16_t)p; } else L6[p] = 0; }
+    for (int p = 0; p < N; p++) RS[p] = (p && buf[p - 1] == buf[p]) ? RS[p - 1] : (uint16_t)p;  // start of the run of equal bytes p lies in
     memset(head, 0, sizeof head);
     for (int p = 0; p < N; p++) { if (p < Mpos) { const uint32_t h = hash8(buf + p); L8[p] = head[h]; head[h] = (uint16_t)p; } else L8[p] = 0; }
 }
 static int lcp(int q, int p, int maxlen) { int i = 0; while (i < maxlen && buf[q + i] == buf[p + i]) i++; return i; }
+static int all_b(int q, int n, uint8_t b) { for (int i = 0; i < n; i++) if (buf[q + i] != b) return 0; return 1; }
 #define PROBE 8
+// offset mode: with a match of at least offset_mode bytes in hand (and p not at a run) the walk follows the chain of p + off,
+// off = len + 1 - 8: its members, moved back by off, are the positions that share the LAST 8 of the len + 1 bytes a better candidate must share
+#define OFFSET_OF(LEN) ((offset_mode && (LEN) >= offset_mode && (LEN) >= 7 && !prun && !all_b(p + (LEN) + 1 - 8, 8, buf[p + (LEN) + 1 - 8])) ? (LEN) + 1 - 8 : 0)
+#define RUNSKIP 512
+static int run_skip = 1;
+static unsigned long long n_runskip;
+
 static int level_of(int len) { return len < 5 ? 4 : (len < 7 ? 6 : 8); }
 
 // deflate.zig:233-266 with the sparser chains; returns len (0 = none)
-static int find_match(int p, int len0, int* dist) {
+static const uint16_t* chain_of(int K) { return K == 4 ? L4 : K == 6 ? L6 : L8; }
+static int find_match_impl(int p, int len0, int* dist) {
     n_calls++;
     if (p >= Mpos) return 0;
     const int maxlen = N - p < 258 ? N - p : 258;
@@ -50,44 +60,111 @@ static int find_match(int p, int len0, int* dist) {
     const int B = len0 >= good ? chainmax >> 2 : chainmax;
     const int lo = p > 32768 ? p - 32768 : 1;
     int len = len0, found = 0, last = p, K = level_of(len0), cnt = B, off = 0, probe = PROBE;
-    for (;;) {  // one level (and, in offset mode, one offset) per trip
-        off = (offset_mode && K > 4) ? len + 1 - K : 0;
-        probe = PROBE;
-        n_top++; n_iter++;
-        int q = (K == 4 ? L4 : K == 6 ? L6 : L8)[p + off];
-        int switched = 0;
-        for (;;) {
-            if (q < lo + off) break;
-            if (K == 4 && cnt == 0) break;
-            n_iter++;
-            const int qc = q - off;  // the candidate
-            if (qc >= last) n_skip++;
-            else {
-                n_step[K == 4 ? 0 : K == 6 ? 1 : 2]++;
-                if (K != 4 && probe) probe--;
-                const int fo = off ? 0 : (len ? len - 3 : 0);  // filter: four bytes the candidate must share
-                if (ld32(buf + qc + fo) == ld32(buf + p + fo)) {
-                    n_meas++;
-                    const int l = lcp(qc, p, maxlen);
-                    if (l >= 4 && l > len) {
-                        if (K != 4) { n_rank++; n_iter++; if ((int)RK[p] - (int)RK[qc] > B) return found; }
-                        found = l; *dist = p - qc; len = l; last = qc;
-                        if (l >= nice || l >= maxlen) return found;
-                        if (level_of(len) != K || off != ((offset_mode && K > 4) ? len + 1 - K : 0)) { K = level_of(len); switched = 1; break; }
-                    }
+    int prun = 0;  // bytes equal to the first from p on (capped at maxlen) if at least 4
+    if (run_skip && maxlen >= 8) { int r = 1; while (r < maxlen && buf[p + r] == buf[p]) r++; if (r >= 4) prun = r; }
+    off = OFFSET_OF(len);
+    n_top++; n_iter++;
+    int q = chain_of(K)[p + off];
+    for (;;) {
+        if (q < lo + off) return found;
+        if (K == 4 && cnt == 0) return found;
+        n_iter++;
+        const int qc = q - off;  // the candidate
+        if (qc >= last) { n_skip++; q = chain_of(K)[q]; continue; }  // looked at before the walk changed chains
+        n_step[K == 4 ? 0 : K == 6 ? 1 : 2]++;
+        if (K == 4) { cnt--; last = qc; } else if (probe) probe--;
+        int accept_l = 0, acc = -1;   // candidate to accept (after the rank check on L6 / L8)
+        int next_from = qc;           // the walk goes on with the link of this chain member
+        if (prun && !off && all_b(qc, 8, buf[p])) {
+            // ---- a run of p's byte b: [s, E) with qc inside.  q' in it matches p over min(prun, E - q') bytes (more only at
+            // q* = E - prun), so with c bytes in hand the only positions that can help are U = [max(s, q*), min(qc, max(E - c - 1, q*))]:
+            // the walk would take every one of them in turn, each a byte longer than the last; it ends up at the lowest one
+            // (or at the first that reaches `nice`), unless the budget or the distance ends it before.
+            n_runskip++; n_iter++;
+            const uint8_t bb = buf[p];
+            const int c = len, r = prun, cap = (c > r ? c : r) + 1;
+            int d = 8; while (d <= cap && buf[qc + d] == bb) d++;   // bytes b from qc on, counted up to cap + 1
+            const int s0 = RS[qc];
+            int target = -1, hi = -1;
+            if (d <= cap) {
+                const int E = qc + d;
+                hi = E - c - 1 > E - r ? E - c - 1 : E - r;  // (q* = E - r itself may go on behind the runs: always worth a look)
+                if (hi > qc) hi = qc;
+                const int lo_u = s0 > E - r ? s0 : E - r;
+                if (hi >= lo_u) {
+                    target = hi < E - nice ? hi : E - nice;
+                    if (target < lo_u) target = lo_u;
                 }
-                else if (K != 4 && probe == 0 && ld32(buf + qc) == ld32(buf + p)) {
-                    // a walk on L6 / L8 is not counted down: every PROBE steps a candidate of p's own bucket is asked for its rank
-                    n_rank++; n_iter++; probe = PROBE;
-                    if ((int)RK[p] - (int)RK[qc] > B) return found;
-                }
-                if (K == 4) last = qc;
             }
-            if (K == 4) cnt--;
-            q = (K == 4 ? L4 : K == 6 ? L6 : L8)[q];
+            // (below q* every position matches exactly prun bytes: the first one met helps if less than that is in hand)
+            if (target < 0 && len < prun && d > prun) { target = qc; hi = qc; }
+            if (target < 0) {
+                // nothing in this run can help: on below its start; what is skipped counts as looked at
+                if (K == 4) { const int need = qc - s0; if (cnt < need) return found; cnt -= need; last = s0; } else probe = 0;
+                next_from = s0;
+            } else {
+                if (target < lo) target = lo;            // (beyond the distance nothing is looked at)
+                if (K == 4) { if (cnt < qc - target) target = qc - cnt; cnt -= qc - target; }
+                if (target > hi) return found;           // budget / distance end among positions that cannot help
+                if (K == 4) last = target; else probe = 0;
+                n_meas++;
+                const int l = lcp(target, p, maxlen);
+                if (l > len) { accept_l = l; acc = target; }
+                next_from = target;
+                if (K != 4 && l > len) {
+                    n_rank++; n_iter++;
+                    const int dt = (int)RK[p] - (int)RK[target];
+                    if (dt > B) {
+                        // the budget ends inside the run (its members have consecutive ranks): the last one within it
+                        const int t2 = target + (dt - B);
+                        if (t2 > hi) return found;
+                        n_meas++;
+                        const int l2 = lcp(t2, p, maxlen);
+                        if (l2 > len) { found = l2; *dist = p - t2; }
+                        return found;
+                    }
+                    found = l; *dist = p - target; len = l; last = target;
+                    if (l >= nice || l >= maxlen) return found;
+                    accept_l = 0;  // (done here)
+                    if (level_of(len) != K || OFFSET_OF(len) != off) { K = level_of(len); off = OFFSET_OF(len); probe = PROBE; n_top++; n_iter++; q = chain_of(K)[p + off]; continue; }
+                }
+            }
+        } else {
+            const int fo = off ? 0 : (len ? len - 3 : 0);  // filter: four bytes the candidate must share
+            if (ld32(buf + qc + fo) == ld32(buf + p + fo)) {
+                n_meas++;
+                const int l = lcp(qc, p, maxlen);
+                if (l >= 4 && l > len) { accept_l = l; acc = qc; }
+            } else if (K != 4 && probe == 0 && ld32(buf + qc) == ld32(buf + p)) {
+                // a walk on L6 / L8 is not counted down: every PROBE steps a candidate of p's own bucket is asked for its rank
+                n_rank++; n_iter++; probe = PROBE;
+                if ((int)RK[p] - (int)RK[qc] > B) return found;
+            }
         }
-        if (!switched) return found;
+        if (accept_l) {
+            if (K != 4) { n_rank++; n_iter++; probe = PROBE; if ((int)RK[p] - (int)RK[acc] > B) return found; }
+            found = accept_l; *dist = p - acc; len = accept_l; last = acc;
+            if (len >= nice || len >= maxlen) return found;
+            if (level_of(len) != K || OFFSET_OF(len) != off) { K = level_of(len); off = OFFSET_OF(len); probe = PROBE; n_top++; n_iter++; q = chain_of(K)[p + off]; continue; }
+        }
+        q = chain_of(K)[next_from + off];
     }
+}
+
+static int dbg_compare;
+static int find_match(int p, int len0, int* dist) {
+    if (!dbg_compare) return find_match_impl(p, len0, dist);
+    int d0 = 0, d1 = 0;
+    const int rs = run_skip;
+    run_skip = 0; const int l0 = find_match_impl(p, len0, &d0);
+    run_skip = rs; const int l1 = find_match_impl(p, len0, &d1);
+    if (l0 != l1 || (l0 && d0 != d1)) {
+        int r = 1; while (r < 258 && buf[p + r] == buf[p]) r++;
+        printf("call p=%d len0=%d: plain (%d,%d) run-skip (%d,%d)  prun %d byte %02x N %d\n", p, len0, l0, d0, l1, d1, r, buf[p], N);
+        dbg_compare = 2;
+    }
+    *dist = d0;
+    return l0;
 }
 
 int main(int argc, char** argv) {
@@ -97,6 +174,8 @@ int main(int argc, char** argv) {
     const int nchunks = argc > 3 ? atoi(argv[3]) : 64;
     const size_t chunk = argc > 4 ? (size_t)atol(argv[4]) : 65535;
     offset_mode = argc > 5 ? atoi(argv[5]) : 0;
+    run_skip = argc > 6 ? atoi(argv[6]) : 1;
+    dbg_compare = argc > 7 ? atoi(argv[7]) : 0;
     const level_args_t la = level_args(level);
     good = la.good; lazy = la.lazy; nice = la.nice; chainmax = la.chain;
     static uint32_t toks[65536 + 16], mine[65536 + 16];
@@ -137,5 +216,6 @@ int main(int argc, char** argv) {
     printf("per byte: calls %.3f  tops %.3f  steps L4 %.3f L6 %.3f L8 %.3f  skipped %.3f  measures %.3f  rank checks %.3f  gather rounds %.3f\n",
            (double)n_calls / total, (double)n_top / total, (double)n_step[0] / total, (double)n_step[1] / total, (double)n_step[2] / total,
            (double)n_skip / total, (double)n_meas / total, (double)n_rank / total, (double)n_iter / total);
+    printf("run skips %.4f/B\n", (double)n_runskip / total);
     return bad != 0;
 }

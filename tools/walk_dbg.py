@@ -9,7 +9,11 @@ import _oracle as O
 from flate_amd import default_engine
 eng = default_engine()
 level = int(sys.argv[1]); name = sys.argv[2]; n = int(sys.argv[3]) if len(sys.argv) > 3 else 65535
-data = {"x_then_zeros": b"x" + bytes(n - 1), "zeros_then_x": bytes(n - 1) + b"x", "zeros_x_zeros": bytes(n // 2) + b"x" + bytes(n - n // 2 - 1)}[name]
+if os.path.exists(name):   # a file: chunk number n of it (65535-byte chunks)
+    with open(name, "rb") as f:
+        f.seek(65535 * n); data = f.read(65535)
+else:
+    data = {"x_then_zeros": b"x" + bytes(n - 1), "zeros_then_x": bytes(n - 1) + b"x", "zeros_x_zeros": bytes(n // 2) + b"x" + bytes(n - n // 2 - 1)}[name]
 t0 = eng.phase_cycles().astype(np.int64)
 print("level %d %s %d bytes ..." % (level, name, n), end="", flush=True)
 t = time.time()
@@ -17,4 +21,4 @@ outs, st = eng.compress_many([data], O.RAW, level)
 dt = time.time() - t
 c = eng.phase_cycles().astype(np.int64) - t0
 ok = st == [0] and outs[0] == O.compress(data, O.RAW, level)
-print(" %.1f ms %s  waves %d trips/wave %.0f rounds %d trip-cap hits %d round-cap hits %d" % (dt * 1e3, "ok" if ok else "MISMATCH", c[42], c[40] / max(c[42], 1), c[43], c[45], c[46]), flush=True)
+print(" %.1f ms %s  waves %d trips/wave %.0f (max %d) rounds %d  per wave: walk steps %.0f runs %.0f measures %.0f moves %.0f  caps %d %d" % (dt * 1e3, "ok" if ok else "MISMATCH", c[42], c[40] / max(c[42], 1), c[51], c[43], c[49] / max(c[42], 1), c[47] / max(c[42], 1), c[48] / max(c[42], 1), c[50] / max(c[42], 1), c[45], c[46]), flush=True)
