@@ -648,8 +648,8 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         pt_first[k + 1] = (uint32_t)points.size();
     }
     const uint32_t npts = (uint32_t)points.size();
-    if ((rc = ensure(h, h->sp_points, sizeof(fl_scan_point) * npts))) return -1;
-    if ((rc = ensure(h, h->sp_found, sizeof(uint64_t) * npts))) return -1;
+    if ((rc = ensure(h, h->sp_points, sizeof(fl_scan_point) * npts))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_found, sizeof(uint64_t) * npts))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
     if (hipMemcpyAsync(h->sp_points.p, points.data(), sizeof(fl_scan_point) * npts, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
     {
@@ -697,12 +697,12 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     const uint32_t nsp = (uint32_t)spans.size();
     if (dbg) fprintf(stderr, "[spans] %zu streams, %u scan points, %u spans\n", elig.size(), npts, nsp);
     if (nsp == (uint32_t)elig.size()) return 0;  // nothing to cut
-    if ((rc = ensure(h, h->sp_spans, sizeof(fl_span) * nsp))) return -1;
-    if ((rc = ensure(h, h->sp_res, sizeof(fl_span_res) * 2 * nsp))) return -1;
-    if ((rc = ensure(h, h->sp_cand, sizeof(uint64_t) * (cand.size() + 1)))) return -1;
-    if ((rc = ensure(h, h->sp_candoff, sizeof(uint32_t) * (n_chunks + 1)))) return -1;
-    if ((rc = ensure(h, h->sp_tails, (size_t)FP_TAIL * nsp))) return -1;
-    if ((rc = ensure(h, h->sp_tails_b, (size_t)FP_TAIL * nsp))) return -1;
+    if ((rc = ensure(h, h->sp_spans, sizeof(fl_span) * nsp))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_res, sizeof(fl_span_res) * 2 * nsp))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_cand, sizeof(uint64_t) * (cand.size() + 1)))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_candoff, sizeof(uint32_t) * (n_chunks + 1)))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_tails, (size_t)FP_TAIL * nsp))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_tails_b, (size_t)FP_TAIL * nsp))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
     if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (!cand.empty() && hipMemcpyAsync(h->sp_cand.p, cand.data(), sizeof(uint64_t) * cand.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_candoff.p, cand_off.data(), sizeof(uint32_t) * (n_chunks + 1), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
@@ -713,14 +713,24 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         uint64_t bytes = 0;
         for (uint32_t ci : elig) bytes += std::min<uint64_t>(chunks[ci].out_cap, 32ull * chunks[ci].in_len);
         const uint64_t pieces = ((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1) * (twin ? 2 : 1);
-        // (a pool the device cannot give -- callers who reserve the worst case for gigabytes of input: the old way)
+        // (a pool the device cannot give -- callers who reserve the worst case for gigabytes of input: the old way.  The
+        // pool is a second copy of the decoded output: it may take a quarter of what is free next to what it holds
+        // already, never more than 16 GiB, so that an allocator that shares the device -- PyTorch's -- is not starved.)
         if (pieces * FP_PIECE > (16ull << 30)) return 0;
+        if (pieces * FP_PIECE + 16 > h->sp_pool.cap) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            if (pieces * FP_PIECE + 16 > h->sp_pool.cap + free_b / 4) return 0;
+        }
         if (ensure(h, h->sp_pool, (size_t)(pieces * FP_PIECE + 16))) {
             (void)hipGetLastError();  // (not this call's failure)
             return 0;
         }
-        if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp * 2))) return -1;
-        if ((rc = ensure(h, h->sp_poolctl, 16))) return -1;
+        if ((rc = ensure(h, h->sp_pooltab, sizeof(uint32_t) * (size_t)FP_MAX_PIECES * nsp * 2))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+        if ((rc = ensure(h, h->sp_poolctl, 16))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
         if (hipMemsetAsync(h->sp_poolctl.p, 0, 16, st) != hipSuccess) return -1;
         pool.base = (uint8_t*)h->sp_pool.p;
         pool.next = (uint32_t*)h->sp_poolctl.p;
@@ -819,10 +829,10 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         item_first[k + 1] = (uint32_t)items.size();
     }
     const uint32_t n_items = (uint32_t)items.size();
-    if ((rc = ensure(h, h->sp_chain, sizeof(uint32_t) * (chain_all.size() + 1)))) return -1;
-    if ((rc = ensure(h, h->sp_chainoff, sizeof(uint32_t) * chain_off.size()))) return -1;
-    if ((rc = ensure(h, h->sp_items, sizeof(fl_fix_item) * ((size_t)n_items + 1)))) return -1;
-    if ((rc = ensure(h, h->sp_part, sizeof(uint32_t) * 2 * ((size_t)n_items + 1)))) return -1;
+    if ((rc = ensure(h, h->sp_chain, sizeof(uint32_t) * (chain_all.size() + 1)))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_chainoff, sizeof(uint32_t) * chain_off.size()))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_items, sizeof(fl_fix_item) * ((size_t)n_items + 1)))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+    if ((rc = ensure(h, h->sp_part, sizeof(uint32_t) * 2 * ((size_t)n_items + 1)))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
     if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
@@ -852,8 +862,8 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
             const uint64_t fb = (plans[k].end_bit + 7) >> 3;
             if (plans[k].ok && fb + flen <= c.in_len) foot_off[k] = c.in_off + fb;
         }
-        if ((rc = ensure(h, h->sp_footoff, sizeof(uint64_t) * nel))) return -1;
-        if ((rc = ensure(h, h->sp_foot, 8 * (size_t)nel))) return -1;
+        if ((rc = ensure(h, h->sp_footoff, sizeof(uint64_t) * nel))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
+        if ((rc = ensure(h, h->sp_foot, 8 * (size_t)nel))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
         if (hipMemcpyAsync(h->sp_footoff.p, foot_off.data(), sizeof(uint64_t) * nel, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_span_footers, dim3((nel + 63) / 64), dim3(64), 0, st, d_in, (const uint64_t*)h->sp_footoff.p, nel, flen,
                            (uint8_t*)h->sp_foot.p);
@@ -918,7 +928,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         done++;
     }
     if (done) {
-        if ((rc = ensure(h, h->sp_fin, sizeof(fl_span_fin) * fin.size()))) return -1;
+        if ((rc = ensure(h, h->sp_fin, sizeof(fl_span_fin) * fin.size()))) { (void)hipGetLastError(); return 0; }  // (no room: the old way)
         if (hipMemcpyAsync(h->sp_fin.p, fin.data(), sizeof(fl_span_fin) * fin.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_span_finish, dim3(((uint32_t)fin.size() + 63) / 64), dim3(64), 0, st, (const fl_span_fin*)h->sp_fin.p,
                            (uint32_t)fin.size(), d_status, d_outlen, d_consumed);
@@ -1139,6 +1149,17 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                     if (n) memcpy(out + hout[i], pout + (hout[i] - out_lo), n);
                 }
             });
+            // (large mirrors do not stay pinned with the handle)
+            if (h->pin_in_cap > (1ull << 30)) {
+                (void)hipHostFree(h->pin_in);
+                h->pin_in = nullptr;
+                h->pin_in_cap = 0;
+            }
+            if (h->pin_out_cap > (1ull << 30)) {
+                (void)hipHostFree(h->pin_out);
+                h->pin_out = nullptr;
+                h->pin_out_cap = 0;
+            }
             return FLATE_HIP_OK;
         }
     }
@@ -1458,6 +1479,13 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     // A few long streams: each by many workgroups at once (spans); what comes out whole is skipped below.
     if (!pin_io) {
         const int done = try_span_inflate(h, st, d_in, chunks, container, flags, d_out, d_outlen, d_status, d_consumed);
+        // (the pool holds a second copy of the decoded output: a large one does not stay with the handle)
+        if (h->sp_pool.cap > (2ull << 30)) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(h->sp_pool.p);
+            h->sp_pool.p = nullptr;
+            h->sp_pool.cap = 0;
+        }
         if (done < 0) {
             h->last_error = std::string("inflate by spans: ") + hipGetErrorString(hipGetLastError());
             return FLATE_HIP_E_LAUNCH;

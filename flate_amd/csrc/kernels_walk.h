@@ -291,6 +291,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
     const uint16_t* lk = lnk + (uint64_t)c * (4u * FL_CHUNK_STRIDE);  // level K: lk[(K << 16) + position]; RK: lk[(3 << 16) + position]
 #ifdef WK_PROF
     uint32_t c_iter = 0, c_gath = 0, c_judge = 0, c_meas = 0, c_move = 0, c_rank = 0, c_runs = 0;
+    uint64_t c_tstitch = 0, c_tloop = 0, c_tr0 = 0;
     const uint64_t c_t0 = __builtin_readcyclecounter();
 #endif
     // ---- the chunk's bytes, zero padded
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         uint32_t a = 0;
         uint64_t stopmask = 0;
         uint32_t y_in = PZ_NONE;
+        bool deferred = false; // this lane's entry is not the one it is resolved for, but may still move: next round
         bool fixing = false;   // this lane parses its segment again in this round ...
         uint32_t ex_used = 0;  // ... and this is the exit the round's path assumed for it
         if (round == 0) {
@@ -348,6 +350,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                 a = seg0;
             }
         } else {
+#ifdef WK_PROF
+            const uint64_t c_ts0 = __builtin_readcyclecounter();
+#endif
             // the path, assuming every segment not resolved yet leaves through its own exit
             if (m < nseg) {
                 const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
@@ -375,12 +380,25 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
             marked = m < nseg && tMark[m] != 0;
             if (marked) {
                 const uint32_t ex = tExg[m];
-                if (ex < N) tEnt[ex >> 6] = (uint16_t)ex;
+                if (ex < N) {
+                    tEnt[ex >> 6] = (uint16_t)ex;
+                    tNxt[0][ex >> 6] = (uint16_t)m;  // (the segment the path comes from; the jump tables are free now)
+                }
             }
             __syncthreads();
             if (marked) y_in = tEnt[m];
-            const bool work = marked && y_in != res_entry;
-            if (!__syncthreads_or(work ? 1 : 0)) break;
+            const bool need = marked && y_in != res_entry;
+            // A segment is parsed again only when the segment the path comes from is settled for the entry IT got: else that
+            // one's exit -- this one's entry -- may still move.  (A run of one byte is entered 258 bytes further in every
+            // round, 16 rounds for 4 KiB of padding: everything behind the run was parsed again in every one of them.)
+            tMark[m] = need ? 0 : 1;
+            __syncthreads();
+            const bool work = need && (m == 0 || tMark[tNxt[0][m]] != 0);
+            deferred = need && !work;
+#ifdef WK_PROF
+            c_tstitch += __builtin_readcyclecounter() - c_ts0;
+#endif
+            if (!__syncthreads_or(need ? 1 : 0)) break;
             if (work) {
                 st = ST_FIX;
                 a = y_in;
@@ -462,6 +480,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         }
         uint32_t cs = st != ST_DONE ? CS_MOVE : CS_IDLE;
         bool first_call = true;  // the next move is the first call of the parse (at a, nothing pending)
+#ifdef WK_PROF
+        const uint64_t c_tl0 = __builtin_readcyclecounter();
+#endif
         // Lanes do the same thing at the same time: a wave's trip through this loop is (M) the automaton's move for the
         // lanes between calls, (W) up to WK_BURST chain steps for the lanes that walk -- a step is the arrival of a
         // link, the bounds, the four-byte filter, the request of the next link --, (R) runs, (J) the exact length of the
@@ -626,12 +647,24 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                     } else {
                         const uint32_t qc = q - off;
                         bool next = true;  // the walk goes on with the link of q
-                        if (qc < last) {   // (else: looked at before the walk changed chains)
+                        const bool fresh = qc < last;  // (else: looked at before the walk changed chains)
+                        if (fresh) {
                             if (cnt) cnt--;
                             if (K == WK_L4) last = qc;
-                            uint32_t pat;
-                            if (prun != 0 && allsame8(qc, pat) && pat == (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u) {
+                        }
+                        uint32_t pat;
+                        const bool run8 = allsame8(q, pat);  // the chain member lies in a run of one byte
+                        const bool same = run8 && prun != 0 && off == 0 && pat == (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u;
+                        if (run8 && !same) {
+                            // ... and p + off does not start with that byte four times: a collision of the hash with a crowded
+                            // bucket (zero padding: thousands of members).  No member of the run can be what the walk looks for.
+                            cs = CS_RUN;
+                            pend_l = fresh ? 1u : 2u;
+                            next = false;
+                        } else if (fresh) {
+                            if (same) {
                                 cs = CS_RUN;
+                                pend_l = 0;
                                 next = false;
                             } else if (pz_lds4(win32, qc + fo) == pref) {
                                 cs = CS_MEAS;
@@ -665,7 +698,31 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
             // skips what is left of the run, WK_RUNSKIP bytes per trip at most.  Everything skipped lies in p's bucket and
             // counts against the budget as if it had been looked at; on L6 / L8 the ranks say where the budget ends.
             // CPU model of exactly this, checked against the oracle on run-heavy inputs: tools/multilevel_model.c.
-            if (cs == CS_RUN) {
+            if (cs == CS_RUN && pend_l != 0) {
+                // a run of another byte (see (W)): what is known to be run is skipped; it counts as looked at if it has not
+                // been before (pend_l 1)
+                WK_CNT(c_runs, 1);
+                uint32_t pat;
+                (void)allsame8(q, pat);
+                const uint32_t t = scan_down(q, q > WK_RUNSKIP ? q - WK_RUNSKIP : 0u, pat);
+                cs = CS_WALK;
+                if (pend_l == 1u) {
+                    if (K == WK_L4) {
+                        const uint32_t need = q - t;
+                        if (cnt < need) cs = CS_MOVE;
+                        cnt -= min(cnt, need);
+                        last = t;
+                    } else {
+                        cnt = 0;  // (the next candidate of p's bucket is asked for its rank)
+                    }
+                }
+                pend_l = 0;
+                if (cs == CS_WALK) {
+                    q = t;
+                    WK_CNT(c_gath, 1);
+                    g_link = lk[(K << 16) + t];
+                }
+            } else if (cs == CS_RUN) {
                 WK_CNT(c_runs, 1);
                 const uint32_t bp = (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u;
                 const uint32_t c = best, r = prun, cap = max(c, r) + 1u;
@@ -802,9 +859,13 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
                 }
             }
         }
+#ifdef WK_PROF
+        c_tloop += __builtin_readcyclecounter() - c_tl0;
+        if (round == 0) c_tr0 = c_tloop;
+#endif
         // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with
         // it the marks and entries found above -- no round to confirm it.
-        if (round >= 1 && !__syncthreads_or((fixing && res_exit != ex_used) ? 1 : 0)) break;
+        if (round >= 1 && !__syncthreads_or(((fixing && res_exit != ex_used) || deferred) ? 1 : 0)) break;
     }
     // ---- the true anchors
     if (m < nseg) {
@@ -827,6 +888,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const 
         atomicAdd((unsigned long long*)&g_fl_prof[49], (unsigned long long)c_judge);
         atomicAdd((unsigned long long*)&g_fl_prof[50], (unsigned long long)c_move);
         atomicMax((unsigned long long*)&g_fl_prof[51], (unsigned long long)c_iter);
+        atomicAdd((unsigned long long*)&g_fl_prof[52], (unsigned long long)c_tstitch);
+        atomicAdd((unsigned long long*)&g_fl_prof[53], (unsigned long long)c_tloop);
+        atomicAdd((unsigned long long*)&g_fl_prof[54], (unsigned long long)c_tr0);
     }
     (void)c_gath; (void)c_rank;
 #endif

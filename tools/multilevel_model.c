@@ -61,7 +61,7 @@ static int find_match_impl(int p, int len0, int* dist) {
     const int lo = p > 32768 ? p - 32768 : 1;
     int len = len0, found = 0, last = p, K = level_of(len0), cnt = B, off = 0, probe = PROBE;
     int prun = 0;  // bytes equal to the first from p on (capped at maxlen) if at least 4
-    if (run_skip && maxlen >= 8) { int r = 1; while (r < maxlen && buf[p + r] == buf[p]) r++; if (r >= 4) prun = r; }
+    if (run_skip) { int r = 1; while (r < maxlen && buf[p + r] == buf[p]) r++; if (r >= 4) prun = r; }
     off = OFFSET_OF(len);
     n_top++; n_iter++;
     int q = chain_of(K)[p + off];
@@ -70,12 +70,26 @@ static int find_match_impl(int p, int len0, int* dist) {
         if (K == 4 && cnt == 0) return found;
         n_iter++;
         const int qc = q - off;  // the candidate
+        if (run_skip && qc >= last && all_b(q, 8, buf[q]) && !(prun && !off && buf[q] == buf[p])) {
+            // (a foreign run among what has been looked at already: skipped in one step as well, nothing to count)
+            n_runskip++; n_iter++;
+            int t = q; while (q - t < RUNSKIP && t != 0 && buf[t - 1] == buf[q]) t--;
+            q = chain_of(K)[t]; continue;
+        }
         if (qc >= last) { n_skip++; q = chain_of(K)[q]; continue; }  // looked at before the walk changed chains
         n_step[K == 4 ? 0 : K == 6 ? 1 : 2]++;
         if (K == 4) { cnt--; last = qc; } else if (probe) probe--;
         int accept_l = 0, acc = -1;   // candidate to accept (after the rank check on L6 / L8)
         int next_from = qc;           // the walk goes on with the link of this chain member
-        if (prun && !off && all_b(qc, 8, buf[p])) {
+        if (run_skip && all_b(q, 8, buf[q]) && !(prun && !off && buf[q] == buf[p])) {
+            // ---- the chain member lies in a run of one byte, and it is not the case below (p itself at a run of that byte): a
+            // collision of the hash with a crowded bucket (zero padding).  No member of that run shares with p + off the bytes
+            // the chain stands for: what is known to be run is skipped, and counts as looked at.
+            n_runskip++; n_iter++;
+            int t = q; while (q - t < RUNSKIP && t != 0 && buf[t - 1] == buf[q]) t--;
+            if (K == 4) { const int need = q - t; if (cnt < need) return found; cnt -= need; last = t; } else probe = 0;
+            next_from = t - off;
+        } else if (prun && !off && all_b(qc, 8, buf[p])) {
             // ---- a run of p's byte b: [s, E) with qc inside.  q' in it matches p over min(prun, E - q') bytes (more only at
             // q* = E - prun), so with c bytes in hand the only positions that can help are U = [max(s, q*), min(qc, max(E - c - 1, q*))]:
             // the walk would take every one of them in turn, each a byte longer than the last; it ends up at the lowest one
@@ -152,15 +166,36 @@ static int find_match_impl(int p, int len0, int* dist) {
 }
 
 static int dbg_compare;
+static int ref_find_match(int p, int min_len, int* dist) {
+    if (N - p < 4) return 0;
+    int len = min_len, found = 0, ch = chainmax;
+    if (len >= good) ch >>= 2;
+    const int maxlen = N - p < 258 ? N - p : 258;
+    int q = L4[p];
+    while (q > 0 && ch > 0) {
+        if (p - q > 32768) break;
+        int l = 0;
+        if (!(len > 0 && maxlen <= len)) { if (len == 0 || buf[q + len] == buf[p + len]) { l = lcp(q, p, maxlen); if (l < 4) l = 0; } }
+        if (l > len) { found = l; *dist = p - q; len = l; if (l >= nice) break; }
+        q = L4[q]; ch--;
+    }
+    return found;
+}
+static unsigned long long worst_iter; static int worst_p, worst_len0, worst_chunk, cur_chunk;
 static int find_match(int p, int len0, int* dist) {
+    if (dbg_compare == 3) {
+        const unsigned long long i0 = n_iter;
+        const int l = find_match_impl(p, len0, dist);
+        if (n_iter - i0 > worst_iter) { worst_iter = n_iter - i0; worst_p = p; worst_len0 = len0; worst_chunk = cur_chunk; }
+        return l;
+    }
     if (!dbg_compare) return find_match_impl(p, len0, dist);
     int d0 = 0, d1 = 0;
-    const int rs = run_skip;
-    run_skip = 0; const int l0 = find_match_impl(p, len0, &d0);
-    run_skip = rs; const int l1 = find_match_impl(p, len0, &d1);
+    const int l0 = ref_find_match(p, len0, &d0);   // deflate.zig:233-266 as written
+    const int l1 = find_match_impl(p, len0, &d1);
     if (l0 != l1 || (l0 && d0 != d1)) {
         int r = 1; while (r < 258 && buf[p + r] == buf[p]) r++;
-        printf("call p=%d len0=%d: plain (%d,%d) run-skip (%d,%d)  prun %d byte %02x N %d\n", p, len0, l0, d0, l1, d1, r, buf[p], N);
+        printf("call p=%d len0=%d: reference (%d,%d) sparse chains (%d,%d)  prun %d byte %02x N %d\n", p, len0, l0, d0, l1, d1, r, buf[p], N);
         dbg_compare = 2;
     }
     *dist = d0;
@@ -188,6 +223,7 @@ int main(int argc, char** argv) {
         Mpos = N >= 4 ? N - 3 : 0;
         total += N;
         size_t nt = 0, k = 0;
+        cur_chunk = c;
         fo_tokenize(buf, N, level, toks, 65536 + 16, &nt);
         build_links();
         int a = 0;
@@ -217,5 +253,6 @@ int main(int argc, char** argv) {
            (double)n_calls / total, (double)n_top / total, (double)n_step[0] / total, (double)n_step[1] / total, (double)n_step[2] / total,
            (double)n_skip / total, (double)n_meas / total, (double)n_rank / total, (double)n_iter / total);
     printf("run skips %.4f/B\n", (double)n_runskip / total);
+    if (dbg_compare == 3) printf("worst call: chunk %d p=%d len0=%d: %llu gather rounds\n", worst_chunk, worst_p, worst_len0, worst_iter);
     return bad != 0;
 }

@@ -21,4 +21,4 @@ outs, st = eng.compress_many([data], O.RAW, level)
 dt = time.time() - t
 c = eng.phase_cycles().astype(np.int64) - t0
 ok = st == [0] and outs[0] == O.compress(data, O.RAW, level)
-print(" %.1f ms %s  waves %d trips/wave %.0f (max %d) rounds %d  per wave: walk steps %.0f runs %.0f measures %.0f moves %.0f  caps %d %d" % (dt * 1e3, "ok" if ok else "MISMATCH", c[42], c[40] / max(c[42], 1), c[51], c[43], c[49] / max(c[42], 1), c[47] / max(c[42], 1), c[48] / max(c[42], 1), c[50] / max(c[42], 1), c[45], c[46]), flush=True)
+print(" %.1f ms %s  kernel %.0f us/wave  waves %d trips/wave %.0f (max %d) rounds %d  per wave: walk steps %.0f runs %.0f measures %.0f moves %.0f  caps %d %d" % (dt * 1e3, "ok" if ok else "MISMATCH", c[41] / max(c[42], 1) / 2100.0, c[42], c[40] / max(c[42], 1), c[51], c[43], c[49] / max(c[42], 1), c[47] / max(c[42], 1), c[48] / max(c[42], 1), c[50] / max(c[42], 1), c[45], c[46]), flush=True)
