@@ -219,6 +219,9 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #define WK_L4 0u
 #define WK_L6 1u
 #define WK_L8 2u
+#ifndef WK_WAVES_PER_SIMD
+#define WK_WAVES_PER_SIMD 8  // two workgroups per CU (64 VGPRs); 4: one (128 VGPRs, nothing spilled)
+#endif
 #ifndef WK_BURST
 #define WK_BURST 4        // chain steps per trip, at most
 #endif
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #define WK_RUNSKIP 512u   // bytes of a run skipped per trip, at most
 #endif
 #ifndef WK_MINWALK
-#define WK_MINWALK 8u     // ... fewer when fewer lanes than this still walk
+#define WK_MINWALK 1u     // ... fewer when fewer lanes than this still walk (1: never -- 8: text level 9 19.9 GB/s, 1: 22.4)
 #endif
 
 #ifdef WK_PROF
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #endif
 
 // lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
-__global__ __launch_bounds__(WK_THREADS, WK_THREADS / 128) void k_lz_walk(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const uint8_t* __restrict__ in,
                                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                                            const uint16_t* __restrict__ lnk,
                                                                            const uint32_t* __restrict__ cflag,
