@@ -356,7 +356,7 @@ def run_compress(args, torch, dist, eng, world, rank, device):
                                     job.n_chunks, args.config - 1),
                        "container": ["raw", "gzip", "zlib"][args.container], "chunk_bytes": args.chunk,
                        "bytes_per_gpu": n_in, "ratio": round(n_out / max(n_in, 1), 4),
-                       "gather": "rccl exchange of the compressed shards (%s)" % gather.algo if gather is not None else "none"},
+                       "gather": gather.form if gather is not None else "none"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

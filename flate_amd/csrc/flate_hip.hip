@@ -89,7 +89,7 @@ struct flate_hip_ctx {
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
-    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links;
+    DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     size_t pin_in_cap = 0, pin_out_cap = 0;
@@ -998,7 +998,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})
@@ -1823,7 +1823,32 @@ int flate_hip_decompress_batch_sharded(flate_hip_handle h, void* nccl_comm, int 
     // the outputs of this rank's streams go straight into its slice (out_off is relative to the slice)
     int rc = flate_hip_decompress_batch(h, in, in_off, n_chunks, container, flags, gathered + (uint64_t)rank * slice_bytes,
                                         out_off, out_len, status, consumed, FLATE_HIP_MEM_DEVICE);
-    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, slice_bytes);
+    // every peer gets what the fullest slice holds (the end of its last slot), not the slices' capacity: the ends are
+    // all-gathered and read once (one wait on the stream; decompress has waited for its offsets already)
+    uint64_t send_bytes = slice_bytes;
+    if (!rc && world > 1) {
+        std::vector<uint64_t> hs((size_t)world + 1, 0);
+        if ((rc = ensure(h, h->shard_sz, sizeof(uint64_t) * ((size_t)world + 1))) == 0) {
+            uint64_t* dsz = (uint64_t*)h->shard_sz.p;
+            if (hipMemcpyAsync(dsz + world, out_off + n_chunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+                rccl().AllGather(dsz + world, dsz, 1, kNcclUint64, nccl_comm, h->stream) != 0 ||
+                hipMemcpyAsync(hs.data(), dsz, sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) {
+                h->last_error = "exchanging the slice sizes failed";
+                rc = FLATE_HIP_E_LAUNCH;
+            } else {
+                uint64_t mx = 0;
+                for (int i = 0; i < world; i++) mx = std::max(mx, hs[(size_t)i]);
+                if (mx > slice_bytes) {
+                    h->last_error = "a rank's slots end beyond slice_bytes";
+                    rc = FLATE_HIP_E_INVALID_ARG;
+                } else {
+                    send_bytes = std::min<uint64_t>(slice_bytes, (mx + 15) & ~(uint64_t)15);
+                }
+            }
+        }
+    }
+    if (!rc) rc = exchange_slices(h, nccl_comm, rank, world, gathered, slice_bytes, send_bytes);
     h->sync = was_sync;
     if (!rc && h->sync) HIP_OK(h, hipStreamSynchronize(h->stream));
     return rc;

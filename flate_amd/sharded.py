@@ -139,6 +139,7 @@ class OutputGather:
     def calibrate(self, out, out_off, out_len, slack=1.05):
         """Fix the slice width from this batch (one host sync): max packed size over the ranks * slack."""
         import torch.distributed as dist
+        self._wait_exchange()  # (an exchange of an earlier run() may still be adding to `over` / writing `sizes`)
         n = self._pack(out, out_off, out_len)
         dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
         sizes = [int(x) for x in self.sizes.cpu().tolist()]
@@ -154,13 +155,9 @@ class OutputGather:
         import torch
         import torch.distributed as dist
         if self.calibrated and self.overlap:
-            try:
-                return self._run_overlapped(out, out_off, out_len)
-            except Exception as e:  # noqa: BLE001 -- the serial form below still does the job
-                import sys
-                sys.stderr.write("rank %d: overlapped output gather failed (%r): serial from here on\n" % (self.rank, e))
-                self.overlap = False
-                torch.cuda.synchronize(self.device)
+            # (no fallback to the serial form from here: one rank that changed form alone would issue other
+            # collectives than its peers and hang the job -- a failure of the exchange is raised to the caller)
+            return self._run_overlapped(out, out_off, out_len)
         n = self._pack(out, out_off, out_len)
         dist.all_gather_into_tensor(self.sizes, self.dst_off[n:n + 1])
         if self.calibrated:
@@ -194,6 +191,17 @@ class OutputGather:
                 self._exchange(self.width, self.packed_bufs[i])
                 self.ev_done[i].record(self.comm_stream)
             return None
+
+    @property
+    def form(self):
+        """What run() does once calibrated: "p2p-overlapped" / "all_gather-overlapped" (exchange on its own stream beside
+        the next step's kernels) or "p2p-serial" / "all_gather-serial"."""
+        return "%s-%s" % (self.algo, "overlapped" if (self.calibrated and self.overlap) else "serial")
+
+    def wait(self):
+        """Make torch's current stream wait for the exchange in flight: `gathered`, `sizes` and `over` are what the last
+        run() produced from here on (sizes_host(), overflowed(), shard() and calibrate() do this themselves)."""
+        self._wait_exchange()
 
     def _wait_exchange(self):
         if getattr(self, "overlap", False):

@@ -112,3 +112,65 @@ def test_one_stream_of_several_mib(mode):
         outs, st, used = eng.decompress_many([bad], O.ZLIB, caps=[len(data) + 8])
         name, want, wused = O.decompress(bad, O.ZLIB, 0, cap=len(data) + 8)
         assert O.STATUS[st[0]] == name
+
+
+def test_output_gather_overlapped_three_steps_one_rank():
+    # The exchange of step k on its own stream beside the kernels of step k + 1 (sharded.OutputGather, two pack
+    # buffers, events both ways): three steps with different inputs, every step's reassembled shard compared with
+    # that step's packed streams.  One rank (RCCL through torch.distributed); the 8-GPU run is the driver's.
+    import torch
+    import torch.distributed as dist
+    from flate_amd import sharded, synth
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    # its own process: a process group is process-wide state
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import _oracle as O
+from flate_amd import Engine, sharded, synth
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", FLATE_GATHER_OVERLAP="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
+eng = Engine(0); eng.set_stream(stream.cuda_stream); eng.set_sync(False)
+n_chunks, chunk = 300, 40000
+def batch(seed):
+    d = torch.from_numpy(synth.text(seed, n_chunks * chunk)).to(dev)
+    off = np.arange(n_chunks + 1, dtype=np.int64) * chunk
+    caps = np.array([(eng.compress_bound(chunk, 0, 6) + 7) & ~7] * n_chunks, dtype=np.int64)
+    oo = np.zeros(n_chunks + 1, dtype=np.int64); np.cumsum(caps, out=oo[1:])
+    return d, torch.from_numpy(off).to(dev), torch.from_numpy(oo).to(dev), oo
+datas = [batch(s) for s in (11, 12, 13)]
+out = [torch.empty(int(datas[0][3][-1]) + 8, dtype=torch.uint8, device=dev) for _ in range(3)]
+lens = [torch.zeros(n_chunks, dtype=torch.int64, device=dev) for _ in range(3)]
+st = [torch.zeros(n_chunks, dtype=torch.int32, device=dev) for _ in range(3)]
+def compress(i):
+    d, io, oo, _ = datas[i]
+    eng.compress_device(d.data_ptr(), io.data_ptr(), n_chunks, 0, 6, out[i].data_ptr(), oo.data_ptr(), lens[i].data_ptr(), st[i].data_ptr())
+compress(0)
+g = sharded.OutputGather(1, 0, dev, int(datas[0][3][-1]), engine=eng)
+g.calibrate(out[0], datas[0][2], lens[0])
+assert g.form.endswith("-overlapped"), g.form
+for i in range(3):
+    compress(i)
+    g.run(out[i], datas[i][2], lens[i])   # returns at once; the exchange of step i runs beside step i + 1
+    if i < 2:
+        compress(i + 1)                   # (the next step's kernels, enqueued while the exchange is in flight)
+    sizes = g.sizes_host()
+    got = g.shard(0, sizes).cpu().numpy().tobytes()
+    l = lens[i].cpu().numpy(); oo = datas[i][3]
+    o = out[i].cpu().numpy()
+    want = b"".join(o[int(oo[k]):int(oo[k]) + int(l[k])].tobytes() for k in range(n_chunks))
+    assert int(st[i].abs().sum().item()) == 0 and got == want, "step %%d: reassembled shard differs" %% i
+    data = datas[i][0].cpu().numpy().tobytes()
+    assert want[:int(l[0])] == O.compress(data[:chunk], O.RAW, 6)
+assert not g.overflowed()
+dist.destroy_process_group()
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -658,3 +658,48 @@ def test_link_kernels_fallback_path_matches_oracle():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__) +
                         "::test_tokenizer_matches_oracle_tokens"], env=env, capture_output=True, text=True, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sparse_chain_kernels_at_every_level():
+    # Levels 8 and 9 take k_lz_links / k_lz_walk (the match finder over sparser chains, runs of one byte in one step,
+    # offset mode); the build with -DFL_BULK_MIN_CHAIN=1 sends levels 4-7 through them as well: same token lists, same
+    # bytes as the oracle (its own process: the library is chosen at import).
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "flate_amd", "lib", "var", "libflate_hip_walkall.so")
+    assert os.path.exists(lib), "build() makes it (flate_amd/csrc/Makefile)"
+    env = dict(os.environ, FLATE_HIP_LIB=lib)
+    me = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", me + "::test_tokenizer_matches_oracle_tokens",
+                        me + "::test_bytes_match_oracle", me + "::test_runny_inputs_match_oracle"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_runny_inputs_match_oracle():
+    # runs of one byte of every length, junk between them, repeated blocks, sparse zeros: what the run logic of
+    # k_lz_walk (levels 8, 9) skips must be exactly what cannot change the result
+    eng = engine()
+    rng = np.random.default_rng(77)
+
+    def mk(seed, n, maxrun, alphabet, junkmax):
+        r = np.random.default_rng(seed)
+        parts, k = [], 0
+        while k < n:
+            a = bytes([int(r.integers(0, alphabet))]) * int(r.integers(1, maxrun))
+            b = r.integers(0, alphabet + 2, int(r.integers(0, junkmax)), dtype=np.uint8).tobytes()
+            parts += [a, b]
+            k += len(a) + len(b)
+        return b"".join(parts)[:n]
+
+    blk = mk(4, 3000, 100, 2, 6)
+    sparse = np.zeros(65535, dtype=np.uint8)
+    sparse[rng.integers(0, 65535, 700)] = rng.integers(0, 256, 700, dtype=np.uint8)
+    datas = [mk(1, 65535, 40, 2, 4), mk(2, 65535, 700, 1, 3), mk(3, 60000, 300, 3, 12), (blk * 30)[:65535], mk(5, 65535, 1200, 1, 2),
+             sparse.tobytes(), b"x" + bytes(65534), bytes(30000) + b"abcdefgh" * 100 + bytes(30000), mk(6, 777, 50, 2, 3)]
+    for level in (4, 6, 8, 9):
+        outs, st = eng.compress_many(datas, O.RAW, level)
+        assert st == [0] * len(datas)
+        for i, d in enumerate(datas):
+            assert outs[i] == O.compress(d, O.RAW, level), (i, level)
