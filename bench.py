@@ -428,7 +428,7 @@ def measured_traffic(args, n_in, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, two separate
     rocprofv3 --pmc runs of this very command; profiles/r0N_hbm_traffic_1gib.json), when the workload matches;
     PMC counters cannot be read from inside an un-profiled run, so otherwise null."""
-    for name in ("r03_hbm_traffic_1gib.json",):
+    for name in ("r04_hbm_traffic_1gib.json", "r03_hbm_traffic_1gib.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -697,7 +697,9 @@ def baseline_configs(args, torch, eng, device):
     sil = torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA, 128 << 20)).to(device)
     job, lens = compress_case("config4_huffman_only_128MiB_stream", sil, 128 << 20, 1, 1, steps=3, sample=1)
     del job
-    # configs[4]: gunzip of 128 members of 1 MiB (per GPU)
+    # configs[4]: gunzip of 128 members of 1 MiB (per GPU; the members of `--config 5`: same seed)
+    del sil
+    sil = torch.from_numpy(synth.silesia_like(synth.SEED_SILESIA + 1, 128 << 20)).to(device)
     mk = CompressJob(torch, eng, sil, 1 << 20, 1, 6)
     mk.step()
     torch.cuda.synchronize()

@@ -40,7 +40,6 @@ enum KernelId {
     K_LZ_LINKS,
     K_LZ_WALK,
     K_LZ_EMIT,
-    K_LZ_TOK,
     K_ST_PARSE,
     K_ST_EMIT,
     K_PLAN,
@@ -55,7 +54,7 @@ enum KernelId {
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
                                            "k_lz_chain", "k_lz_parse", "k_lz_links", "k_lz_walk", "k_lz_emit",
-                                           "k_lz_tok", "k_st_parse", "k_st_emit", "k_plan",
+                                           "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_span_scan", "k_inflate_span",
                                            "k_gather"};
 

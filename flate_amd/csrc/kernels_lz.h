@@ -1,7 +1,8 @@
-// kernels_lz.h -- the LZ77 tokenizer of levels 4..9 on the GPU.  The kernels of the chunk
-// path (inputs of at most 65535 bytes: SlidingWindow.zig:36-44 is never reached,
-// deflate.zig:304-321 breaks out after the first short read); k_lz_sort and k_lz_match also
-// serve, as <true> instances, the tiles of the whole-stream path (kernels_stream.h).
+// kernels_lz.h -- the hash-order match finder (round 1-2) and helpers shared by the tokenizer kernels.
+// k_lz_sort and k_lz_match serve, as <true> instances, the tiles of the whole-stream path (kernels_stream.h: inputs
+// longer than 65535 bytes at levels 4..9).  The chunk path (inputs of at most 65535 bytes) no longer uses them:
+// levels 4-7 take kernels_parse.h (round 3), levels 8-9 kernels_walk.h (round 4); the <false> code paths below are
+// what is left of the chunk-path use and are not instantiated.
 //
 // Reference path: Deflate.tokenize / findMatch (deflate.zig:154-266),
 // SlidingWindow.match (SlidingWindow.zig:81-104), Lookup (Lookup.zig:12-84).
@@ -9,21 +10,16 @@
 // The reference walks a hash chain sequentially.  The chain content does not
 // depend on the parse: every position is inserted exactly once, in ascending
 // order (deflate.zig:207-211,236; Lookup.zig:55-72), so chain[p] is simply the
-// nearest earlier position with the same 15-bit hash.  That makes the whole
-// tokenizer data-parallel (one workgroup per chunk in every kernel):
+// nearest earlier position with the same 15-bit hash:
 //
 //   k_lz_sort   stable LSD radix sort of the positions by hash: the candidates of a
 //               position are its predecessors in its bucket, nearest first.
 //   k_lz_match  for EVERY position, the longest-match record the reference's findMatch
 //               would return, for the full chain budget and for chain >> 2
-//               (deflate.zig:241-245); window staged in LDS.  Two instantiations per path:
+//               (deflate.zig:241-245); window staged in LDS.  Two instantiations:
 //               plain windows, and windows the sort marks runny (runs, padding, records).
-//   k_lz_tok    the lazy-matching automaton (deflate.zig:154-205) as a function
-//               "anchor -> next anchor", resolved with pointer jumping instead of a
-//               serial walk; then the token list, per-block histograms and the block
-//               boundaries (32768 tokens, deflate.zig:227-230) by prefix sums over the anchors.
 //
-// Bounds: k_lz_match and k_lz_tok are bound by vector-ALU issue, k_lz_sort by the CU's memory pipe
+// Bounds: k_lz_match is bound by vector-ALU issue, k_lz_sort by the CU's memory pipe
 // (one scattered gather and one scattered store per element) and issue; no MFMA.
 #pragma once
 #include "kernels_common.h"
@@ -961,7 +957,7 @@ __device__ __forceinline__ uint32_t fl_anchor_desc(const uint2* __restrict__ rec
 }
 
 // ------------------------------------------------------------------ token emission helpers
-// (k_lz_tok below; k_st_emit in kernels_stream.h)
+// (k_lz_emit in kernels_parse.h; k_st_emit in kernels_stream.h)
 #define FL_EMIT_WAVES 16
 #define FL_EMIT_THREADS (64 * FL_EMIT_WAVES)
 
@@ -969,274 +965,13 @@ __device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t 
     return (win32[off >> 2] >> (8 * (off & 3))) & 0xff;
 }
 
-// ------------------------------------------------------------------ k_lz_tok
-// Parse and emit of the chunk path in one kernel (they were two until round 2): the descriptors never
-// leave the registers of the thread that computed them, so the 4-byte-per-position desc array is
-// neither written nor read back (it was read three times), the anchor bits stay in LDS, and the
-// chunk's bytes are staged once, a part at a time, for the literals.
-//
-// The chunk is handled in parts of 8192 positions; wave w owns positions
-// [h0 + 512 w, h0 + 512 (w + 1)) of a part (two 256-position pieces of four 64-position
-// sub-pieces), 8 per lane, and everything except the hand-over of the anchor chain from piece to
-// piece is local to the wave -- four workgroup barriers per part.  Per part:
-//  (a) descriptor and one-step pointer J1 of every position (deflate.zig:154-194, fl_anchor_desc);
-//  (b) pointer jumping: J64[p] = first anchor on p's path beyond p's sub-piece (6 rounds), then
-//      J256[p] = ... beyond p's piece (2 more rounds);
-//  (c) the first anchor of every piece, <= 32 serial steps of one thread over J256;
-//  (d) the first anchor of every sub-piece, <= 4 steps of one lane per piece over J64;
-//  (e) the anchors of every sub-piece, one lane per sub-piece over J1, bits collected in registers;
-//  (f) tokens, histograms and the 32768-token block cut (deflate.zig:213-230, 268-288;
-//      block_writer.zig:444-462) by prefix sums over the anchors.
-#define FL_TOK_THREADS 1024
+// ------------------------------------------------------------------ parts of a chunk in the emitters
+// k_lz_emit (kernels_parse.h) handles a chunk in parts of 8192 positions; wave w owns positions
+// [h0 + 512 w, h0 + 512 (w + 1)) of a part.  (k_lz_tok -- parse and emit of the round-2 chunk path in one kernel over the
+// records of k_lz_match -- went with round 4: levels 8 and 9 take kernels_walk.h.)
 #define FL_TOK_PART 8192u
 #define FL_TOK_SPAN (FL_TOK_PART / 16u)  // positions per wave per part
 #define FL_TOK_R (FL_TOK_SPAN / 64u)     // positions per lane per part
 #define FL_TOK_LOOK 256u                 // literals of an anchor may reach this far past its part (j < 256)
 #define FL_TOK_WIN_DW ((FL_TOK_PART + FL_TOK_LOOK) / 4u + 2u)
 
-__global__ __launch_bounds__(FL_TOK_THREADS, 8) void k_lz_tok(const uint8_t* __restrict__ in,
-                                                             const fl_chunk* __restrict__ chunks, fl_params prm,
-                                                             const uint32_t* __restrict__ rec_all,
-                                                             uint32_t* __restrict__ tokens_all,
-                                                             uint32_t* __restrict__ hist_all,
-                                                             fl_block_plan* __restrict__ plans,
-                                                             uint32_t* __restrict__ ntok_all) {
-    __shared__ uint16_t J1[FL_TOK_PART];
-    __shared__ uint16_t J64[FL_TOK_PART];
-    __shared__ uint16_t J256[FL_TOK_PART];
-    __shared__ uint32_t winp[FL_TOK_WIN_DW];
-    __shared__ uint32_t marks[FL_TOK_PART / 32];
-    __shared__ uint16_t entry[FL_TOK_PART / 256];
-    __shared__ uint16_t entry64[FL_TOK_PART / 64];
-    __shared__ uint32_t hist[2][320];
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t next_anchor, v1_sh;
-    const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    fl_block_plan* plan0 = &plans[ck.first_block];
-    fl_block_plan* plan1 = &plans[ck.first_block + 1];
-    if (ck.skip) {
-        if (tid == 0) {
-            plan0->valid = 0;
-            plan1->valid = 0;
-            ntok_all[c] = 0;
-        }
-        return;
-    }
-    const uint32_t N = ck.in_len;
-    const uint8_t* src = in + ck.in_off;
-    const uint2* rec2 = (const uint2*)rec_all + ck.pos_off;
-    uint32_t* tokens = tokens_all + ck.pos_off;
-
-    for (uint32_t i = tid; i < 640; i += FL_TOK_THREADS) (&hist[0][0])[i] = 0;
-    if (tid == 0) {
-        next_anchor = 0;
-        v1_sh = N;
-    }
-    uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
-    fl_prof_mark(16);
-    for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
-        const uint32_t h1 = min(h0 + FL_TOK_PART, N);
-        const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
-        // the records of the wave's positions (in flight while the bytes are staged)
-        uint2 ra[FL_TOK_R];
-#pragma unroll
-        for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t p = span0 + r * 64 + lane;
-            ra[r] = p < h1 ? rec2[p] : make_uint2(0u, 0u);
-        }
-        // the record of the position after the wave's last one
-        uint2 rx = make_uint2(0u, 0u);
-        if (lane == 63 && span0 + FL_TOK_SPAN < N) rx = rec2[span0 + FL_TOK_SPAN];
-        // the part's bytes (+ lookahead for the literals of its last anchors), zero padded
-        {
-            const uint32_t nb = min(N - h0, FL_TOK_PART + FL_TOK_LOOK);
-            for (uint32_t i = tid; i < FL_TOK_WIN_DW; i += FL_TOK_THREADS)
-                winp[i] = 4 * i < nb ? fl_load_u32_clamped(src + h0, 4 * i, nb) : 0u;
-        }
-        if (h0 == 0) fl_prof_mark(23);
-        if (tid < FL_TOK_PART / 256) entry[tid] = 0xffff;
-        if (lane < FL_TOK_SPAN / 64) entry64[wave * (FL_TOK_SPAN / 64) + lane] = 0xffff;
-        // (a) anchor function of the wave's positions; (b) pointer jumping inside the sub-piece a round
-        // of the wave covers (lane = position): J64 = first anchor on the path beyond the sub-piece.
-        // The pointers stay in registers and travel by ds_bpermute; a lane reads a node further along
-        // its own path, so the rounds end when no pointer moves any more (<= 6: 2^6 positions).
-        uint32_t d[FL_TOK_R];
-#pragma unroll
-        for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t p = span0 + r * 64 + lane;
-            // record of p + 1: the next lane's, the next round's first lane's, or rx
-            // (DPP wave_shl:1 -- lane i reads lane i + 1; lane 63 keeps `old`: the value that follows the wave)
-            const uint2 nf = ra[r + 1 < (int)FL_TOK_R ? r + 1 : r];
-            const uint32_t fx = r + 1 < (int)FL_TOK_R ? (uint32_t)__builtin_amdgcn_readfirstlane((int)nf.x) : rx.x;
-            const uint32_t fy = r + 1 < (int)FL_TOK_R ? (uint32_t)__builtin_amdgcn_readfirstlane((int)nf.y) : rx.y;
-            uint2 rb;
-            rb.x = (uint32_t)__builtin_amdgcn_update_dpp((int)fx, (int)ra[r].x, 0x130, 0xf, 0xf, false);
-            rb.y = (uint32_t)__builtin_amdgcn_update_dpp((int)fy, (int)ra[r].y, 0x130, 0xf, 0xf, false);
-            uint32_t dd = 0, nx = 0xffffu;
-            if (p < h1) {
-                dd = fl_anchor_desc(rec2, p, ra[r], rb, prm.good, prm.lazy);
-                nx = fl_desc_next(dd, p);
-                J1[p - h0] = (uint16_t)nx;
-            }
-            d[r] = dd;
-            const uint32_t base = span0 + r * 64;
-            const uint32_t seg_end = min(base + 64u, N);
-            while (__any(nx < seg_end)) {
-                const uint32_t o = __shfl(nx, (nx - base) & 63u, 64);
-                if (nx < seg_end) nx = o;
-            }
-            if (p < h1) {
-                J64[p - h0] = (uint16_t)nx;
-                J256[p - h0] = (uint16_t)nx;
-            }
-        }
-        fl_lds_order();
-        if (h0 == 0) fl_prof_mark(17);
-        // J256 = first anchor on the path beyond the 256-position piece: a piece is four sub-pieces,
-        // so two doubling rounds over J64's result always suffice
-        for (int round = 0; round < 2; round++) {
-#pragma unroll
-            for (int r = 0; r < (int)FL_TOK_R; r++) {
-                const uint32_t p = span0 + r * 64 + lane;
-                if (p < h1) {
-                    const uint32_t seg_end = min((p | 255u) + 1u, N);
-                    const uint32_t j = J256[p - h0];
-                    if (j < seg_end) J256[p - h0] = J256[j - h0];
-                }
-            }
-            fl_lds_order();
-        }
-        if (h0 == 0) fl_prof_mark(24);
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(18);
-        // (c) first anchor of every piece of this part: at most 32 serial steps
-        if (tid == 0) {
-            uint32_t a = next_anchor;
-            while (a < h1) {
-                entry[(a - h0) >> 8] = (uint16_t)a;
-                a = J256[a - h0];
-            }
-            next_anchor = a;
-        }
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(19);
-        // (d) first anchor of every sub-piece of the wave's pieces
-        if (lane < FL_TOK_SPAN / 256) {
-            const uint32_t piece = wave * (FL_TOK_SPAN / 256) + lane;
-            uint32_t a = entry[piece];
-            const uint32_t end = min(h0 + ((piece + 1) << 8), N);
-            while (a < end) {
-                entry64[(a - h0) >> 6] = (uint16_t)a;
-                a = J64[a - h0];
-            }
-        }
-        fl_lds_order();
-        // (e) the anchors of the wave's sub-pieces (one lane per sub-piece, bits in registers)
-        if (lane < FL_TOK_SPAN / 64) {
-            const uint32_t sub = wave * (FL_TOK_SPAN / 64) + lane;
-            uint32_t a = entry64[sub];
-            const uint32_t base = h0 + (sub << 6);
-            const uint32_t end = min(base + 64u, N);
-            uint32_t m0 = 0, m1 = 0;
-            while (a < end) {
-                const uint32_t o = a - base;
-                if (o < 32)
-                    m0 |= 1u << o;
-                else
-                    m1 |= 1u << (o - 32);
-                a = J1[a - h0];
-            }
-            marks[2 * sub] = m0;
-            marks[2 * sub + 1] = m1;
-        }
-        fl_lds_order();
-        if (h0 == 0) fl_prof_mark(21);
-        // (f) tokens per wave, then emit
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t q = span0 + r * 64 + lane - h0;
-            const bool mk = (marks[q >> 5] >> (q & 31)) & 1;
-            cnt += mk ? (d[r] ? ((d[r] >> 23) & 0xff) + 1 : 1) : 0;
-        }
-        cnt = fl_wave_sum(cnt);
-        if (lane == 0) wtot[wave] = cnt;
-        __syncthreads();
-        if (h0 == 0) fl_prof_mark(25);
-        uint32_t run = run0;
-        for (uint32_t w = 0; w < 16; w++) {
-            if (w < wave) run += wtot[w];
-            run0 += wtot[w];
-        }
-#pragma unroll 1  // (rolled: the descriptors rotate through d[0])
-        for (int r = 0; r < (int)FL_TOK_R; r++) {
-            const uint32_t p = span0 + r * 64 + lane;
-            const uint32_t q = p - h0;
-            const bool mk = (marks[q >> 5] >> (q & 31)) & 1;
-            const uint32_t dd = d[0];
-#pragma unroll
-            for (int k = 0; k + 1 < (int)FL_TOK_R; k++) d[k] = d[k + 1];
-            d[FL_TOK_R - 1] = dd;
-            const uint32_t nl = mk ? (dd ? ((dd >> 23) & 0xff) : 1u) : 0u;  // literals of this anchor
-            const uint32_t nt = mk ? (dd ? nl + 1 : 1u) : 0u;
-            const uint32_t incl = fl_wave_incl_scan_dpp(nt);
-            uint32_t idx = run + incl - nt;
-            run += __builtin_amdgcn_readlane(incl, 63);
-            for (uint32_t x = 0; x < nl; x++) {
-                const uint32_t byte = fl_win_byte(winp, q + x);
-                tokens[idx] = FL_TOK_LIT(byte);
-                atomicAdd(&hist[idx >> 15][byte], 1u);
-                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
-                idx++;
-            }
-            if (mk && dd) {
-                const uint32_t ll = (dd >> 15) & 0xff, d0 = dd & 0x7fff;
-                tokens[idx] = (1u << 23) | (ll << 15) | d0;
-                atomicAdd(&hist[idx >> 15][257 + fl_len_index(ll)], 1u);
-                atomicAdd(&hist[idx >> 15][286 + fl_dist_code(d0)], 1u);
-                // a match of at least `lazy` goes out at its own visit, a shorter one at the next
-                // (deflate.zig:171-173 vs 182-184); rp at that moment decides the Q1 input slice
-                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
-            }
-        }
-        __syncthreads();  // wtot, winp and the pointer tables are reused by the next part
-        if (h0 == 0) fl_prof_mark(22);
-    }
-    fl_prof_mark(27);
-    // block boundaries (deflate.zig:227-230, 268-288) and histograms
-    const uint32_t total = run0;
-    const uint32_t nblk = total >= FL_MAX_TOKENS ? 2 : 1;
-    uint32_t* hg = hist_all + (uint64_t)ck.first_block * 320;
-    for (uint32_t i = tid; i < 640; i += FL_TOK_THREADS)
-        if (i < 320 * nblk) hg[i] = (&hist[0][0])[i];
-    if (tid == 0) {
-        ntok_all[c] = total;
-        const uint32_t v1 = v1_sh;
-        plan0->no_input = 0;
-        plan1->no_input = 0;
-        if (nblk == 1) {
-            plan0->valid = 1;
-            plan0->tok_start = 0;
-            plan0->tok_count = total;
-            plan0->in_start = 0;
-            plan0->in_len = N;
-            plan0->final_block = 1;
-            plan1->valid = 0;
-        } else {
-            plan0->valid = 1;
-            plan0->tok_start = 0;
-            plan0->tok_count = FL_MAX_TOKENS;
-            plan0->in_start = 0;
-            plan0->in_len = v1;
-            plan0->final_block = 0;
-            plan1->valid = 1;
-            plan1->tok_start = FL_MAX_TOKENS;
-            plan1->tok_count = total - FL_MAX_TOKENS;
-            plan1->in_start = v1;
-            plan1->in_len = N - v1;
-            plan1->final_block = 1;
-        }
-    }
-}

@@ -356,11 +356,16 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             // the rest comes from memory: a third of the loads.
             const uint32_t wkeep = sub ? PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u : 0u;          // window dwords that stay
             const uint32_t pkeep = sub ? (PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u : 0u;         // link dwords that stay
-            const uint32_t ash = (uint32_t)((uintptr_t)(src + r0) & 3);
-            const uint32_t* a32 = (const uint32_t*)(src + r0 - ash);
-            const uint32_t ndw = (Nr + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
+            // The loads are 16 bytes wide: a granule of the input (aligned; the window is that shifted by sh16 bytes: dshift
+            // dwords and ash bytes) and the first dword of the granule behind it per four window dwords, eight links per
+            // load -- a quarter of the vector-memory instructions of one dword per load (staging was 9 % of the kernel and
+            // bound by their issue).
+            const uint32_t sh16 = (uint32_t)((uintptr_t)(src + r0) & 15);
+            const uint32_t ash = sh16 & 3u, dshift = sh16 >> 2;
+            const uint4* src16 = (const uint4*)(src + r0 - sh16);
+            const uint32_t ngran = (Nr + sh16 + 15) >> 4;  // granules that hold at least one byte of the input
             const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
-            const uint32_t* pv2 = (const uint32_t*)(pvg + r0);    // r0 is even
+            const uint4* pv4 = (const uint4*)(pvg + r0);         // (r0 * 2 bytes is a multiple of 16)
             uint32_t* prv2 = (uint32_t*)prv;
             auto put_win = [&](uint32_t i, uint32_t lo, uint32_t hi) {
                 uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, ash);
@@ -376,40 +381,56 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 hi16 = hi16 > r0 ? hi16 - r0 : 0u;
                 if (i < PZ_PRV_N / 2) prv2[i] = lo16 | (hi16 << 16);
             };
+            // granule G holds the window dwords 4 G - dshift .. 4 G - dshift + 3 (those from `first` on are written)
+            auto put_gran = [&](uint32_t G, const uint4& g, uint32_t nx, uint32_t first) {
+                const uint32_t d[5] = {g.x, g.y, g.z, g.w, nx};
+#pragma unroll
+                for (uint32_t jj = 0; jj < 4; jj++) {
+                    const int32_t i = (int32_t)(4 * G + jj) - (int32_t)dshift;
+                    if (i >= (int32_t)first) put_win((uint32_t)i, d[jj], d[jj + 1]);
+                }
+            };
+            auto load_gran = [&](uint32_t G, uint4& g, uint32_t& nx) {
+                g = G < ngran ? src16[G] : make_uint4(0, 0, 0, 0);
+                nx = G + 1 < ngran ? ((const uint32_t*)(src16 + G + 1))[0] : 0u;
+            };
+            auto put_links = [&](uint32_t i4, const uint4& v) {
+                put_prv(4 * i4, v.x);
+                put_prv(4 * i4 + 1, v.y);
+                put_prv(4 * i4 + 2, v.z);
+                put_prv(4 * i4 + 3, v.w);
+            };
             if (!sub) {
                 // everything a thread stages is requested before anything is written: one round of memory latency
-                constexpr uint32_t WB = (PZ_WIN_DW + PZ_THREADS - 1) / PZ_THREADS, PB = (PZ_PRV_N / 2 + PZ_THREADS - 1) / PZ_THREADS;
-                uint32_t lo[WB], hi[WB], lv[PB];
+                constexpr uint32_t WG = ((PZ_WIN_DW + 6) / 4 + PZ_THREADS - 1) / PZ_THREADS, PG = (PZ_PRV_N / 8 + PZ_THREADS - 1) / PZ_THREADS;
+                uint4 wg[WG], lg[PG];
+                uint32_t wx[WG];
 #pragma unroll
-                for (uint32_t u = 0; u < WB; u++) {
-                    const uint32_t i = u * PZ_THREADS + tid;
-                    lo[u] = i < ndw ? a32[i] : 0u;
-                    hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
+                for (uint32_t u = 0; u < WG; u++) load_gran(u * PZ_THREADS + tid, wg[u], wx[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < PG; u++) {
+                    const uint32_t i4 = u * PZ_THREADS + tid;
+                    lg[u] = 8 * i4 < nb_pos ? pv4[i4] : make_uint4(0, 0, 0, 0);
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < PB; u++) {
-                    const uint32_t i = u * PZ_THREADS + tid;
-                    lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
-                }
+                for (uint32_t u = 0; u < WG; u++) put_gran(u * PZ_THREADS + tid, wg[u], wx[u], 0u);
 #pragma unroll
-                for (uint32_t u = 0; u < WB; u++) put_win(u * PZ_THREADS + tid, lo[u], hi[u]);
-#pragma unroll
-                for (uint32_t u = 0; u < PB; u++) put_prv(u * PZ_THREADS + tid, lv[u]);
+                for (uint32_t u = 0; u < PG; u++) put_links(u * PZ_THREADS + tid, lg[u]);
             } else {
                 // the new part: loads first ...
-                constexpr uint32_t WN = (PZ_WIN_DW - (PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u) + PZ_THREADS - 1) / PZ_THREADS;
-                constexpr uint32_t PN = (PZ_PRV_N / 2 - (PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u + PZ_THREADS - 1) / PZ_THREADS;
-                uint32_t lo[WN], hi[WN], lv[PN];
+                constexpr uint32_t WNEW = (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u;                       // window dwords that come from memory
+                constexpr uint32_t PNEW = PZ_PRV_N / 2 - (PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u;  // link dwords
+                constexpr uint32_t WNG = ((WNEW + 6) / 4 + PZ_THREADS - 1) / PZ_THREADS, PNG = (PNEW / 4 + PZ_THREADS - 1) / PZ_THREADS;
+                static_assert(PNEW % 4 == 0 && ((PZ_PRV_N - (PZ_TA - FL_MAX_DIST - PZ_MARGIN)) / 2u) % 4 == 0, "whole 16-byte loads of links");
+                const uint32_t Gfirst = (wkeep + dshift) >> 2;
+                uint4 wg[WNG], lg[PNG];
+                uint32_t wx[WNG];
 #pragma unroll
-                for (uint32_t u = 0; u < WN; u++) {
-                    const uint32_t i = wkeep + u * PZ_THREADS + tid;
-                    lo[u] = i < ndw ? a32[i] : 0u;
-                    hi[u] = (ash && i + 1 < ndw) ? a32[i + 1] : 0u;
-                }
+                for (uint32_t u = 0; u < WNG; u++) load_gran(Gfirst + u * PZ_THREADS + tid, wg[u], wx[u]);
 #pragma unroll
-                for (uint32_t u = 0; u < PN; u++) {
-                    const uint32_t i = pkeep + u * PZ_THREADS + tid;
-                    lv[u] = 2 * i < nb_pos ? pv2[i] : 0u;
+                for (uint32_t u = 0; u < PNG; u++) {
+                    const uint32_t i4 = pkeep / 4 + u * PZ_THREADS + tid;
+                    lg[u] = (8 * i4 < nb_pos && 4 * i4 < PZ_PRV_N / 2) ? pv4[i4] : make_uint4(0, 0, 0, 0);
                 }
                 // ... then what stays: read by everybody, a barrier, written r0 positions further down
                 constexpr uint32_t WK = ((PZ_WIN_DW - (PZ_TA - FL_MAX_DIST - PZ_MARGIN) / 4u) + PZ_THREADS - 1) / PZ_THREADS;
@@ -443,9 +464,9 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < WN; u++) put_win(wkeep + u * PZ_THREADS + tid, lo[u], hi[u]);
+                for (uint32_t u = 0; u < WNG; u++) put_gran(Gfirst + u * PZ_THREADS + tid, wg[u], wx[u], wkeep);
 #pragma unroll
-                for (uint32_t u = 0; u < PN; u++) put_prv(pkeep + u * PZ_THREADS + tid, lv[u]);
+                for (uint32_t u = 0; u < PNG; u++) put_links(pkeep / 4 + u * PZ_THREADS + tid, lg[u]);
             }
         }
         __syncthreads();
