@@ -879,6 +879,11 @@ struct fo_deflate {
     int has_prev_match, has_prev_literal;
     uint32_t prev_match;
     uint8_t prev_literal;
+    /* what every flushTokens handed to the block writer, in stream offsets (tests: the window-slide path against the
+     * independent model of tests/golden/make_slide_fixtures.py): tokens, final, has input, slice start, slice length */
+    uint64_t slid_total;
+    uint64_t* blk_log;
+    size_t blk_log_len, blk_log_cap;
     /* simple compressors: deflate.zig:456-457 */
     uint8_t sbuf[65535];
     size_t swp;
@@ -899,7 +904,12 @@ void fo_deflate_free(fo_deflate* d) {
     if (!d) return;
     fo_sink_free(&d->out);
     free(d->bw.tok_log);
+    free(d->blk_log);
     free(d);
+}
+const uint64_t* fo_deflate_block_log(const fo_deflate* d, size_t* count) {
+    *count = d->blk_log_len / 5;
+    return d->blk_log;
 }
 const uint8_t* fo_deflate_output(const fo_deflate* d, size_t* len) {
     *len = d->out.len;
@@ -917,6 +927,20 @@ static void df_flush_tokens(fo_deflate* d, int flush_opt) {
     int has_input = d->win.fp >= 0;
     const uint8_t* input = has_input ? d->win.buffer + d->win.fp : NULL;
     size_t input_len = has_input ? d->win.rp - (size_t)d->win.fp : 0;
+    if (d->bw.log_tokens) {
+        if (d->blk_log_len + 5 > d->blk_log_cap) {
+            d->blk_log_cap = d->blk_log_cap ? d->blk_log_cap * 2 : 320;
+            d->blk_log = (uint64_t*)realloc(d->blk_log, d->blk_log_cap * sizeof(uint64_t));
+            if (!d->blk_log) abort();
+        }
+        uint64_t* e = d->blk_log + d->blk_log_len;
+        e[0] = d->tokens_pos;
+        e[1] = flush_opt == FLUSH_FINAL;
+        e[2] = (uint64_t)has_input;
+        e[3] = has_input ? d->slid_total + (uint64_t)d->win.fp : 0;
+        e[4] = input_len;
+        d->blk_log_len += 5;
+    }
     blockw_write(&d->bw, d->tokens, d->tokens_pos, flush_opt == FLUSH_FINAL, input, input_len,
                  has_input);
     if (flush_opt == FLUSH_FLUSH) blockw_stored_block(&d->bw, NULL, 0, 0);
@@ -1028,6 +1052,7 @@ static void df_compress(fo_deflate* d, const uint8_t* in, size_t n) {
         if (room == 0) {
             df_tokenize(d, FLUSH_NONE);
             uint16_t k = win_slide(&d->win); /* deflate.zig:291-294 */
+            d->slid_total += HIST_LEN;
             lookup_slide(&d->lookup, k);
             continue;
         }

@@ -90,6 +90,8 @@ const uint8_t* fo_deflate_output(const fo_deflate* d, size_t* len);
  * also appended to an internal log. */
 void fo_deflate_log_tokens(fo_deflate* d, int enable);
 const uint32_t* fo_deflate_token_log(const fo_deflate* d, size_t* count);
+/* with the token log on: per flushTokens five values -- tokens, final, has input, slice start (stream offset), slice length */
+const uint64_t* fo_deflate_block_log(const fo_deflate* d, size_t* count);
 
 /* one-shot: compress()+finish().  returns 0, or FO_OUTPUT_TOO_SMALL. */
 int fo_compress(const uint8_t* in, size_t n, int container, int mode,

@@ -82,6 +82,8 @@ def lib():
         L.fo_deflate_log_tokens.argtypes = [C.c_void_p, C.c_int]
         L.fo_deflate_token_log.restype = C.c_void_p
         L.fo_deflate_token_log.argtypes = [C.c_void_p, szp]
+        L.fo_deflate_block_log.restype = C.c_void_p
+        L.fo_deflate_block_log.argtypes = [C.c_void_p, szp]
         _lib = L
     return _lib
 
@@ -208,6 +210,15 @@ class Deflate:
         if not n.value:
             return np.zeros(0, dtype=np.uint32)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+
+    def blocks(self):
+        """(tokens, final, has_input, slice_start, slice_len) of every flushTokens (needs log_tokens)."""
+        n = C.c_size_t(0)
+        p = lib().fo_deflate_block_log(self._h, C.byref(n))
+        if not n.value:
+            return []
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n.value, 5)).copy()
+        return [tuple(int(x) for x in row) for row in a]
 
     def close(self):
         if self._h:

@@ -250,3 +250,24 @@ def test_adversarial_long_streams_match_oracle():
         assert st == [0] * len(datas)
         for d, got in zip(datas, outs):
             assert got == O.compress(d, O.GZIP, level), (level, len(d))
+
+
+def test_whole_stream_tokens_match_the_independent_slide_fixtures():
+    # tests/golden/slide: inputs of 150-300 KB with token lists from a pure-Python model of the reference that is
+    # independent of the oracle (tests/golden/make_slide_fixtures.py): the GPU's whole-stream path against it directly
+    import hashlib
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "slide", "fixtures.json")) as f:
+        fix = json.load(f)
+    eng = engine()
+    for key in sorted(fix):
+        name, level = key.split("@")
+        with open(os.path.join(GOLDEN, "slide", name + ".bin"), "rb") as f:
+            data = f.read()
+        outs, st = eng.compress_many([data], O.RAW, int(level))
+        assert st == [0], key
+        toks = eng.debug_tokens(0)
+        assert len(toks) == fix[key]["tokens"], key
+        assert hashlib.sha256(np.ascontiguousarray(toks, dtype="<u4").tobytes()).hexdigest() == fix[key]["sha256"], key
+        assert pyzlib.decompress(outs[0], -15) == data
