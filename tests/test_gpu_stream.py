@@ -1,6 +1,7 @@
 """GPU parity tests of the whole-stream path (levels 4..9, inputs longer than 65535 bytes):
 one deflate stream per input, byte-identical to the reference's sliding-window compressor
 (deflate.zig:304-321, SlidingWindow.zig:36-44, Lookup.zig:43-51) as restated by the oracle."""
+import os
 import zlib as pyzlib
 
 import numpy as np
