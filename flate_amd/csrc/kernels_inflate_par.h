@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_resolve(const uint32_t* __r
 #pragma unroll
                     for (int y = 0; y < 4; y++) {
                         const uint32_t xa = (aw[w] >> (8 * y)) & 0xff, xd = (x >> (8 * y)) & 0xff;
-                        if (xd) aw[w] = (aw[w] & ~(0xffu << (8 * y))) | ((uint32_t)prev[((xd - 1u) << 8) | xa] << (8 * y));
+                        if (xd) aw[w] = (aw[w] & ~(0xffu << (8 * y))) | ((uint32_t)prev[(((xd - 1u) << 8) | xa) & (FP_TAIL - 1u)] << (8 * y));  // (masked as in k_span_fix: a ^ b is at most 128 unless the two runs disagree)
                     }
                 }
                 mine[8 * tid + 4 * q + w] = aw[w];

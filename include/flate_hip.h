@@ -163,6 +163,12 @@ int flate_hip_compress_flush(flate_hip_handle h, const uint8_t* in, uint64_t n, 
  * number of bytes produced; status[i] the reference's error name for a bad stream.
  * consumed (optional, may be NULL) receives the input bytes used by each stream, so a
  * caller can walk concatenated members the way Inflate.reset() does (inflate.zig:301-309).
+ * Stream order: the call always waits once for the offsets; beyond that a batch of short streams is
+ * only enqueued (set_sync(0)).  A batch with long streams (>= 128 KiB, at most 140 of them) is cut
+ * into spans and BLOCKS ON THE HOST three to four times between its kernels (the chain of spans is
+ * followed on the CPU): such a call cannot be captured in a graph or overlapped behind other work on the
+ * stream.  FLATE_HIP_INFLATE_SPANS=0 (environment) or flag bit 0 keeps the old one-workgroup-per-stream path.
+ * Host buffers (FLATE_HIP_MEM_HOST): a slot's bytes beyond out_len[i] may be overwritten with zeros.
  */
 int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                                uint32_t n_chunks, int container, int flags, uint8_t* out,
