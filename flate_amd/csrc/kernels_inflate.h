@@ -313,7 +313,21 @@ struct fl_inf_out {
     uint32_t bias;
     uint32_t rmask;     // ring size - 1
     uint32_t near_max;  // ring size - 260
+    // A far match of at most 64 bytes whose bytes are still on their way from the output buffer (fast rounds): the load
+    // is issued when the match is decoded, the ring gets the bytes (lane i: byte i) when something is about to read the
+    // ring -- a near match, a flush -- or the next far match comes.  What a symbol IS does not depend on what is copied:
+    // the decode goes on in the shadow of the load.
+    uint32_t pend_len;  // 0: none
+    uint32_t pend_vp;   // ring position of its first byte
+    uint32_t pend_val;  // (per lane)
 };
+__device__ __forceinline__ void fl_inf_pend_commit(fl_inf_out& o, uint32_t lane) {
+    if (o.pend_len) {
+        if (lane < o.pend_len) o.ring[(o.pend_vp + lane) & o.rmask] = (uint8_t)o.pend_val;
+        o.pend_len = 0;
+        fl_lds_order();
+    }
+}
 
 // wave-uniform values the compiler cannot prove uniform (anything derived from an LDS load)
 __device__ __forceinline__ uint32_t fl_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -325,6 +339,7 @@ __device__ __forceinline__ uint64_t fl_uni64(uint64_t v) {
 __device__ __forceinline__ void fl_inf_flush(fl_inf_out& o, uint64_t upto, uint32_t lane) {
     const uint64_t a = o.flushed;
     if (upto <= a) return;
+    fl_inf_pend_commit(o, lane);
     fl_lds_order();
     const uint64_t va = a + o.bias, vb = upto + o.bias;  // same low bits as the global addresses
     const uint64_t w0 = (va + 7) >> 3, w1 = vb >> 3;     // whole 8-byte words [w0, w1)
@@ -357,6 +372,7 @@ __device__ __forceinline__ void fl_inf_advance(fl_inf_out& o, uint32_t lane) {
 __device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint32_t distance, uint32_t lane) {
     if (o.wp < distance || length < 3 || length > 258 || distance < 1 || distance > 32768) return 11;
     if (o.wp + length > o.cap) return 100;
+    fl_inf_pend_commit(o, lane);
     const uint32_t vp = (uint32_t)o.wp + o.bias;  // ring positions only need the low bits
     if (distance <= o.near_max) {
         for (uint32_t i0 = 0; i0 < length; i0 += 64) {  // one trip for lengths up to 64
@@ -730,6 +746,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             const uint64_t tm_ = __builtin_readcyclecounter();
 #endif
             if (distance <= near_max) {
+                fl_inf_pend_commit(o, lane);
                 // A match that overlaps itself repeats its first `distance` bytes: every pass
                 // copies as much as is already there (no per-lane modulo), so the period doubles.
                 uint32_t have = distance, done = 0;
@@ -754,11 +771,21 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
                     o.fenced = o.flushed;
                 }
                 const uint8_t* from = o.out + wp - distance;
-                for (uint32_t i0 = 0; i0 < length; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    if (i < length) o.ring[(vp + i) & rmask] = from[i];
+                if (length <= 64u) {
+                    // the bytes are requested now and go to the ring later (fl_inf_out): the one before goes first
+                    const uint32_t v = lane < length ? (uint32_t)from[lane] : 0u;
+                    fl_inf_pend_commit(o, lane);
+                    o.pend_val = v;
+                    o.pend_vp = vp;
+                    o.pend_len = length;
+                } else {
+                    fl_inf_pend_commit(o, lane);
+                    for (uint32_t i0 = 0; i0 < length; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        if (i < length) o.ring[(vp + i) & rmask] = from[i];
+                    }
+                    fl_lds_order();
                 }
-                fl_lds_order();
             }
             adv += length;
             p = p2 + (d & 0xff);
@@ -978,6 +1005,9 @@ __global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const u
     o.wp = 0;
     o.flushed = 0;
     o.fenced = 0;
+    o.pend_len = 0;
+    o.pend_vp = 0;
+    o.pend_val = 0;
     o.bias = (uint32_t)((uintptr_t)o.out & 7);
 
     int rc = fl_inf_header(r, container);
