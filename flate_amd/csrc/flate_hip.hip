@@ -538,7 +538,10 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             }
             {
                 ProfScope ps(h, K_LZ_WALK);
-                hipLaunchKernelGGL(k_lz_walk, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
+                hipLaunchKernelGGL(k_lz_walk<false>, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+                // the chunks k_lz_links<0> found a run of one byte in (workgroups of the other kind return at once)
+                hipLaunchKernelGGL(k_lz_walk<true>, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
             }
         } else {

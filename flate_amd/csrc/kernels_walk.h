@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t fl_lds_add_rtn(uint32_t* lds_word, uint32_t 
 // above its own position, a count that is not the number of earlier bucket members) sends the chunk to the
 // one-position-at-a-time path.
 template <int WHICH>
-__global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_links(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ out_all,
                                                                    uint32_t* __restrict__ cflag) {
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
     __syncthreads();
     // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs (7 bytes more for the 8-byte
     // hash): granules 64 b .. 64 b + 65 (sh + 1023 + 7 < 1056 = 66 granules); lane l loads granule 64 b + l, lanes 0..1 two more
+    uint64_t runny = 0;  // (WHICH 0; wave-uniform) some granule of the chunk is 16 times one byte: a run of 323 holds 19 of them
     auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {
         const uint32_t ga = 64 * b + lane, gb = 64 * b + 64 + lane;
         g0 = ga < n_gran ? src16[ga] : make_uint4(0, 0, 0, 0);
@@ -129,6 +130,10 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
         const uint32_t b = b0 + wave;
         ((uint4*)sb)[lane] = ga0;
         if (lane < 2) ((uint4*)sb)[64 + lane] = ga1;
+        if (WHICH == 0) {  // (a granule that is not whole in the chunk may count: the flag only picks the kernel)
+            const uint32_t bp = (ga0.x & 0xffu) * 0x01010101u;
+            runny |= __ballot(ga0.x == bp && ga0.y == bp && ga0.z == bp && ga0.w == bp);
+        }
         if (b + FL_CHAIN_WAVES < n_blocks) load_block(b + FL_CHAIN_WAVES, ga0, ga1);
         fl_lds_order();
         uint32_t hw[16];   // word of the table, or the lane's dummy word for a position past the end
@@ -187,6 +192,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
             }
         }
     }
+    // (k_lz_walk<true> takes the chunks with long runs of one byte, k_lz_walk<false> the others: cflag 2 / 0)
+    if (WHICH == 0 && __syncthreads_or(runny != 0 ? 1 : 0) && threadIdx.x == 0) cflag[c] = 2u;
 #ifdef FL_CHAIN_FORCE_SLOW
     overtaken = true;  // (test builds: exercise the fallback)
 #endif
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_links(const uint8_t*
 #endif
 
 // lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
+template <bool DEEP>
 __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const uint8_t* __restrict__ in,
                                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                                            const uint16_t* __restrict__ lnk,
@@ -265,7 +273,10 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
     uint32_t* trueg = true_all + (ck.pos_off >> 5);
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
     if (N == 0) return;
-    if (cflag[c] == 1u) {
+    const uint32_t kind = cflag[c];
+    if (kind != 1u && (kind == 2u) != DEEP) return;  // (the other instantiation's chunk)
+    if (kind == 1u && DEEP) return;
+    if (kind == 1u) {
         // The chunk is one repeated byte (k_lz_links<0> saw it and built no chains): see k_lz_parse.
         for (uint32_t k = tid; 2 + FL_MAX_MATCH * k < N || k < 1; k += WK_THREADS) {
             if (k == 0) {
@@ -328,6 +339,28 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
     bool marked = false;
     tX[m] = (uint16_t)PZ_NONE;
     __syncthreads();
+    // A segment that lies DEEP inside a run of one byte -- bytes [seg0 - 1, seg0 + 64 + 258) all equal -- is parsed in closed
+    // form: from any entry e in it the reference finds (258, distance 1) at once (the candidate e - 1 is the head of e's
+    // chain and matches 258 bytes >= nice >= lazy) and goes on at e + 258.  Such segments cost no trips, and a change of the
+    // path's phase crosses a whole run of them inside ONE round of the stitch (4 KiB of padding took 16 rounds).
+    bool deep = false;
+    if (DEEP && m >= 1 && seg0 + WK_SEG + FL_MAX_MATCH <= N) {
+        const uint32_t x0 = seg0 - 1u, x1 = seg0 + WK_SEG + FL_MAX_MATCH;
+        const uint32_t bp = (win32[x0 >> 2] >> (8u * (x0 & 3u)) & 0xffu) * 0x01010101u;
+        deep = true;
+        for (uint32_t x = x0; x < x1; x += 8) {
+            uint32_t w0, w1;
+            fl_lds_load8(win32, x, w0, w1);
+            uint64_t d = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+            if (x1 - x < 8u) d &= (1ull << (8u * (x1 - x))) - 1ull;
+            if (d) {
+                deep = false;
+                break;
+            }
+        }
+    }
+    const bool wg_deep = DEEP && __syncthreads_or(deep ? 1 : 0) != 0;
+    const uint32_t DEEP_DESC = 0x80000000u | ((uint32_t)(FL_MAX_MATCH - 3) << 15);  // j = 0, 258 bytes, distance 1
 
     enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
     for (uint32_t round = 0;; round++) {
@@ -347,10 +380,18 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         bool deferred = false; // this lane's entry is not the one it is resolved for, but may still move: next round
         bool fixing = false;   // this lane parses its segment again in this round ...
         uint32_t ex_used = 0;  // ... and this is the exit the round's path assumed for it
+        bool moved = false;  // a deep segment got another entry in this round: the path has changed
         if (round == 0) {
             if (m < nseg) {
                 st = ST_SPEC;
                 a = seg0;
+            }
+            if (DEEP && deep) {  // the own parse in closed form; what is left is the wait for the lane before
+                descg[seg0] = DEEP_DESC;
+                A = 1ull;
+                X = seg0 + FL_MAX_MATCH;
+                __hip_atomic_store(&tX[m], (uint16_t)~X, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                st = ST_WAIT;
             }
         } else {
 #ifdef WK_PROF
@@ -390,6 +431,30 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
             }
             __syncthreads();
             if (marked) y_in = tEnt[m];
+            if (DEEP && wg_deep) {
+                // deep segments take their new entries at once and hand their exits on: a run is crossed in this round
+                for (uint32_t it = 0; it < 1024u; it++) {
+                    bool upd = false;
+                    if (deep && marked && y_in != res_entry) {
+                        descg[y_in] = DEEP_DESC;
+                        F = 1ull << (y_in - seg0);
+                        Z = PZ_NONE;
+                        res_entry = y_in;
+                        res_exit = y_in + FL_MAX_MATCH;  // (< N: the segment is deep)
+                        tEnt[res_exit >> 6] = (uint16_t)res_exit;
+                        tNxt[0][res_exit >> 6] = (uint16_t)m;
+                        upd = true;
+                        moved = true;
+                    }
+                    if (!__syncthreads_or(upd ? 1 : 0)) break;
+                    const uint32_t e2 = tEnt[m];
+                    if (m < nseg && e2 != PZ_NONE && e2 != y_in) {  // (handed on by a deep segment: on the path now)
+                        y_in = e2;
+                        marked = true;
+                    }
+                    __syncthreads();
+                }
+            }
             const bool need = marked && y_in != res_entry;
             // A segment is parsed again only when the segment the path comes from is settled for the entry IT got: else that
             // one's exit -- this one's entry -- may still move.  (A run of one byte is entered 258 bytes further in every
@@ -520,6 +585,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                                 res_entry = v;
                                 Z = v;
                                 res_exit = X;
+                            } else if (DEEP && deep) {  // (closed form)
+                                descg[v] = DEEP_DESC;
+                                F = 1ull << (v - seg0);
+                                res_entry = v;
+                                Z = PZ_NONE;
+                                res_exit = v + FL_MAX_MATCH;
                             } else {
                                 st = ST_FIX;
                                 a = v;
@@ -868,7 +939,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
 #endif
         // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with
         // it the marks and entries found above -- no round to confirm it.
-        if (round >= 1 && !__syncthreads_or(((fixing && res_exit != ex_used) || deferred) ? 1 : 0)) break;
+        if (round >= 1 && !__syncthreads_or(((fixing && res_exit != ex_used) || deferred || moved) ? 1 : 0)) break;
     }
     // ---- the true anchors
     if (m < nseg) {
