@@ -174,3 +174,49 @@ print("ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_config2_at_its_real_size_sampled_parity_and_round_trip():
+    # BASELINE.json configs[1] at full size: raw deflate level 6 of 1 GiB of the benchmark text in 16385 chunks of 65535
+    # bytes -- 256 chunks spread over the batch byte for byte against the oracle, every stream through the GPU inflater
+    # back to the input (the size-independent property), lengths and statuses of all of them.
+    import torch
+    from flate_amd import synth
+    eng = engine()
+    dev = torch.device("cuda", 0)
+    n, chunk = 1 << 30, 65535
+    data = synth.text_torch(synth.SEED_TEXT, n, device=dev)
+    off = synth.split_offsets(n, chunk)
+    k = len(off) - 1
+    assert k == 16385
+    caps = np.array([(eng.compress_bound(int(off[i + 1] - off[i]), 0, 6) + 7) & ~7 for i in range(k)], dtype=np.uint64)
+    oo = np.zeros(k + 1, dtype=np.uint64)
+    np.cumsum(caps, out=oo[1:])
+    io = torch.from_numpy(off.astype(np.int64)).to(dev)
+    ot = torch.from_numpy(oo.astype(np.int64)).to(dev)
+    out = torch.empty(int(oo[-1]) + 8, dtype=torch.uint8, device=dev)
+    ol = torch.zeros(k, dtype=torch.int64, device=dev)
+    st = torch.zeros(k, dtype=torch.int32, device=dev)
+    eng.compress_device(data.data_ptr(), io.data_ptr(), k, 0, 6, out.data_ptr(), ot.data_ptr(), ol.data_ptr(), st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    lens = ol.cpu().numpy()
+    for i in list(range(0, k, 65)) + [k - 2, k - 1]:
+        a, b = int(off[i]), int(off[i + 1])
+        got = out[int(oo[i]):int(oo[i]) + int(lens[i])].cpu().numpy().tobytes()
+        assert got == O.compress(data[a:b].cpu().numpy().tobytes(), O.RAW, 6), i
+    # every stream back through the inflater (the streams packed back to back first): slots = the input's own layout
+    from flate_amd import sharded
+    comp_off_np = np.zeros(k + 1, dtype=np.int64)
+    np.cumsum(lens, out=comp_off_np[1:])
+    comp = torch.empty(int(comp_off_np[-1]) + 8, dtype=torch.uint8, device=dev)
+    comp_off = torch.from_numpy(comp_off_np).to(dev)
+    sharded.compact(out, torch.from_numpy(oo[:-1].astype(np.int64)).to(dev), ol, comp, comp_off, engine=eng)
+    out, ot = comp, comp_off
+    dec = torch.empty(n + 8, dtype=torch.uint8, device=dev)
+    dl = torch.zeros(k, dtype=torch.int64, device=dev)
+    ds = torch.zeros(k, dtype=torch.int32, device=dev)
+    eng.decompress_device(out.data_ptr(), ot.data_ptr(), k, 0, 0, dec.data_ptr(), io.data_ptr(), dl.data_ptr(), ds.data_ptr())
+    torch.cuda.synchronize()
+    assert int(ds.abs().sum().item()) == 0
+    assert bool(torch.equal(dec[:n], data))
