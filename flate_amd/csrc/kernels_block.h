@@ -151,10 +151,23 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
         }
         uint32_t c = 0xffffffffu;
         uint32_t i = lo;
-        while (i < hi && (((uintptr_t)(src + i)) & 3)) c = tab[0][(c ^ src[i++]) & 0xff] ^ (c >> 8);
-        for (; i + 4 <= hi; i += 4) {
-            c ^= *(const uint32_t*)(src + i);
-            c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+        // (16 bytes per load, the next ones requested before these are folded: the lanes' slices are 1 KiB apart, every load
+        // instruction touches 64 cache lines -- with one dword per load the kernel took 1.07 ms for 2705 chunks)
+        while (i < hi && (((uintptr_t)(src + i)) & 15)) c = tab[0][(c ^ src[i++]) & 0xff] ^ (c >> 8);
+        if (i + 16 <= hi) {
+            uint4 v = *(const uint4*)(src + i);
+            for (; i + 16 <= hi; i += 16) {
+                const uint4 cur = v;
+                if (i + 32 <= hi) v = *(const uint4*)(src + i + 16);
+                c ^= cur.x;
+                c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+                c ^= cur.y;
+                c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+                c ^= cur.z;
+                c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+                c ^= cur.w;
+                c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+            }
         }
         for (; i < hi; i++) c = tab[0][(c ^ src[i]) & 0xff] ^ (c >> 8);
         c = (hi > lo) ? ~c : 0u;  // crc of an empty slice is 0
@@ -173,7 +186,24 @@ __global__ __launch_bounds__(64) void k_checksum(const uint8_t* __restrict__ in,
     } else if (prm.container == 2) {
         // Adler-32 pieces with a = b = 0 start: A = sum d_k, B = sum (n - k) d_k
         uint32_t A = 0, B = 0;
-        for (uint32_t i = lo; i < hi; i++) {  // <= 1024 bytes: B < 2^28, no overflow
+        uint32_t i = lo;  // <= 1024 bytes: B < 2^28, no overflow
+        for (; i < hi && (((uintptr_t)(src + i)) & 15); i++) {
+            A += src[i];
+            B += A;
+        }
+        for (; i + 16 <= hi; i += 16) {  // (16 bytes per load: see the CRC above)
+            const uint4 v = *(const uint4*)(src + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    A += (w[k] >> (8 * bb)) & 0xffu;
+                    B += A;
+                }
+            }
+        }
+        for (; i < hi; i++) {
             A += src[i];
             B += A;
         }
