@@ -639,14 +639,23 @@ __device__ __forceinline__ void fl_br_resync(fl_bitr& r) {
     }
 }
 
-// One fast round of a dynamic block.  Every lane decodes, from the LDS tables, the literal /
-// length code and the distance code that would start at "current bit + lane"; the wave then
-// walks the chain of real symbol starts with scalar reads of those per-lane results, so the
-// serial part of a symbol is a handful of scalar instructions instead of two dependent LDS
-// round trips.  Anything out of the ordinary (a code longer than the tables, an invalid symbol
-// or match, the end of the input or of the output slot in sight) is left to the symbol-at-a-time
-// path, which owns the reference's error order.  Returns 0 = go on, 1 = end of block,
-// 2 = the next symbol needs the slow path, >= 7 a match error code.
+// One fast round of a dynamic block: every token that starts in the next 64 bits of the stream.
+//
+// (1) Every lane decodes the WHOLE token that would start at "current bit + lane" from the LDS tables (literal / length
+//     code + extra bits, and for a length the distance code + extra bits behind it: a 64-bit window per lane), giving
+//     its size in bits `nb` and in output bytes `olen`.
+// (2) The only serial step left is the chain of real token starts, p -> p + nb[p]: one v_readlane, one s_bitset and one
+//     s_add per token (the PMC counters of round 3's walk said 51 scalar instructions per token, with the CU's scalar
+//     issue saturated: SQ_INSTS_SALU + BRANCH = 0.93 per cycle and CU).  Its result is the mask S of lanes that are tokens.
+// (3) Output offsets by a prefix sum over S; the checks that need them (room in the slot, distance against the history)
+//     cut S in front of the first token that fails: that one is left to the symbol-at-a-time path, which owns the
+//     reference's error order -- as is a code longer than the tables, an invalid symbol, the end of input in sight.
+// (4) Tokens whose source lies wholly before this round's output (nearly all matches of text) are copied TOGETHER:
+//     output byte b of the round belongs to lane b, which finds its token (owner lanes through a small LDS array and a
+//     max-scan), takes the literal or reads ring / output buffer at b - distance and writes the ring.  From the first
+//     token that reads this round's own output (or from 260 bytes on: the ring must not be lapped) the rest goes one
+//     match at a time, as before.
+// Returns 0 = go on, 1 = end of block, 2 = the next symbol needs the slow path.
 #ifdef FL_INF_COUNT
 #define FL_T0() const uint64_t t0_ = __builtin_readcyclecounter()
 #define FL_TACC(slot)                                                                          \
@@ -657,101 +666,170 @@ __device__ __forceinline__ void fl_br_resync(fl_bitr& r) {
 #define FL_T0()
 #define FL_TACC(slot)
 #endif
-#define FL_INF_FAST_MIN_BITS 160  // a round looks at 64 + 32 bits and consumes at most 63 + 48
+#define FL_INF_FAST_MIN_BITS 192  // a round looks at 63 + 64 bits and consumes at most 63 + 36
+#define FL_INF_PAR_MAX 260u       // bytes of one round that are copied together (ring - near_max: nothing live is lapped)
+__device__ __forceinline__ uint32_t fl_wave_incl_max_dpp(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
     FL_T0();
     const uint64_t pos = (uint64_t)r.nbytes * 8 - (uint64_t)r.left;
     const uint32_t byte0 = (uint32_t)(pos >> 3);
-    if (byte0 + 16 > r.in_loaded) fl_br_commit_half(r);
-    // the 32 stream bits that start at pos + lane
+    if (byte0 + 24 > r.in_loaded) fl_br_commit_half(r);
+    // ---- (1) the token that starts at pos + lane ----
     const uint32_t bp = ((byte0 & (FL_INF_INRING - 1)) << 3) + ((uint32_t)pos & 7) + lane;  // bit index in the ring
     const uint32_t di = bp >> 5;
-    const uint32_t lo = r.inring[di & (FL_INF_INRING / 4 - 1)], hi = r.inring[(di + 1) & (FL_INF_INRING / 4 - 1)];
-    const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, bp & 31);
-    const uint32_t le = ws->lit_lut[w & ((1u << FL_INF_LIT_BITS) - 1)];
-    const uint32_t de = ws->dst_lut[w & ((1u << FL_INF_DST_BITS) - 1)];
-    // literal / length result of this start: kind << 30 | value << 8 | bits up to the distance code
-    uint32_t lp = 0;
-    {
-        const uint32_t sym = le & 511, cb = (le >> 9) & 15, eb = (le >> 13) & 15, val = le >> 17;
-        if (le != 0 && eb != 15) {
-            if (sym < 256)
-                lp = (1u << 30) | (val << 8) | cb;
-            else if (sym == 256)
-                lp = (2u << 30) | cb;
-            else
-                lp = (3u << 30) | ((val + ((w >> cb) & ((1u << eb) - 1))) << 8) | (cb + eb);
-        }
-    }
-    // distance result: 1 << 31 | distance << 8 | bits
-    uint32_t dp = 0;
-    {
-        const uint32_t cb = (de >> 9) & 15, eb = (de >> 13) & 15, val = de >> 17;
-        if (de != 0 && eb != 15) dp = (1u << 31) | ((val + ((w >> cb) & ((1u << eb) - 1))) << 8) | (cb + eb);
-    }
-    // The walk below is wave-uniform; the compiler cannot see that for anything that came out of
-    // LDS, so the state is pinned to scalar registers explicitly.
+    const uint32_t IM = FL_INF_INRING / 4 - 1;
+    const uint32_t d0 = r.inring[di & IM], d1 = r.inring[(di + 1) & IM], d2 = r.inring[(di + 2) & IM];
+    const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, bp & 31);  // stream bits [pos + lane, + 32)
+    const uint32_t w1 = __builtin_amdgcn_alignbit(d2, d1, bp & 31);  // ... [+ 32, + 64)
+    const uint32_t le = ws->lit_lut[w0 & ((1u << FL_INF_LIT_BITS) - 1)];
+    const uint32_t lsym = le & 511, lcb = (le >> 9) & 15, leb = (le >> 13) & 15, lval = le >> 17;
+    const bool lok = le != 0 && leb != 15;
+    const bool is_lit = lok && lsym < 256, is_eob = lok && lsym == 256, is_len = lok && lsym > 256;
+    const uint32_t lbits = lcb + leb;  // at most 10 + 5
+    const uint32_t wd = __builtin_amdgcn_alignbit(w1, w0, lbits & 31);  // the 32 bits behind the length code
+    const uint32_t de = ws->dst_lut[wd & ((1u << FL_INF_DST_BITS) - 1)];
+    const uint32_t dcb = (de >> 9) & 15, deb = (de >> 13) & 15, dval = de >> 17;
+    const bool is_match = is_len && de != 0 && deb != 15;
+    const uint32_t length = lval + ((w0 >> lcb) & ((1u << leb) - 1));
+    const uint32_t dist = dval + ((wd >> dcb) & ((1u << deb) - 1));
+    // anything that is not a plain literal or match ends the chain: it is the last member of S
+    const uint32_t nb = is_lit ? lcb : is_match ? lbits + dcb + deb : 64u;
+    const uint32_t olen = is_lit ? 1u : is_match ? length : 0u;
+    // The rest is wave-uniform; the compiler cannot see that for anything that came out of LDS, so the state is
+    // pinned to scalar registers explicitly.
     const uint64_t wp0 = fl_uni64(o.wp);
     const uint64_t cap = fl_uni64(o.cap);
     const uint32_t room0 = (uint32_t)(cap - wp0 < 0x40000000ull ? cap - wp0 : 0x40000000ull);  // output bytes left (saturated)
-    if (room0 < 64) return 2;  // a round emits at most 64 literals: no per-literal check below
     const uint32_t hist0 = (uint32_t)(wp0 < 0x100000ull ? wp0 : 0x100000ull);  // bytes a match may reach back (saturated)
     int32_t unfl0 = (int32_t)fl_uni((uint32_t)(wp0 - o.flushed));                // unflushed bytes = unfl0 + adv
     const uint32_t bias = fl_uni(o.bias), rmask = fl_uni(o.rmask), near_max = fl_uni(o.near_max);
     const uint32_t vp0 = (uint32_t)wp0 + bias;  // ring position of output byte wp0 (low bits)
-    const uint32_t my_byte = (lp >> 8) & 0xff;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint64_t lits = 0;  // start lanes of the literals met since the last match: they go out together
-    uint32_t adv = 0;   // output bytes produced in this round: the only running output counter
-    uint32_t p = 0;
-    int rc = 0;
-#ifdef FL_INF_COUNT  // tuning build only (tools/inflate_probe.py): cycles of the table lookups vs the walk
-    if (__builtin_amdgcn_readlane((int)lp, 0) == 0x7fffffff) rc = 5;  // wait for lp
+#ifdef FL_INF_COUNT  // tuning build only (tools/inflate_probe.py): cycles of the table lookups vs the rest
+    if (__builtin_amdgcn_readlane((int)nb, 0) == 0x7fffffff) return 5;  // wait for the lookups
     FL_TACC(44);
     const uint64_t t1_ = __builtin_readcyclecounter();
 #endif
-    // the literals collected in `lits` are written by their own lanes, in chain order
-#define FL_INF_PUT_LITS()                                                                                \
-    do {                                                                                                 \
-        if (lits) {                                                                                      \
-            if ((lits >> lane) & 1)                                                                      \
-                o.ring[(vp0 + adv + (uint32_t)__popcll(lits & lt_mask)) & rmask] = (uint8_t)my_byte;      \
-            adv += (uint32_t)__popcll(lits);                                                             \
-            lits = 0;                                                                                    \
-        }                                                                                                \
-    } while (0)
-    while (p < 64) {
-        uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
-        // a run of literals: a loop of its own so that it carries nothing but p and the mask
-        while ((l >> 30) == 1) {
-            lits |= 1ull << p;
-            p += l & 0xff;
-            if (p >= 64) break;
-            l = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)p);
-        }
-        if (p >= 64) break;
-        const uint32_t kind = l >> 30;
-        if (kind == 3) {
-            const uint32_t p2 = p + (l & 0xff);
-            if (p2 >= 64) break;  // the distance code starts beyond this round's lanes
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dp, (int)p2);
-            const uint32_t length = (l >> 8) & 0x1ff, distance = (d >> 8) & 0xffff;
-            FL_INF_PUT_LITS();
-            if (d == 0 || distance > hist0 + adv || adv + length > room0) {
+    // ---- (2) the chain of token starts ----
+    uint64_t S = 0;
+    uint32_t p = 0;
+    do {
+        S |= 1ull << p;
+        p += (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)p);
+    } while (p < 64);
+    int rc = 0;
+    uint32_t consumed = p;
+    {
+        const uint32_t top = 63u - (uint32_t)__builtin_clzll(S);
+        const uint64_t plain = __ballot(is_lit || is_match);
+        if (!((plain >> top) & 1)) {
+            if ((__ballot(is_eob) >> top) & 1) {
+                consumed = top + (uint32_t)__builtin_amdgcn_readlane((int)lcb, (int)top);
+                rc = 1;
+            } else {
+                consumed = top;
                 rc = 2;
-                break;
             }
-            const uint32_t vp = vp0 + adv;
+        }
+    }
+    // ---- (3) where every token's bytes go; the first token that does not fit or reaches too far back ends the round ----
+    const uint32_t mylen = ((S >> lane) & 1) ? olen : 0u;
+    const uint32_t incl = fl_wave_incl_scan_dpp(mylen);
+    const uint32_t off = incl - mylen;
+    uint32_t T;
+    {
+        const uint64_t fm = __ballot(mylen != 0 && (off + mylen > room0 || (is_match && dist > hist0 + off)));
+        if (fm) {
+            const uint32_t f = (uint32_t)__builtin_ctzll(fm);
+            S &= (1ull << f) - 1;
+            consumed = f;
+            rc = 2;
+            T = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)f);
+        } else {
+            T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    const bool in_s = ((S >> lane) & 1) && olen != 0;
+    // ---- (4a) the tokens that read nothing of this round, together ----
+    const uint64_t qm = __ballot(in_s && ((is_match && dist < off + olen) || off + olen > FL_INF_PAR_MAX));
+    const uint32_t q0 = qm ? (uint32_t)__builtin_ctzll(qm) : 64u;
+    const uint32_t TP = qm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)q0) : T;
 #ifdef FL_INF_COUNT
-            const uint64_t tm_ = __builtin_readcyclecounter();
+    const uint64_t tm_ = __builtin_readcyclecounter();
+#endif
+    if (TP) {
+        FL_LDS uint8_t* own = ws->lens;  // free between two block headers
+        for (uint32_t i = lane * 4; i < TP; i += 256) *(FL_LDS uint32_t*)(own + i) = 0;
+        fl_lds_order();
+        if (in_s && lane < q0) own[off] = (uint8_t)(lane + 1);
+        fl_lds_order();
+        const uint32_t tokinfo = is_lit ? ((lsym << 1) | 1u) : (dist << 1);
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < TP; b0 += 64) {
+            const uint32_t b = b0 + lane;
+            const bool live = b < TP;
+            uint32_t x = live ? (uint32_t)own[b] : 0u;
+            x = max(fl_wave_incl_max_dpp(x), carry);  // owners come in rising order: the last one at or before b
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+            const uint32_t info = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1) << 2), (int)tokinfo);
+            const uint32_t v = info >> 1;
+            const bool copy = live && !(info & 1);
+            const bool far = copy && v > near_max;
+            uint32_t byte = v;
+            if (__ballot(far && wp0 + b - v + 1 > o.fenced)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                o.fenced = o.flushed;
+            }
+            if (far) byte = o.out[wp0 + b - v];
+            if (copy && !far) byte = o.ring[(vp0 + b - v) & rmask];
+            fl_lds_order();
+            if (live) o.ring[(vp0 + b) & rmask] = (uint8_t)byte;
+            fl_lds_order();
+        }
+    }
+    uint32_t adv = TP;  // output bytes produced in this round so far
+    if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) {
+        o.wp = wp0 + adv;
+        fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
+        unfl0 = (int32_t)fl_uni((uint32_t)(o.wp - o.flushed)) - (int32_t)adv;
+    }
+#ifdef FL_INF_COUNT
+    if (blockIdx.x == 0 && lane == 0) g_fl_prof[46] += __builtin_readcyclecounter() - tm_;
+#endif
+    // ---- (4b) from the first token that reads this round's output: one match at a time, literals by their lanes ----
+    if (qm) {
+        const uint64_t rest = S & ~((1ull << q0) - 1);
+        uint64_t lq = __ballot(in_s && is_lit) & rest;
+        uint64_t mq = __ballot(in_s && is_match) & rest;
+        while (mq) {
+            const uint32_t m = (uint32_t)__builtin_ctzll(mq);
+            mq &= mq - 1;
+            const uint64_t lb = lq & ((1ull << m) - 1);
+            if (lb) {
+                if ((lb >> lane) & 1) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
+                lq &= ~lb;
+                fl_lds_order();
+            }
+            const uint32_t length_m = (uint32_t)__builtin_amdgcn_readlane((int)olen, (int)m);
+            const uint32_t distance = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)m);
+            const uint32_t moff = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)m);
+            const uint32_t vp = vp0 + moff;
+#ifdef FL_INF_COUNT
+            if (blockIdx.x == 0 && lane == 0) g_fl_prof[47]++;
 #endif
             if (distance <= near_max) {
-                fl_inf_pend_commit(o, lane);
                 // A match that overlaps itself repeats its first `distance` bytes: every pass
                 // copies as much as is already there (no per-lane modulo), so the period doubles.
                 uint32_t have = distance, done = 0;
                 do {
-                    const uint32_t chunk = min(have, length - done);
+                    const uint32_t chunk = min(have, length_m - done);
                     const uint32_t src0 = vp + done - have, dst0 = vp + done;
                     for (uint32_t i0 = 0; i0 < chunk; i0 += 64) {
                         const uint32_t i = i0 + lane;
@@ -763,63 +841,38 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
                     }
                     done += chunk;
                     have += chunk;
-                } while (done < length);
+                } while (done < length_m);
             } else {
-                const uint64_t wp = wp0 + adv;
-                if (wp - distance + length > fl_uni64(o.fenced)) {
+                const uint64_t wp = wp0 + moff;
+                if (wp - distance + length_m > fl_uni64(o.fenced)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     o.fenced = o.flushed;
                 }
                 const uint8_t* from = o.out + wp - distance;
-                if (length <= 64u) {
-                    // the bytes are requested now and go to the ring later (fl_inf_out): the one before goes first
-                    const uint32_t v = lane < length ? (uint32_t)from[lane] : 0u;
-                    fl_inf_pend_commit(o, lane);
-                    o.pend_val = v;
-                    o.pend_vp = vp;
-                    o.pend_len = length;
-                } else {
-                    fl_inf_pend_commit(o, lane);
-                    for (uint32_t i0 = 0; i0 < length; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        if (i < length) o.ring[(vp + i) & rmask] = from[i];
-                    }
-                    fl_lds_order();
+                for (uint32_t i0 = 0; i0 < length_m; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < length_m) o.ring[(vp + i) & rmask] = from[i];
                 }
+                fl_lds_order();
             }
-            adv += length;
-            p = p2 + (d & 0xff);
-#ifdef FL_INF_COUNT
-            if (blockIdx.x == 0 && lane == 0) {
-                g_fl_prof[46] += __builtin_readcyclecounter() - tm_;
-                g_fl_prof[47]++;
-            }
-#endif
+            adv = moff + length_m;
             if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) {
                 o.wp = wp0 + adv;
                 fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
                 unfl0 = (int32_t)fl_uni((uint32_t)(o.wp - o.flushed)) - (int32_t)adv;
             }
-            if (room0 - adv < 64) break;  // keep the guarantee for the literals of the rest of the round
-            continue;
         }
-        if (kind == 2) {
-            p += l & 0xff;
-            rc = 1;
-        } else {
-            rc = 2;
+        if (lq) {
+            if ((lq >> lane) & 1) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
+            fl_lds_order();
         }
-        break;
     }
-    FL_INF_PUT_LITS();
-#undef FL_INF_PUT_LITS
-    fl_lds_order();
 #ifdef FL_INF_COUNT
     if (blockIdx.x == 0 && lane == 0) g_fl_prof[45] += __builtin_readcyclecounter() - t1_;
 #endif
-    o.wp = wp0 + adv;
-    if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
-    r.left -= p;
+    o.wp = wp0 + T;
+    if (unfl0 + (int32_t)T >= (int32_t)FL_INF_PILE) fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
+    r.left -= consumed;
     return rc;
 }
 
