@@ -52,7 +52,69 @@ struct fl_inflate_ws {
     uint16_t cl_lut[128];  // code-length code: symbol | code bits << 8 | 0x8000 by the next 7 stream bits, 0 = no code
 };
 
+// k_inflate's own, smaller workspace: what a stream keeps in LDS decides how many streams a CU decodes at once, and
+// the kernel's time is inversely proportional to that number (16 -> 12 streams per CU: 20.1 -> 26.8 ms, r04).  Table
+// entries of 16 bits -- the base values follow from symbol and extra-bit count in a few VALU instructions -- and
+// the structures that only the block header needs lie where the literal table is built afterwards.
+//   lit_lut: symbol | code_bits << 9 | extra_bits << 13 (7 = not a valid length code), 0 = not in the table
+//   dst_lut: symbol | code_bits << 5 | extra_bits << 9 (15 = not a valid distance code), 0 = not in the table
+struct fl_inflate_ws16 {
+    fl_hdec lit;
+    fl_hdec_small dst;
+    union {
+        uint16_t lit_lut[1u << FL_INF_LIT_BITS];
+        struct {  // dead once the two decoders are generated, before the tables are filled
+            fl_hdec_small cl;
+            uint8_t cl_lens[20];
+            uint16_t offs[18];
+            uint16_t cl_lut[128];
+        };
+    };
+    uint16_t dst_lut[1u << FL_INF_DST_BITS];
+    uint8_t lens[320];
+};
+// table entry of a symbol with a code of cb bits, by table type
+template <bool DIST>
+__device__ __forceinline__ uint32_t fl_lut_entry(uint32_t sym, uint32_t cb, uint32_t /*tag*/) {
+    uint32_t eb, val;
+    if (DIST) {
+        eb = sym <= 29 ? fl_dist_extra_bits(sym) : 15u;
+        val = sym <= 29 ? fl_dist_base_scaled(sym) + 1 : 0u;
+    } else if (sym < 256) {
+        eb = 0;
+        val = sym;
+    } else if (sym == 256) {
+        eb = 0;
+        val = 0;
+    } else {
+        eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
+        val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
+    }
+    return sym | (cb << 9) | (eb << 13) | (val << 17);
+}
+template <bool DIST>
+__device__ __forceinline__ uint16_t fl_lut_entry(uint32_t sym, uint32_t cb, uint16_t /*tag*/) {
+    if (DIST) return (uint16_t)(sym | (cb << 5) | ((sym <= 29 ? fl_dist_extra_bits(sym) : 15u) << 9));
+    const uint32_t eb = sym <= 256 ? 0u : sym <= 285 ? fl_len_extra_bits(sym - 257) : 7u;
+    return (uint16_t)(sym | (cb << 9) | (eb << 13));
+}
+// symbol and code bits of a distance table entry (the slow path wants nothing else)
+__device__ __forceinline__ void fl_dst_sym_cb(uint32_t e, uint32_t& sym, uint32_t& cb) {
+    sym = e & 0x1ff;
+    cb = (e >> 9) & 15;
+}
+__device__ __forceinline__ void fl_dst_sym_cb(uint16_t e, uint32_t& sym, uint32_t& cb) {
+    sym = e & 31u;
+    cb = (e >> 5) & 15;
+}
+
 #define FL_INF_INRING 1024u  // compressed bytes staged in LDS (two 512-byte halves)
+
+// wave-uniform values the compiler cannot prove uniform (anything derived from an LDS load)
+__device__ __forceinline__ uint32_t fl_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t fl_uni64(uint64_t v) {
+    return (uint64_t)fl_uni((uint32_t)v) | ((uint64_t)fl_uni((uint32_t)(v >> 32)) << 32);
+}
 
 // Bit reader (bit_reader.zig:18-219) in position-free form: `left` = bits of the stream not yet
 // consumed.  fill(nice) fails only when no bit at all is left (bit_reader.zig:59-67), shift(n)
@@ -116,7 +178,9 @@ __device__ __forceinline__ void fl_br_refill(fl_bitr& r) {
         if (r.next_byte + 8 > r.in_loaded) fl_br_commit_half(r);
         const uint32_t i = (r.next_byte & (FL_INF_INRING - 1)) >> 2;
         const uint32_t lo = r.inring[i], hi = r.inring[(i + 1) & (FL_INF_INRING / 4 - 1)];
-        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, r.next_byte & 3);
+        // everything the reader's state is computed from is pinned to scalar registers: what comes out of LDS is
+        // divergent as far as the compiler knows, and the stream position would live in vector registers with it
+        const uint32_t w = fl_uni(__builtin_amdgcn_alignbyte(hi, lo, r.next_byte & 3));
         r.buf |= (uint64_t)w << r.have;
         r.have += 32;
         r.next_byte += 4;
@@ -248,13 +312,11 @@ __device__ __forceinline__ int fl_hdec_find(const FL_LDS H* d, uint32_t peek, in
 // Fill a 2^bits-entry table: entry[i] = the symbol whose code is a prefix of i (stream bit
 // order) when that code has at most `bits` bits, else 0.  Every lane decodes its share of the
 // indices with the same walk as fl_hdec_find, so table and walk cannot disagree.
-template <bool DIST, class H>
-__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS uint32_t* lut, int bits,
-                                                  uint32_t lane) {
+template <bool DIST, class H, class E>
+__device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS E* lut, int bits, uint32_t lane) {
     // Every symbol with a code of at most `bits` bits writes the entries whose low bits are its code (first bit of the
     // code = lowest bit of the index): a lane per symbol in (length, symbol) order, which is the order of the codes
     // (huffman_decoder.zig:62-117).  What no code covers stays 0 (a longer code, or none: InvalidCode).
-    for (uint32_t i = lane; i < (1u << bits); i += 64) lut[i] = 0;
     uint32_t cnt[16];
     uint32_t upto = 0;  // symbols with a code of at most `bits` bits
 #pragma unroll
@@ -262,6 +324,8 @@ __device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS uint
         cnt[len] = d->count[len];
         if (len <= bits) upto += cnt[len];
     }
+    fl_wave_lds_sync();  // (the 16-bit literal table lies over structures of the block header: counts first)
+    for (uint32_t i = lane; i < (1u << bits); i += 64) lut[i] = 0;
     fl_wave_lds_sync();
     for (uint32_t j = lane; j < upto; j += 64) {
         uint32_t code = 0, idx = 0, my_len = 0, my_code = 0;
@@ -274,22 +338,7 @@ __device__ __forceinline__ void fl_hdec_build_lut(const FL_LDS H* d, FL_LDS uint
             code = (code + cnt[len]) << 1;
             idx += cnt[len];
         }
-        const uint32_t sym = d->symbol[j], cb = my_len;
-        uint32_t eb, val;
-        if (DIST) {
-            eb = sym <= 29 ? fl_dist_extra_bits(sym) : 15u;
-            val = sym <= 29 ? fl_dist_base_scaled(sym) + 1 : 0u;
-        } else if (sym < 256) {
-            eb = 0;
-            val = sym;
-        } else if (sym == 256) {
-            eb = 0;
-            val = 0;
-        } else {
-            eb = sym <= 285 ? fl_len_extra_bits(sym - 257) : 15u;
-            val = sym <= 285 ? fl_len_base_scaled(sym - 257) + 3 : 0u;
-        }
-        const uint32_t e = sym | (cb << 9) | (eb << 13) | (val << 17);
+        const E e = fl_lut_entry<DIST>((uint32_t)d->symbol[j], my_len, E());
         const uint32_t rev = __brev(my_code) >> (32 - my_len);
         for (uint32_t t = rev; t < (1u << bits); t += 1u << my_len) lut[t] = e;
     }
@@ -313,33 +362,12 @@ struct fl_inf_out {
     uint32_t bias;
     uint32_t rmask;     // ring size - 1
     uint32_t near_max;  // ring size - 260
-    // A far match of at most 64 bytes whose bytes are still on their way from the output buffer (fast rounds): the load
-    // is issued when the match is decoded, the ring gets the bytes (lane i: byte i) when something is about to read the
-    // ring -- a near match, a flush -- or the next far match comes.  What a symbol IS does not depend on what is copied:
-    // the decode goes on in the shadow of the load.
-    uint32_t pend_len;  // 0: none
-    uint32_t pend_vp;   // ring position of its first byte
-    uint32_t pend_val;  // (per lane)
 };
-__device__ __forceinline__ void fl_inf_pend_commit(fl_inf_out& o, uint32_t lane) {
-    if (o.pend_len) {
-        if (lane < o.pend_len) o.ring[(o.pend_vp + lane) & o.rmask] = (uint8_t)o.pend_val;
-        o.pend_len = 0;
-        fl_lds_order();
-    }
-}
-
-// wave-uniform values the compiler cannot prove uniform (anything derived from an LDS load)
-__device__ __forceinline__ uint32_t fl_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint64_t fl_uni64(uint64_t v) {
-    return (uint64_t)fl_uni((uint32_t)v) | ((uint64_t)fl_uni((uint32_t)(v >> 32)) << 32);
-}
 
 // store output bytes [flushed, upto) from the ring
 __device__ __forceinline__ void fl_inf_flush(fl_inf_out& o, uint64_t upto, uint32_t lane) {
     const uint64_t a = o.flushed;
     if (upto <= a) return;
-    fl_inf_pend_commit(o, lane);
     fl_lds_order();
     const uint64_t va = a + o.bias, vb = upto + o.bias;  // same low bits as the global addresses
     const uint64_t w0 = (va + 7) >> 3, w1 = vb >> 3;     // whole 8-byte words [w0, w1)
@@ -372,7 +400,6 @@ __device__ __forceinline__ void fl_inf_advance(fl_inf_out& o, uint32_t lane) {
 __device__ __forceinline__ int fl_inf_match(fl_inf_out& o, uint32_t length, uint32_t distance, uint32_t lane) {
     if (o.wp < distance || length < 3 || length > 258 || distance < 1 || distance > 32768) return 11;
     if (o.wp + length > o.cap) return 100;
-    fl_inf_pend_commit(o, lane);
     const uint32_t vp = (uint32_t)o.wp + o.bias;  // ring positions only need the low bits
     if (distance <= o.near_max) {
         for (uint32_t i0 = 0; i0 < length; i0 += 64) {  // one trip for lengths up to 64
@@ -412,10 +439,12 @@ __device__ __forceinline__ int fl_inf_literal(fl_inf_out& o, uint32_t byte, uint
     return 0;
 }
 
-#define FL_TRY(expr)            \
-    do {                        \
-        const int rc_ = (expr); \
-        if (rc_) return rc_;    \
+// (the status is pinned to a scalar register: a status that depends on something read from LDS is divergent as far as
+// the compiler knows, and every loop that ends on it would keep the stream position in vector registers)
+#define FL_TRY(expr)                               \
+    do {                                           \
+        const int rc_ = (int)fl_uni((uint32_t)(expr)); \
+        if (rc_) return rc_;                       \
     } while (0)
 
 // inflate.zig:123-140 (the caller has already filled)
@@ -511,7 +540,8 @@ __device__ __forceinline__ int fl_inf_fixed(fl_bitr& r, fl_inf_out& o, uint32_t 
 }
 
 // inflate.zig:188-216 + the read loops of :161-180
-__device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws* ws, uint32_t base, uint32_t lens_len, uint32_t want,
+template <class WS>
+__device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS WS* ws, uint32_t base, uint32_t lens_len, uint32_t want,
                                 uint32_t boundary, bool& crossed, uint32_t lane) {
     uint32_t pos = 0;
     FL_LDS uint8_t* lens = ws->lens + base;
@@ -519,7 +549,7 @@ __device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws
         FL_TRY(fl_br_fill(r, 7));
         uint32_t sym, cb;
         {
-            const uint32_t e = ws->cl_lut[fl_br_peek(r, 7)];
+            const uint32_t e = fl_uni(ws->cl_lut[fl_br_peek(r, 7)]);
             if (e == 0) return 7;  // InvalidCode (huffman_decoder.zig:156-175)
             sym = e & 0xff;
             cb = (e >> 8) & 15;
@@ -560,7 +590,8 @@ __device__ __forceinline__ int fl_inf_read_lens(fl_bitr& r, FL_LDS fl_inflate_ws
 #else
 #define FL_HDR_T(slot)
 #endif
-__device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_inflate_ws* ws, int flags, uint32_t lane) {
+template <class WS>
+__device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS WS* ws, int flags, uint32_t lane) {
     uint32_t v;
 #ifdef FL_PAR_PROF
     uint64_t th_ = __builtin_readcyclecounter();
@@ -602,7 +633,7 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
         fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
         return 0;
     }
-    rc = fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane);
+    rc = (int)fl_uni((uint32_t)fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane));
     if (rc) return crossed ? 14 : rc;
     fl_wave_lds_sync();
     FL_HDR_T(22);
@@ -614,9 +645,9 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS fl_infla
     fl_wave_lds_sync();
     if (lane < 30) ws->lens[288 + lane] = dl;
     fl_wave_lds_sync();
-    rc = fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane);
+    rc = (int)fl_uni((uint32_t)fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane));
     if (rc) return crossed ? 14 : rc;
-    rc = fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane);
+    rc = (int)fl_uni((uint32_t)fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane));
     if (rc) return crossed ? 14 : rc;
     FL_HDR_T(23);
     fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
@@ -677,11 +708,13 @@ __device__ __forceinline__ uint32_t fl_wave_incl_max_dpp(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+#define FL_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
+__device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_ws16* ws, fl_inf_out& o, uint32_t lane) {
     FL_T0();
-    const uint64_t pos = (uint64_t)r.nbytes * 8 - (uint64_t)r.left;
+    const uint64_t left0 = fl_uni64((uint64_t)r.left);
+    const uint64_t pos = (uint64_t)fl_uni(r.nbytes) * 8 - left0;
     const uint32_t byte0 = (uint32_t)(pos >> 3);
-    if (byte0 + 24 > r.in_loaded) fl_br_commit_half(r);
+    if (__builtin_expect(byte0 + 24 > fl_uni(r.in_loaded), 0)) fl_br_commit_half(r);
     // ---- (1) the token that starts at pos + lane ----
     const uint32_t bp = ((byte0 & (FL_INF_INRING - 1)) << 3) + ((uint32_t)pos & 7) + lane;  // bit index in the ring
     const uint32_t di = bp >> 5;
@@ -690,16 +723,20 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, bp & 31);  // stream bits [pos + lane, + 32)
     const uint32_t w1 = __builtin_amdgcn_alignbit(d2, d1, bp & 31);  // ... [+ 32, + 64)
     const uint32_t le = ws->lit_lut[w0 & ((1u << FL_INF_LIT_BITS) - 1)];
-    const uint32_t lsym = le & 511, lcb = (le >> 9) & 15, leb = (le >> 13) & 15, lval = le >> 17;
-    const bool lok = le != 0 && leb != 15;
+    const uint32_t lsym = le & 511, lcb = (le >> 9) & 15, leb = le >> 13;
+    const bool lok = le != 0 && leb != 7;
     const bool is_lit = lok && lsym < 256, is_eob = lok && lsym == 256, is_len = lok && lsym > 256;
     const uint32_t lbits = lcb + leb;  // at most 10 + 5
     const uint32_t wd = __builtin_amdgcn_alignbit(w1, w0, lbits & 31);  // the 32 bits behind the length code
     const uint32_t de = ws->dst_lut[wd & ((1u << FL_INF_DST_BITS) - 1)];
-    const uint32_t dcb = (de >> 9) & 15, deb = (de >> 13) & 15, dval = de >> 17;
+    const uint32_t dsym = de & 31, dcb = (de >> 5) & 15, deb = de >> 9;
     const bool is_match = is_len && de != 0 && deb != 15;
-    const uint32_t length = lval + ((w0 >> lcb) & ((1u << leb) - 1));
-    const uint32_t dist = dval + ((wd >> dcb) & ((1u << deb) - 1));
+    // base values (inflate.zig:123-140) from the code and its extra-bit count
+    const uint32_t lc = lsym - 257;
+    const uint32_t lbase = leb ? (((4u | (lc & 3u)) << leb) + 3u) : (lc == 28u ? 258u : lc + 3u);
+    const uint32_t dbase = deb ? (((2u | (dsym & 1u)) << deb) + 1u) : dsym + 1u;
+    const uint32_t length = lbase + ((w0 >> lcb) & ((1u << leb) - 1));
+    const uint32_t dist = dbase + ((wd >> dcb) & ((1u << deb) - 1));
     // anything that is not a plain literal or match ends the chain: it is the last member of S
     const uint32_t nb = is_lit ? lcb : is_match ? lbits + dcb + deb : 64u;
     const uint32_t olen = is_lit ? 1u : is_match ? length : 0u;
@@ -728,9 +765,9 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     uint32_t consumed = p;
     {
         const uint32_t top = 63u - (uint32_t)__builtin_clzll(S);
-        const uint64_t plain = __ballot(is_lit || is_match);
-        if (!((plain >> top) & 1)) {
-            if ((__ballot(is_eob) >> top) & 1) {
+        const uint64_t plain = FL_BALLOT(is_lit || is_match);
+        if (__builtin_expect(!((plain >> top) & 1), 0)) {
+            if ((FL_BALLOT(is_eob) >> top) & 1) {
                 consumed = top + (uint32_t)__builtin_amdgcn_readlane((int)lcb, (int)top);
                 rc = 1;
             } else {
@@ -743,39 +780,38 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     const uint32_t mylen = ((S >> lane) & 1) ? olen : 0u;
     const uint32_t incl = fl_wave_incl_scan_dpp(mylen);
     const uint32_t off = incl - mylen;
-    uint32_t T;
-    {
-        const uint64_t fm = __ballot(mylen != 0 && (off + mylen > room0 || (is_match && dist > hist0 + off)));
+    uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (__builtin_expect(room0 < 64u * 258u || hist0 < 32768u, 0)) {  // (else everything fits and every distance has its history)
+        const uint64_t fm = FL_BALLOT(mylen != 0 && (off + mylen > room0 || (is_match && dist > hist0 + off)));
         if (fm) {
             const uint32_t f = (uint32_t)__builtin_ctzll(fm);
             S &= (1ull << f) - 1;
             consumed = f;
             rc = 2;
             T = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)f);
-        } else {
-            T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
     const bool in_s = ((S >> lane) & 1) && olen != 0;
     // ---- (4a) the tokens that read nothing of this round, together ----
-    const uint64_t qm = __ballot(in_s && ((is_match && dist < off + olen) || off + olen > FL_INF_PAR_MAX));
+    const uint64_t qm = FL_BALLOT(in_s && ((is_match && dist < off + olen) || off + olen > FL_INF_PAR_MAX));
     const uint32_t q0 = qm ? (uint32_t)__builtin_ctzll(qm) : 64u;
     const uint32_t TP = qm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)q0) : T;
 #ifdef FL_INF_COUNT
     const uint64_t tm_ = __builtin_readcyclecounter();
 #endif
     if (TP) {
-        FL_LDS uint8_t* own = ws->lens;  // free between two block headers
-        for (uint32_t i = lane * 4; i < TP; i += 256) *(FL_LDS uint32_t*)(own + i) = 0;
-        fl_lds_order();
+        FL_LDS uint8_t* own = ws->lens;  // free between two block headers, all zero between two rounds
         if (in_s && lane < q0) own[off] = (uint8_t)(lane + 1);
         fl_lds_order();
         const uint32_t tokinfo = is_lit ? ((lsym << 1) | 1u) : (dist << 1);
         uint32_t carry = 0;
+        uint64_t fenced0 = fl_uni64(o.fenced);
+        const uint8_t* far_base = o.out + ((int64_t)wp0 - 32768);  // (pointer arithmetic: stays a global address)
         for (uint32_t b0 = 0; b0 < TP; b0 += 64) {
             const uint32_t b = b0 + lane;
             const bool live = b < TP;
             uint32_t x = live ? (uint32_t)own[b] : 0u;
+            if (live) own[b] = 0;
             x = max(fl_wave_incl_max_dpp(x), carry);  // owners come in rising order: the last one at or before b
             carry = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
             const uint32_t info = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1) << 2), (int)tokinfo);
@@ -783,11 +819,16 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             const bool copy = live && !(info & 1);
             const bool far = copy && v > near_max;
             uint32_t byte = v;
-            if (__ballot(far && wp0 + b - v + 1 > o.fenced)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                o.fenced = o.flushed;
+            if (FL_BALLOT(far)) {
+                // every far source of this pass ends at or before wp0 + b0 + 63 - near_max
+                if (__builtin_expect(wp0 + b0 + 64 > fenced0 + near_max, 0)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    o.fenced = o.flushed;
+                    fenced0 = fl_uni64(o.fenced);
+                }
+                // a far match reaches back 32768 at most: uniform base, unsigned 32-bit lane offset
+                if (far) byte = far_base[b + 32768u - v];
             }
-            if (far) byte = o.out[wp0 + b - v];
             if (copy && !far) byte = o.ring[(vp0 + b - v) & rmask];
             fl_lds_order();
             if (live) o.ring[(vp0 + b) & rmask] = (uint8_t)byte;
@@ -795,7 +836,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
         }
     }
     uint32_t adv = TP;  // output bytes produced in this round so far
-    if (unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE) {
+    if (__builtin_expect(unfl0 + (int32_t)adv >= (int32_t)FL_INF_PILE, 0)) {
         o.wp = wp0 + adv;
         fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
         unfl0 = (int32_t)fl_uni((uint32_t)(o.wp - o.flushed)) - (int32_t)adv;
@@ -804,10 +845,10 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     if (blockIdx.x == 0 && lane == 0) g_fl_prof[46] += __builtin_readcyclecounter() - tm_;
 #endif
     // ---- (4b) from the first token that reads this round's output: one match at a time, literals by their lanes ----
-    if (qm) {
+    if (__builtin_expect(qm != 0, 0)) {
         const uint64_t rest = S & ~((1ull << q0) - 1);
-        uint64_t lq = __ballot(in_s && is_lit) & rest;
-        uint64_t mq = __ballot(in_s && is_match) & rest;
+        uint64_t lq = FL_BALLOT(in_s && is_lit) & rest;
+        uint64_t mq = FL_BALLOT(in_s && is_match) & rest;
         while (mq) {
             const uint32_t m = (uint32_t)__builtin_ctzll(mq);
             mq &= mq - 1;
@@ -871,8 +912,8 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     if (blockIdx.x == 0 && lane == 0) g_fl_prof[45] += __builtin_readcyclecounter() - t1_;
 #endif
     o.wp = wp0 + T;
-    if (unfl0 + (int32_t)T >= (int32_t)FL_INF_PILE) fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
-    r.left -= consumed;
+    if (__builtin_expect(unfl0 + (int32_t)T >= (int32_t)FL_INF_PILE, 0)) fl_inf_flush(o, ((o.wp + bias) & ~(uint64_t)511) - bias, lane);
+    r.left = (int64_t)(left0 - consumed);
     return rc;
 }
 
@@ -881,17 +922,19 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
 // keeps the reference's order of errors: a miss in the table of the decoder is InvalidCode
 // before the bits are consumed (huffman_decoder.zig:156-175), running out of input is
 // EndOfStream at the shift (bit_reader.zig:159-163).  Returns -1 at the end of the block.
-__device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+__device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_inflate_ws16* ws, fl_inf_out& o, uint32_t lane) {
     FL_TRY(fl_br_fill(r, 15));
     uint32_t sym, cb;
     {
         const uint32_t pk = fl_br_peek(r, 15);
-        const uint32_t e = ws->lit_lut[pk & ((1u << FL_INF_LIT_BITS) - 1)];
+        const uint32_t e = fl_uni(ws->lit_lut[pk & ((1u << FL_INF_LIT_BITS) - 1)]);
         if (e) {
             sym = e & 0x1ff;
             cb = (e >> 9) & 15;
         } else {
             FL_TRY(fl_hdec_find(&ws->lit, pk, 15, sym, cb));
+            sym = fl_uni(sym);
+            cb = fl_uni(cb);
         }
     }
     FL_TRY(fl_br_shift(r, cb));
@@ -905,12 +948,13 @@ __device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_infla
         FL_TRY(fl_inf_length(r, sym - 257, length));
         {
             const uint32_t pk = fl_br_peek(r, 15);
-            const uint32_t e = ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)];
+            const uint16_t e = (uint16_t)fl_uni(ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)]);
             if (e) {
-                dsym = e & 0x1ff;
-                cb = (e >> 9) & 15;
+                fl_dst_sym_cb(e, dsym, cb);
             } else {
                 FL_TRY(fl_hdec_find(&ws->dst, pk, 15, dsym, cb));
+                dsym = fl_uni(dsym);
+                cb = fl_uni(cb);
             }
         }
         FL_TRY(fl_br_shift(r, cb));
@@ -920,7 +964,7 @@ __device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_infla
     return 0;
 }
 
-__device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws* ws, fl_inf_out& o, uint32_t lane) {
+__device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws16* ws, fl_inf_out& o, uint32_t lane) {
     for (;;) {
         if (r.left >= FL_INF_FAST_MIN_BITS) {
             int rc;
@@ -929,12 +973,12 @@ __device__ __forceinline__ int fl_inf_dynamic(fl_bitr& r, FL_LDS fl_inflate_ws* 
 #ifdef FL_INF_COUNT
                 if (blockIdx.x == 0 && lane == 0) { g_fl_prof[40]++; if (rc == 2) g_fl_prof[41]++; }
 #endif
-            } while (rc == 0 && r.left >= FL_INF_FAST_MIN_BITS);
+            } while (__builtin_expect(rc == 0 && r.left >= FL_INF_FAST_MIN_BITS, 1));
             fl_br_resync(r);
             if (rc == 1) return 0;
             if (rc > 2) return rc;
         }
-        const int rc = fl_inf_dynamic_symbol(r, ws, o, lane);
+        const int rc = (int)fl_uni((uint32_t)fl_inf_dynamic_symbol(r, ws, o, lane));
 #ifdef FL_INF_COUNT
         if (blockIdx.x == 0 && lane == 0) g_fl_prof[42]++;
 #endif
@@ -1025,16 +1069,26 @@ __device__ __forceinline__ uint32_t fl_wave_adler32(const uint8_t* p, uint64_t n
 }
 
 // One wave per stream.
+#ifndef FL_INF_WAVES
+#define FL_INF_WAVES 5
+#endif
+#ifndef FL_INF_ATTR
+#define FL_INF_ATTR
+#endif
 template <uint32_t RING>
-__global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
+__global__ FL_INF_ATTR __launch_bounds__(64, (RING <= 4096u ? FL_INF_WAVES : 1)) void k_inflate(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks,
                                                 int container, int flags, fl_crc_consts cc,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                 int32_t* __restrict__ status, uint64_t* __restrict__ consumed,
                                                 const int32_t* redo_only /* non-null: only streams marked -1 */) {
-    __shared__ fl_inflate_ws ws_mem;
+    __shared__ fl_inflate_ws16 ws_mem;
     __shared__ alignas(8) uint8_t ring_mem[RING];
+#ifdef FL_INF_PAD  // tuning build: fewer streams per CU
+    __shared__ uint32_t pad_mem[FL_INF_PAD / 4];
+    if (out_len == nullptr) pad_mem[threadIdx.x] = 0;
+#endif
     __shared__ uint32_t inring_mem[FL_INF_INRING / 4];
-    FL_LDS fl_inflate_ws* ws = (FL_LDS fl_inflate_ws*)&ws_mem;
+    FL_LDS fl_inflate_ws16* ws = (FL_LDS fl_inflate_ws16*)&ws_mem;
     // the CRC-32 table is only needed after the last block: it takes the place of the literal table
     FL_LDS uint32_t* crc_tab = (FL_LDS uint32_t*)ws->lit_lut;
     const uint32_t c = blockIdx.x;
@@ -1058,23 +1112,22 @@ __global__ __launch_bounds__(64, (RING <= 4096u ? 4 : 1)) void k_inflate(const u
     o.wp = 0;
     o.flushed = 0;
     o.fenced = 0;
-    o.pend_len = 0;
-    o.pend_vp = 0;
-    o.pend_val = 0;
     o.bias = (uint32_t)((uintptr_t)o.out & 7);
 
-    int rc = fl_inf_header(r, container);
+    int rc = (int)fl_uni((uint32_t)fl_inf_header(r, container));
     while (rc == 0) {  // inflate.zig:251-280
         uint32_t bfinal, btype;
-        if ((rc = fl_br_read(r, 1, bfinal))) break;
-        if ((rc = fl_br_read(r, 2, btype))) break;
+        if ((rc = (int)fl_uni((uint32_t)fl_br_read(r, 1, bfinal)))) break;
+        if ((rc = (int)fl_uni((uint32_t)fl_br_read(r, 2, btype)))) break;
         if (btype == 2) {
-            if ((rc = fl_inf_dynamic_header(r, ws, flags, lane))) break;
-            rc = fl_inf_dynamic(r, ws, o, lane);
+            if ((rc = (int)fl_uni((uint32_t)fl_inf_dynamic_header(r, ws, flags, lane)))) break;
+            for (uint32_t i = lane; i < 80; i += 64) ((FL_LDS uint32_t*)ws->lens)[i] = 0;  // the fast rounds' owner array
+            fl_lds_order();
+            rc = (int)fl_uni((uint32_t)fl_inf_dynamic(r, ws, o, lane));
         } else if (btype == 0) {
-            rc = fl_inf_stored(r, o, lane);
+            rc = (int)fl_uni((uint32_t)fl_inf_stored(r, o, lane));
         } else if (btype == 1) {
-            rc = fl_inf_fixed(r, o, lane);
+            rc = (int)fl_uni((uint32_t)fl_inf_fixed(r, o, lane));
         } else {
             rc = 12;  // InvalidBlockType
         }
