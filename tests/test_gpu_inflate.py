@@ -187,6 +187,55 @@ def test_long_streams(inflate_path):
                 assert o == want and u == wused
 
 
+@pytest.mark.parametrize("ring", ["2048", "32768"])
+def test_fast_round_edges(ring, monkeypatch):
+    """(k_inflate itself, both ring sizes: the long-stream kernels are switched off.)  What the fast rounds of k_inflate decide on (kernels_inflate.h): matches at the distances where the source moves
+    from the LDS ring to the output buffer (ring - 260 = 1788), at the largest distance, matches that read the round's
+    own output (runs, short periods) next to literals and far matches, rounds of more than 260 bytes, and output slots
+    that are exactly full or 8 bytes short (the oracle's status for those).  zlib makes the streams (dynamic blocks)."""
+    monkeypatch.setenv("FLATE_HIP_INFLATE_PAR", "0")
+    monkeypatch.setenv("FLATE_HIP_INFLATE_SPANS", "0")
+    monkeypatch.setenv("FLATE_HIP_INFLATE_RING", ring)
+    eng = engine()
+    rng = np.random.default_rng(4321)
+    parts = []
+    for d in (259, 260, 261, 1787, 1788, 1789, 1790, 2047, 2048, 2049, 4095, 32767, 32768):
+        blk = rng.integers(0, 256, d, dtype=np.uint8).tobytes()
+        parts.append(blk + blk[:24 + d % 7])  # a match of 24..30 bytes at distance d
+    edges = b"".join(parts)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(3, 9)), dtype=np.uint8)) for _ in range(300)]
+    mixed = bytearray()
+    while len(mixed) < 600000:
+        k = int(rng.integers(0, 10))
+        if k == 0:
+            mixed += bytes([int(rng.integers(0, 256))]) * int(rng.integers(3, 700))        # runs: distance 1, up to 258 a token
+        elif k == 1:
+            mixed += bytes(rng.integers(0, 256, 2, dtype=np.uint8)) * int(rng.integers(2, 300))  # period 2
+        elif k == 2:
+            mixed += bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))  # literals
+        else:
+            mixed += b" ".join(words[int(i)] for i in rng.integers(0, 300, int(rng.integers(1, 12))))
+    mixed = bytes(mixed)
+    mixed = mixed[:len(mixed) & ~7]
+    edges = edges[:len(edges) & ~7]
+    streams, datas, caps = [], [], []
+    for data in (edges, mixed, mixed[:65528], edges[:32768] + mixed[:32768]):
+        for level in (1, 6, 9):
+            co = pyzlib.compressobj(level, pyzlib.DEFLATED, -15, 9)
+            comp = co.compress(data) + co.flush()
+            for cap in (len(data) + 8, len(data), len(data) - 8):
+                streams.append(comp)
+                datas.append(data)
+                caps.append(cap)
+    outs, st, used = eng.decompress_many(streams, 0, caps=caps)
+    for comp, data, cap, o, s_, u in zip(streams, datas, caps, outs, st, used):
+        name, want, wused = O.decompress(comp, 0, 0, cap=cap)
+        assert O.STATUS[s_] == name, (len(data), cap, O.STATUS[s_], name)
+        assert (name == "Ok") == (cap >= len(data))
+        if name == "Ok":
+            assert o == data and o == want and u == wused == len(comp)
+
+
 def _mutants(seed, n_per_base=120):
     """Differential fuzzing in the spirit of the reference's bin/fuzz_puff.zig: valid streams of
     every block type, then truncated, bit-flipped, byte-smashed and spliced."""
