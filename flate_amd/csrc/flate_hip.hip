@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <deque>
 #include <vector>
 #include <thread>
 #include <functional>
@@ -1230,23 +1231,63 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     const size_t pass_limit = (pin_in || pin_out) ? std::min(pass_chunk_limit(), host_pass_chunk_limit()) : pass_chunk_limit();
     const uint64_t stream_pass_bytes = stream_pass_byte_limit();
     if (pin_out) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
+    // Pinned output: the link is shared by both directions (57 GB/s one way, 28.6 each way at once: tools/pcie_probe.py),
+    // so what must not cross it is the unused part of the slots.  A copy kernel on the output stream writes the
+    // produced bytes of every slot straight into the caller's (device-visible) pinned memory: 52 GB/s for the bytes
+    // that matter (tools/zero_copy_probe.py) instead of 57 GB/s for 2.5 x as many.  Bytes of a slot beyond out_len[i]
+    // are then not touched at all.
+    uint8_t* zc_out = nullptr;  // device view of out + out_lo
+    std::vector<uint64_t> zc_slot;
+    if (pin_out && out_hi > out_lo) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, out + out_lo, 0) == hipSuccess && dp) {
+            zc_out = (uint8_t*)dp;
+            zc_slot.resize((size_t)n_chunks + 1);
+            for (uint32_t i = 0; i <= n_chunks; i++) zc_slot[i] = hout[i] - out_lo;
+            if ((rc = ensure(h, h->st_slot, sizeof(uint64_t) * ((size_t)n_chunks + 1)))) return rc;
+            HIP_OK(h, hipMemcpyAsync(h->st_slot.p, zc_slot.data(), sizeof(uint64_t) * ((size_t)n_chunks + 1), hipMemcpyHostToDevice, st));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    // Pinned path: the tables of a pass (chunk table, block -> chunk) are copies from pageable vectors, which the runtime
+    // stages and moves with a blit kernel -- 0.3-0.4 ms each time, on the compute stream between two passes (rocprofv3
+    // timeline, tools/e2e_timeline.py).  They go on the input stream instead, into a slice of their own per pass, ahead of
+    // the pass's input; the compute stream waits for one event per pass.
+    const bool pinned_passes = (pin_in || pin_out) && !pl;
+    uint64_t blk_total = 0, blk_base = 0;
+    if (pinned_passes) {
+        if (!h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) return FLATE_HIP_E_ALLOC;
+        for (uint32_t i = 0; i < n_chunks; i++)
+            blk_total += mode >= 4 ? 2u : (uint64_t)(chunks[i].in_len / FL_BLOCK_BYTES + 1);
+        if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * (size_t)n_chunks))) return rc;
+        if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * (size_t)std::max<uint64_t>(blk_total, 1)))) return rc;
+        HIP_OK(h, hipStreamSynchronize(h->s_in));  // (nothing of an earlier call may still write the tables)
+    }
     uint32_t nc = 0;
     size_t pass_count = 0;
+    std::deque<std::vector<uint32_t>> keep_blk;
+    std::deque<std::vector<fl_sblock>> keep_sb;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
         const bool stream = mode >= 4 && (fs || chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK);
         uint64_t pass_bytes = 0;
+        // (a sub-batch of the pinned path costs about 0.9 ms whatever it holds: a tail of less than half a sub-batch
+        // goes with the one before it)
+        size_t limit = pass_limit;
+        if (pinned_passes && (size_t)(n_chunks - c0) < pass_limit + pass_limit / 2) limit = std::min(pass_chunk_limit(), (size_t)(n_chunks - c0));
         for (nc = 0; c0 + nc < n_chunks; nc++) {
             const fl_chunk& c = chunks[c0 + nc];
             if ((mode >= 4 && (fs || c.in_len > FLATE_HIP_MAX_LZ_CHUNK)) != stream) break;
-            if (stream ? (nc > 0 && pass_bytes + c.in_len > stream_pass_bytes) : nc >= pass_limit) break;
+            if (stream ? (nc > 0 && pass_bytes + c.in_len > stream_pass_bytes) : nc >= limit) break;
             pass_bytes += c.in_len;
         }
         if (pl && stream) return FLATE_HIP_E_UNSUPPORTED;  // (whole-stream passes build more tables per call)
         const size_t pass_index = pass_count++;
         hipEvent_t ev_in = nullptr;
-        if (pin_in) {  // this sub-batch's input: in flight while the previous sub-batch is computed
+        const bool sliced = pinned_passes && !stream;  // this pass's tables: a slice of their own, filled on the input stream
+        if (pin_in && !sliced) {  // this sub-batch's input: in flight while the previous sub-batch is computed
             const uint64_t a = hin[c0], b = hin[c0 + nc];
-            if ((rc = xfer_event(h, 2 * pass_index, &ev_in))) return rc;
+            if ((rc = xfer_event(h, 3 * pass_index, &ev_in))) return rc;
             if (b > a)
                 HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
             HIP_OK(h, hipEventRecord(ev_in, h->s_in));
@@ -1266,9 +1307,12 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 return rc;
             continue;
         }
-        // block table of this pass
-        std::vector<uint32_t> blk_chunk;
-        std::vector<fl_sblock> sblocks;  // huffman-only / store-only with flush points
+        // block table of this pass (kept until the end of the call: on the pinned path the passes are enqueued without a
+        // host wait in between -- 0.27 ms per pass, tools/e2e_probe.py -- and the copies below read these vectors)
+        keep_blk.emplace_back();
+        keep_sb.emplace_back();
+        std::vector<uint32_t>& blk_chunk = keep_blk.back();
+        std::vector<fl_sblock>& sblocks = keep_sb.back();  // huffman-only / store-only with flush points
         StreamTables tabs;
         uint32_t nb = 0;
         for (uint32_t i = 0; i < nc; i++) {
@@ -1303,13 +1347,29 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         prm.n_chunks = nc;
         prm.n_blocks = nb;
         prm.stream = stream ? 1u : 0u;
-        if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * nc))) return rc;
-        if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * nb))) return rc;
+        if (!sliced) {
+            if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * nc))) return rc;
+            if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * nb))) return rc;
+        }
         if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)nb))) return rc;
         if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320 * (size_t)nb))) return rc;
         if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
-        HIP_OK(h, hipMemcpyAsync(h->chunks.p, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, st));
-        HIP_OK(h, hipMemcpyAsync(h->blk_chunk.p, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));
+        fl_chunk* tab_chunks = (fl_chunk*)h->chunks.p + (sliced ? c0 : 0u);
+        uint32_t* tab_blk = (uint32_t*)h->blk_chunk.p + (sliced ? blk_base : 0u);
+        if (sliced) {
+            if (blk_base + nb > blk_total) return FLATE_HIP_E_LAUNCH;
+            blk_base += nb;
+            HIP_OK(h, hipMemcpyAsync(tab_chunks, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, h->s_in));
+            HIP_OK(h, hipMemcpyAsync(tab_blk, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, h->s_in));
+            const uint64_t a = hin[c0], b = hin[c0 + nc];
+            if (pin_in && b > a)
+                HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
+            if ((rc = xfer_event(h, 3 * pass_index, &ev_in))) return rc;
+            HIP_OK(h, hipEventRecord(ev_in, h->s_in));
+        } else {
+            HIP_OK(h, hipMemcpyAsync(tab_chunks, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, st));
+            HIP_OK(h, hipMemcpyAsync(tab_blk, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));
+        }
         const fl_sblock* dsb = nullptr;
         if (!sblocks.empty()) {
             if ((rc = ensure(h, h->sblocks, sizeof(fl_sblock) * sblocks.size()))) return rc;
@@ -1317,7 +1377,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             dsb = (const fl_sblock*)h->sblocks.p;
         }
         // the host vectors must outlive the async copies
-        HIP_OK(h, hipStreamSynchronize(st));
+        if (!(pin_in || pin_out) || stream || planning) HIP_OK(h, hipStreamSynchronize(st));
         if (ev_in) HIP_OK(h, hipStreamWaitEvent(st, ev_in, 0));
         if (planning) {
             // keep this pass's tables in the plan; size the workspace now so that planned calls never allocate
@@ -1337,8 +1397,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             continue;
         }
 
-        const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
-        const uint32_t* dbc = (const uint32_t*)h->blk_chunk.p;
+        const fl_chunk* dch = tab_chunks;
+        const uint32_t* dbc = tab_blk;
         if (stream) {
             if (container != 0) {
                 ProfScope ps(h, K_CHECKSUM);
@@ -1358,12 +1418,21 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         HIP_OK(h, hipGetLastError());
         if (pin_out) {  // this sub-batch's output slots go home while the next sub-batch is computed
             hipEvent_t ev_out;
-            if ((rc = xfer_event(h, 2 * pass_index + 1, &ev_out))) return rc;
+            if ((rc = xfer_event(h, 3 * pass_index + 1, &ev_out))) return rc;
             HIP_OK(h, hipEventRecord(ev_out, st));
             HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
             const uint64_t a = hout[c0], b = hout[c0 + nc];
-            if (b > a)
+            if (b > a && zc_out) {
+                // (a few workgroups that take the slots in turn; beside the next sub-batch's kernels the copy is not free:
+                // its stores wait for the link and the stores of the other kernels wait behind them -- k_lz_chain took
+                // 0.47 ms instead of 0.09 beside it, and started behind it the tokenizer pays the same 0.4 ms)
+                hipLaunchKernelGGL(k_copy_slots, dim3(std::min(64u, nc)), dim3(256), 0, h->s_out, d_out,
+                                   (const uint64_t*)h->st_slot.p + c0, (const uint64_t*)d_outlen + c0, zc_out,
+                                   (const uint64_t*)h->st_slot.p + c0, nc);
+                HIP_OK(h, hipGetLastError());
+            } else if (b > a) {
                 HIP_OK(h, hipMemcpyAsync(out + a, d_out + (a - out_shift), b - a, hipMemcpyDeviceToHost, h->s_out));
+            }
         }
     }
 

@@ -817,18 +817,17 @@ __global__ __launch_bounds__(1024) void k_scan_lens(const uint64_t* __restrict__
 // stores from unaligned source dwords, the (at most 15 + 15) edge bytes of the stream one by one --
 // neighbouring streams never share a byte.
 #define FL_GATHER_SLICE 16384u
-__global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__ out,
-                                                     const uint64_t* __restrict__ out_off,
-                                                     const uint64_t* __restrict__ out_len,
-                                                     uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off) {
-    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void fl_gather_one(const uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
+                                              const uint64_t* __restrict__ out_len, uint8_t* __restrict__ dst,
+                                              const uint64_t* __restrict__ dst_off, uint32_t c, uint32_t by, uint32_t ny) {
+    const uint32_t tid = threadIdx.x;
     const uint64_t n = out_len[c];
     const uint8_t* s = out + out_off[c];
     uint8_t* d = dst + dst_off[c];
     const uint64_t head = min(n, (uint64_t)((16 - ((uintptr_t)d & 15)) & 15));
     const uint64_t nq = (n - head) >> 4;  // 16-byte units
     const uint64_t tail0 = head + 16 * nq;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
         if (tid < head) d[tid] = s[tid];
         if (tid < 16 && tail0 + tid < n) d[tail0 + tid] = s[tail0 + tid];
     }
@@ -837,7 +836,7 @@ __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__
     const uint32_t sh = (uint32_t)((uintptr_t)s0 & 3);
     const uint32_t* sa = (const uint32_t*)(s0 - sh);  // aligned dwords: unit i = dwords 4 i .. 4 i + 4 shifted by sh bytes
     const uint64_t per = FL_GATHER_SLICE / 16;
-    for (uint64_t u0 = (uint64_t)blockIdx.y * per; u0 < nq; u0 += (uint64_t)gridDim.y * per) {
+    for (uint64_t u0 = (uint64_t)by * per; u0 < nq; u0 += (uint64_t)ny * per) {
         const uint64_t u1 = min(u0 + per, nq);
         for (uint64_t i = u0 + tid; i < u1; i += 256) {
             const uint32_t* w = sa + 4 * i;
@@ -855,4 +854,18 @@ __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__
             d16[i] = v;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__ out,
+                                                     const uint64_t* __restrict__ out_off,
+                                                     const uint64_t* __restrict__ out_len,
+                                                     uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off) {
+    fl_gather_one(out, out_off, out_len, dst, dst_off, blockIdx.x, blockIdx.y, gridDim.y);
+}
+// The same copy by a FEW workgroups that take the streams in turn: the destination is pinned host memory, and a grid that
+// floods the write path with stores that wait for the link stalls every other kernel's stores behind them (the next
+// sub-batch's kernels did not start before the copy had ended: rocprofv3 timeline, tools/e2e_timeline.py).
+__global__ __launch_bounds__(256) void k_copy_slots(const uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
+                                                    const uint64_t* __restrict__ out_len, uint8_t* __restrict__ dst,
+                                                    const uint64_t* __restrict__ dst_off, uint32_t n) {
+    for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) fl_gather_one(out, out_off, out_len, dst, dst_off, c, 0, 1);
 }
