@@ -645,6 +645,135 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                         // needs) or its walk ends.
                         uint32_t nqB, w0B, w1B, a1, a2, xn, t, nqh = 0;
                         uint64_t s_save, s_t, s_hit;
+#if defined(PZ_UNAL)  // (measured: the LDS of gfx950 serves unaligned dwords, bit-exact, but 25.9 ms against 23.2)
+                        // experiment: ONE unaligned ds_read_b32 at the byte address (does the LDS of gfx950 serve it?)
+                        asm volatile(
+                            "s_mov_b64 %[ssave], exec\n\t"
+                            "s_mov_b64 %[shit], 0\n\t"
+                            "v_alignbyte_b32 v120, %[w1A], %[w0A], %[xq]\n\t"
+                            ".rept " PZ_STR(PZ_HALF_UNROLL) "\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqA], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqB], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqA], %[offb]\n\t"
+                            "ds_read_b32 v122, %[xn]\n\t"
+                            "v_mov_b32 %[t], v120\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqA], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqA], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqA]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqB], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqA], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqB], %[offb]\n\t"
+                            "ds_read_b32 v120, %[xn]\n\t"
+                            "v_mov_b32 %[t], v122\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqB], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqB], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqB]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            ".endr\n\t"
+                            ".Lpz_done_%=:\n\t"
+                            "s_mov_b64 %[st], exec\n\t"
+                            "s_mov_b64 exec, %[ssave]\n\t"
+                            "v_and_b32 %[a2], -4, %[xq]\n\t"
+                            "ds_read2_b32 v[120:121], %[a2] offset1:1\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_mov_b32 %[w0A], v120\n\t"
+                            "v_mov_b32 %[w1A], v121\n\t"
+                            : [q] "+v"(q), [cnt] "+v"(cnt), [nqA] "+v"(nqA), [w0A] "+v"(w0A), [w1A] "+v"(w1A), [xq] "+v"(xq),
+                              [qh] "+v"(qh), [nqh] "+v"(nqh), [nqB] "=&v"(nqB),
+                              [a1] "=&v"(a1), [a2] "=&v"(a2), [xn] "=&v"(xn), [t] "=&v"(t), [ssave] "=&s"(s_save),
+                              [st] "=&s"(s_t), [shit] "=&s"(s_hit)
+                            : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
+                            : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
+                        (void)w0B;
+                        (void)w1B;
+#elif !defined(PZ_NO_READ2)  // the two window dwords of a candidate in ONE LDS instruction: 23.19 -> 22.88 ms
+                        // (ds_read2_b32 needs a register PAIR, which an asm operand cannot name half by half: v120..v123 are taken by hand)
+                        asm volatile(
+                            "s_mov_b64 %[ssave], exec\n\t"
+                            "s_mov_b64 %[shit], 0\n\t"
+                            "v_mov_b32 v120, %[w0A]\n\t"
+                            "v_mov_b32 v121, %[w1A]\n\t"
+                            ".rept " PZ_STR(PZ_HALF_UNROLL) "\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqA], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqB], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqA], %[offb]\n\t"
+                            "v_and_b32 %[a2], -4, %[xn]\n\t"
+                            "ds_read2_b32 v[122:123], %[a2] offset1:1\n\t"
+                            "v_alignbyte_b32 %[t], v121, v120, %[xq]\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqA], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqA], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqA]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            "v_lshl_add_u32 %[a1], %[nqB], 1, %[prvb]\n\t"
+                            "ds_read_u16 %[nqA], %[a1]\n\t"
+                            "v_add_u32 %[xn], %[nqB], %[offb]\n\t"
+                            "v_and_b32 %[a2], -4, %[xn]\n\t"
+                            "ds_read2_b32 v[120:121], %[a2] offset1:1\n\t"
+                            "v_alignbyte_b32 %[t], v123, v122, %[xq]\n\t"
+                            "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"
+                            "v_cndmask_b32 %[qh], %[qh], %[q], vcc\n\t"
+                            "v_cndmask_b32 %[nqh], %[nqh], %[nqB], vcc\n\t"
+                            "s_and_b64 %[st], exec, vcc\n\t"
+                            "s_or_b64 %[shit], %[shit], %[st]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmp_ge_u32 vcc, %[nqB], %[lo]\n\t"
+                            "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                            "v_cmp_lt_i32_e64 %[st], 0, %[cnt]\n\t"
+                            "s_and_b64 vcc, vcc, %[st]\n\t"
+                            "s_and_b64 exec, exec, vcc\n\t"
+                            "v_mov_b32 %[q], %[nqB]\n\t"
+                            "v_mov_b32 %[xq], %[xn]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz .Lpz_done_%=\n\t"
+                            ".endr\n\t"
+                            ".Lpz_done_%=:\n\t"
+                            "s_mov_b64 %[st], exec\n\t"
+                            "s_mov_b64 exec, %[ssave]\n\t"
+                            "v_mov_b32 %[w0A], v120\n\t"
+                            "v_mov_b32 %[w1A], v121\n\t"
+                            : [q] "+v"(q), [cnt] "+v"(cnt), [nqA] "+v"(nqA), [w0A] "+v"(w0A), [w1A] "+v"(w1A), [xq] "+v"(xq),
+                              [qh] "+v"(qh), [nqh] "+v"(nqh), [nqB] "=&v"(nqB),
+                              [a1] "=&v"(a1), [a2] "=&v"(a2), [xn] "=&v"(xn), [t] "=&v"(t), [ssave] "=&s"(s_save),
+                              [st] "=&s"(s_t), [shit] "=&s"(s_hit)
+                            : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
+                            : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
+                        (void)w0B;
+                        (void)w1B;
+#else
                         asm volatile(
                             "s_mov_b64 %[ssave], exec\n\t"
                             "s_mov_b64 %[shit], 0\n\t"
@@ -703,6 +832,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                               [st] "=&s"(s_t), [shit] "=&s"(s_hit)
                             : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
                             : "vcc", "scc", "memory");
+#endif
                         // s_t: the lanes that are still walking (their candidate's data is in the A registers again:
                         // an even number of steps); s_hit: those that stopped on a candidate that passes the filter
                         const uint32_t ln = threadIdx.x & 63u;
