@@ -709,7 +709,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
                         (void)w0B;
                         (void)w1B;
-#elif !defined(PZ_NO_READ2)  // the two window dwords of a candidate in ONE LDS instruction: 23.19 -> 22.88 ms
+#elif defined(PZ_READ2)  // experiment: the two window dwords of a candidate in ONE LDS instruction: 23.19 -> 22.9-23.1 ms (noise)
                         // (ds_read2_b32 needs a register PAIR, which an asm operand cannot name half by half: v120..v123 are taken by hand)
                         asm volatile(
                             "s_mov_b64 %[ssave], exec\n\t"
