@@ -92,7 +92,11 @@ struct flate_hip_ctx {
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
-    size_t pin_in_cap = 0, pin_out_cap = 0;
+    void* pin_len = nullptr;  // out_len of a sub-batch on its way home (mirror_out reads it before the call ends)
+    size_t pin_in_cap = 0, pin_out_cap = 0, pin_len_cap = 0;
+    // pageable callers: a sub-batch's input is copied into the mirror right before its H2D copy is enqueued, its produced
+    // bytes out of the mirror as soon as they have landed -- while the GPU works on the other sub-batches
+    std::function<void(uint32_t, uint32_t)> mirror_in, mirror_out;
     uint32_t n_cu = 0;  // of the device (spans)
     DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff,
         sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part, sp_footoff, sp_foot, sp_fin;  // inflate of long streams by spans
@@ -995,6 +999,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     (void)hipStreamSynchronize(h->stream);
     fold_profile(h);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_len) (void)hipHostFree(h->pin_len);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
                       &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff, &h->sp_pool, &h->sp_pooltab, &h->sp_poolctl, &h->sp_items,
@@ -1140,18 +1145,30 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             };
             const uint8_t* src = in + in_lo;
             uint8_t* pin = (uint8_t*)h->pin_in;
-            parallel(in_hi - in_lo, [&](uint64_t a, uint64_t b) { memcpy(pin + a, src + a, b - a); });
-            // the mirrors take the place of the caller's buffers: same offsets
+            const uint8_t* pout = (const uint8_t*)h->pin_out;
+            // the mirrors take the place of the caller's buffers: same offsets.  A sub-batch's input is copied right before
+            // its H2D copy is enqueued, its produced bytes leave the mirror as soon as they have landed.
+            h->mirror_in = [&](uint32_t c0, uint32_t nc) {
+                const uint64_t a = hin[c0] - in_lo, b = hin[c0 + nc] - in_lo;
+                parallel(b - a, [&](uint64_t x, uint64_t y) { memcpy(pin + a + x, src + a + x, y - x); });
+            };
+            bool landed = false;
+            h->mirror_out = [&](uint32_t c0, uint32_t nc) {
+                landed = true;
+                parallel(nc, [&](uint64_t x, uint64_t y) {
+                    for (uint64_t i = c0 + x; i < c0 + y; i++) {
+                        const uint64_t n = std::min<uint64_t>(out_len[i], hout[i + 1] - hout[i]);
+                        if (n) memcpy(out + hout[i], pout + (hout[i] - out_lo), n);
+                    }
+                });
+            };
             rc = compress_impl(h, pin - in_lo, in_off, n_chunks, container, mode, (uint8_t*)h->pin_out - out_lo, out_off, out_len,
                                status, memkind, nullptr, nullptr);
+            auto take_out = h->mirror_out;
+            h->mirror_in = nullptr;
+            h->mirror_out = nullptr;
             if (rc) return rc;
-            const uint8_t* pout = (const uint8_t*)h->pin_out;
-            parallel(n_chunks, [&](uint64_t a, uint64_t b) {
-                for (uint64_t i = a; i < b; i++) {
-                    const uint64_t n = std::min<uint64_t>(out_len[i], hout[i + 1] - hout[i]);
-                    if (n) memcpy(out + hout[i], pout + (hout[i] - out_lo), n);
-                }
-            });
+            if (!landed) take_out(0, n_chunks);  // (the call did not take the overlapped path)
             // (large mirrors do not stay pinned with the handle)
             if (h->pin_in_cap > (1ull << 30)) {
                 (void)hipHostFree(h->pin_in);
@@ -1268,6 +1285,20 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     size_t pass_count = 0;
     std::deque<std::vector<uint32_t>> keep_blk;
     std::deque<std::vector<fl_sblock>> keep_sb;
+    std::vector<uint32_t> pass_c0;  // first chunk of every pass (mirror_out)
+    const bool landing = pin_out && (bool)h->mirror_out;
+    if (landing && h->pin_len_cap < sizeof(uint64_t) * (size_t)n_chunks) {
+        if (h->pin_len) (void)hipHostFree(h->pin_len);
+        h->pin_len = nullptr;
+        h->pin_len_cap = 0;
+        const size_t sz = sizeof(uint64_t) * ((size_t)n_chunks + n_chunks / 4 + 64);
+        if (hipHostMalloc(&h->pin_len, sz, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pin_len = nullptr;
+            return FLATE_HIP_E_ALLOC;
+        }
+        h->pin_len_cap = sz;
+    }
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += nc) {
         const bool stream = mode >= 4 && (fs || chunks[c0].in_len > FLATE_HIP_MAX_LZ_CHUNK);
         uint64_t pass_bytes = 0;
@@ -1283,6 +1314,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         if (pl && stream) return FLATE_HIP_E_UNSUPPORTED;  // (whole-stream passes build more tables per call)
         const size_t pass_index = pass_count++;
+        if (h->mirror_in) h->mirror_in(c0, nc);
+        pass_c0.push_back(c0);
         hipEvent_t ev_in = nullptr;
         const bool sliced = pinned_passes && !stream;  // this pass's tables: a slice of their own, filled on the input stream
         if (pin_in && !sliced) {  // this sub-batch's input: in flight while the previous sub-batch is computed
@@ -1433,6 +1466,23 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             } else if (b > a) {
                 HIP_OK(h, hipMemcpyAsync(out + a, d_out + (a - out_shift), b - a, hipMemcpyDeviceToHost, h->s_out));
             }
+            if (landing) {  // this pass's lengths and an event behind its way home
+                hipEvent_t ev_done;
+                if ((rc = xfer_event(h, 3 * pass_index + 2, &ev_done))) return rc;
+                HIP_OK(h, hipMemcpyAsync((uint64_t*)h->pin_len + c0, d_outlen + c0, sizeof(uint64_t) * nc, hipMemcpyDeviceToHost, h->s_out));
+                HIP_OK(h, hipEventRecord(ev_done, h->s_out));
+            }
+        }
+    }
+    if (landing) {
+        // everything is enqueued: take the passes' output out of the mirror as they land
+        for (size_t k = 0; k < pass_c0.size(); k++) {
+            const uint32_t a = pass_c0[k], b = k + 1 < pass_c0.size() ? pass_c0[k + 1] : n_chunks;
+            hipEvent_t ev_done;
+            if ((rc = xfer_event(h, 3 * k + 2, &ev_done))) return rc;
+            HIP_OK(h, hipEventSynchronize(ev_done));
+            memcpy(out_len + a, (const uint64_t*)h->pin_len + a, sizeof(uint64_t) * (b - a));
+            h->mirror_out(a, b - a);
         }
     }
 
