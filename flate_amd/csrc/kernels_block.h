@@ -819,11 +819,14 @@ __global__ __launch_bounds__(1024) void k_scan_lens(const uint64_t* __restrict__
 #define FL_GATHER_SLICE 16384u
 __device__ __forceinline__ void fl_gather_one(const uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
                                               const uint64_t* __restrict__ out_len, uint8_t* __restrict__ dst,
-                                              const uint64_t* __restrict__ dst_off, uint32_t c, uint32_t by, uint32_t ny) {
+                                              const uint64_t* __restrict__ dst_off, uint32_t c, uint32_t by, uint32_t ny,
+                                              uint64_t skip = 0) {
     const uint32_t tid = threadIdx.x;
-    const uint64_t n = out_len[c];
-    const uint8_t* s = out + out_off[c];
-    uint8_t* d = dst + dst_off[c];
+    const uint64_t n0 = out_len[c];
+    if (n0 <= skip) return;
+    const uint64_t n = n0 - skip;
+    const uint8_t* s = out + out_off[c] + skip;
+    uint8_t* d = dst + dst_off[c] + skip;
     const uint64_t head = min(n, (uint64_t)((16 - ((uintptr_t)d & 15)) & 15));
     const uint64_t nq = (n - head) >> 4;  // 16-byte units
     const uint64_t tail0 = head + 16 * nq;
@@ -864,8 +867,9 @@ __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__
 // The same copy by a FEW workgroups that take the streams in turn: the destination is pinned host memory, and a grid that
 // floods the write path with stores that wait for the link stalls every other kernel's stores behind them (the next
 // sub-batch's kernels did not start before the copy had ended: rocprofv3 timeline, tools/e2e_timeline.py).
+// Of the first `urows` slots the DMA engine's rectangle copy has taken the first `skip` bytes: only what lies behind them.
 __global__ __launch_bounds__(256) void k_copy_slots(const uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
                                                     const uint64_t* __restrict__ out_len, uint8_t* __restrict__ dst,
-                                                    const uint64_t* __restrict__ dst_off, uint32_t n) {
-    for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) fl_gather_one(out, out_off, out_len, dst, dst_off, c, 0, 1);
+                                                    const uint64_t* __restrict__ dst_off, uint32_t n, uint32_t urows, uint64_t skip) {
+    for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) fl_gather_one(out, out_off, out_len, dst, dst_off, c, 0, 1, c < urows ? skip : 0);
 }

@@ -476,6 +476,51 @@ def test_planned_batches_only_enqueue():
     eng.close()
 
 
+def test_pinned_output_slots_of_one_size_rectangle_copy_and_the_rest():
+    """Pinned (and pageable: pinned mirrors) output with slots of one size: the first half of every slot comes home by the DMA
+    engine's rectangle copy, what a chunk produced beyond it by the copy kernel.  Chunks that compress well, chunks that do
+    not (the second half of the slot is needed), empty ones; three sub-batches; every stream against the oracle."""
+    import torch
+    from flate_amd import _capi, synth
+    eng = engine()
+    L = _capi.lib()
+    rng = np.random.default_rng(99)
+    csz, n = 16384, 2500
+    text = synth.text(synth.SEED_TEXT + 9, n * csz)
+    data = text.copy()
+    kinds = rng.integers(0, 4, n)
+    for i in range(n):
+        if kinds[i] == 1:
+            data[i * csz:(i + 1) * csz] = rng.integers(0, 256, csz, dtype=np.uint8)      # incompressible
+        elif kinds[i] == 2:
+            data[i * csz:(i + 1) * csz] = 0
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(csz)).astype(np.uint64)
+    for container, mode in ((O.RAW, 6), (O.GZIP, 1)):
+        cap = (eng.compress_bound(csz, container, mode) + 7) & ~7
+        out_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(cap)).astype(np.uint64)
+        res = []
+        for pinned in (True, False):
+            mk = (lambda k: torch.full((k,), 0xAA, dtype=torch.uint8).pin_memory()) if pinned else (lambda k: torch.full((k,), 0xAA, dtype=torch.uint8))
+            h_in = mk(len(data) + 8)
+            h_in[: len(data)] = torch.from_numpy(data)
+            h_out = mk(int(out_off[-1]) + 8)
+            out_len = np.zeros(n, dtype=np.uint64)
+            status = np.zeros(n, dtype=np.int32)
+            rc = L.flate_hip_compress_batch(eng._h, h_in.data_ptr(), off.ctypes.data, n, container, mode, h_out.data_ptr(),
+                                            out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data, _capi.MEM_HOST)
+            assert rc == 0 and not status.any()
+            o = h_out.numpy()
+            res.append([o[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n)])
+            assert int(o[int(out_off[-1]):].min()) == 0xAA  # nothing behind the last slot
+            for i in range(0, n, 131):  # beyond out_len: zeros or the caller's bytes
+                rest = o[int(out_off[i]) + int(out_len[i]): int(out_off[i + 1])]
+                assert set(np.unique(rest).tolist()) <= {0x00, 0xAA}
+        assert res[0] == res[1]
+        assert max(len(x) for x in res[0]) > cap // 2 > min(len(x) for x in res[0])
+        for i in list(range(0, n, 61)) + [n - 1]:
+            assert res[0][i] == O.compress(data[i * csz:(i + 1) * csz].tobytes(), container, mode), i
+
+
 def test_pinned_host_buffers_take_the_overlapped_path():
     """MEM_HOST with pinned buffers runs in sub-batches (H2D / kernels / D2H on three streams): every stream
     equals what the pageable call produces, chunk sizes ragged, more chunks than one sub-batch holds."""
