@@ -1650,7 +1650,15 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     if (pin_io) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
     // (a wave per stream: a sub-batch must still fill the chip -- 13 streams per CU -- or the kernel's latency per
     // stream, not the copies, decides; measured: sub-batches of 1024 streams are slower than no overlap at all)
-    const uint32_t sub = pin_io ? 4u * (uint32_t)host_pass_chunk_limit() : n_chunks;
+    // sub-batches of one size (4097 streams used to be 4096 + 1, and the launch for the one cost a stream's whole latency)
+    uint32_t sub = n_chunks;
+    if (pin_io) {
+        // (a sub-batch has to fill the chip -- 20 streams per CU -- or the latency of a stream decides: two sub-batches of
+        // 2049 streams take as long as one batch, five of 3277 are 33 GB/s against 24, tools/e2e_inflate_probe.py)
+        const uint32_t target = 3u * (uint32_t)host_pass_chunk_limit();
+        const uint32_t nsub = std::max(1u, n_chunks / target);
+        sub = (n_chunks + nsub - 1) / nsub;
+    }
     size_t pass_index = 0;
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += sub, pass_index++) {
         const uint32_t nc = std::min(sub, n_chunks - c0);

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth, _capi
 eng = Engine(0); L = _capi.lib()
-n = 1 << 30
+n = (int(sys.argv[1]) << 20) if len(sys.argv) > 1 else (1 << 30)
 data = synth.text(synth.SEED_TEXT, n)
 off = synth.split_offsets(n, 65535).astype(np.uint64); k = len(off) - 1
 chunks = [data[int(off[i]):int(off[i+1])].tobytes() for i in range(k)]
@@ -25,6 +25,8 @@ def run(pin, tag):
     assert np.array_equal(po.numpy()[:n], data)
     print(tag, round(n / dt / 1e6, 1), "MB/s")
 run(False, "pageable")
-run(True, "pinned overlapped (sub-batches of 4096)")
+for lim in (sys.argv[2:] or ["1024"]):
+    os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = lim
+    run(True, "pinned overlapped (sub-batches of about 4 x %s streams)" % lim)
 os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = "100000"
 run(True, "pinned, one batch")
