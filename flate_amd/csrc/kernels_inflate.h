@@ -709,6 +709,10 @@ __device__ __forceinline__ uint32_t fl_wave_incl_max_dpp(uint32_t v) {
     return v;
 }
 #define FL_BALLOT(c) __builtin_amdgcn_ballot_w64(c)
+// A lane predicate from a mask held in scalar registers: no vector instruction at all (the mask is the select operand /
+// the exec mask).  The round's predicates are kept as masks and combined on the scalar side: written as lane booleans
+// the compiler turned every combination into a 0/1 vector register and compared it again.
+#define FL_INV(m) __builtin_amdgcn_inverse_ballot_w64(m)
 __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_ws16* ws, fl_inf_out& o, uint32_t lane) {
     FL_T0();
     const uint64_t left0 = fl_uni64((uint64_t)r.left);
@@ -724,17 +728,23 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     const uint32_t w1 = __builtin_amdgcn_alignbit(d2, d1, bp & 31);  // ... [+ 32, + 64)
     const uint32_t le = ws->lit_lut[w0 & ((1u << FL_INF_LIT_BITS) - 1)];
     const uint32_t lsym = le & 511, lcb = (le >> 9) & 15, leb = le >> 13;
-    const bool lok = le != 0 && leb != 7;
-    const bool is_lit = lok && lsym < 256, is_eob = lok && lsym == 256, is_len = lok && lsym > 256;
+    const uint64_t m_lok = FL_BALLOT(le != 0) & FL_BALLOT(leb != 7);
+    const uint64_t m_lit = m_lok & FL_BALLOT(lsym < 256);
     const uint32_t lbits = lcb + leb;  // at most 10 + 5
     const uint32_t wd = __builtin_amdgcn_alignbit(w1, w0, lbits & 31);  // the 32 bits behind the length code
     const uint32_t de = ws->dst_lut[wd & ((1u << FL_INF_DST_BITS) - 1)];
     const uint32_t dsym = de & 31, dcb = (de >> 5) & 15, deb = de >> 9;
-    const bool is_match = is_len && de != 0 && deb != 15;
+    const uint64_t m_match = m_lok & FL_BALLOT(lsym > 256) & FL_BALLOT(de != 0) & FL_BALLOT(deb != 15);
+    const uint64_t m_plain = m_lit | m_match;
+    const bool is_lit = FL_INV(m_lit), is_match = FL_INV(m_match);
     // base values (inflate.zig:123-140) from the code and its extra-bit count
     const uint32_t lc = lsym - 257;
-    const uint32_t lbase = leb ? (((4u | (lc & 3u)) << leb) + 3u) : (lc == 28u ? 258u : lc + 3u);
-    const uint32_t dbase = deb ? (((2u | (dsym & 1u)) << deb) + 1u) : dsym + 1u;
+    // (selects, not branches: written with ?: inside ?: the compiler masked lanes in and out around three instructions)
+    uint32_t lbase = ((4u | (lc & 3u)) << leb) + 3u;
+    lbase = FL_INV(FL_BALLOT(leb != 0)) ? lbase : lc + 3u;
+    lbase = FL_INV(FL_BALLOT(lc == 28u)) ? 258u : lbase;
+    uint32_t dbase = ((2u | (dsym & 1u)) << deb) + 1u;
+    dbase = FL_INV(FL_BALLOT(deb != 0)) ? dbase : dsym + 1u;
     const uint32_t length = lbase + ((w0 >> lcb) & ((1u << leb) - 1));
     const uint32_t dist = dbase + ((wd >> dcb) & ((1u << deb) - 1));
     // anything that is not a plain literal or match ends the chain: it is the last member of S
@@ -744,8 +754,10 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     // pinned to scalar registers explicitly.
     const uint64_t wp0 = fl_uni64(o.wp);
     const uint64_t cap = fl_uni64(o.cap);
-    const uint32_t room0 = (uint32_t)(cap - wp0 < 0x40000000ull ? cap - wp0 : 0x40000000ull);  // output bytes left (saturated)
-    const uint32_t hist0 = (uint32_t)(wp0 < 0x100000ull ? wp0 : 0x100000ull);  // bytes a match may reach back (saturated)
+    // (32-bit halves: there is no 64-bit scalar compare, and the vector one costs a constant pair and the compare each time)
+    const uint64_t roomq = cap - wp0;
+    const uint32_t room0 = (uint32_t)(roomq >> 32) ? 0x40000000u : min((uint32_t)roomq, 0x40000000u);  // output bytes left (saturated)
+    const uint32_t hist0 = (uint32_t)(wp0 >> 32) ? 0x100000u : min((uint32_t)wp0, 0x100000u);  // bytes a match may reach back (saturated)
     int32_t unfl0 = (int32_t)fl_uni((uint32_t)(wp0 - o.flushed));                // unflushed bytes = unfl0 + adv
     const uint32_t bias = fl_uni(o.bias), rmask = fl_uni(o.rmask), near_max = fl_uni(o.near_max);
     const uint32_t vp0 = (uint32_t)wp0 + bias;  // ring position of output byte wp0 (low bits)
@@ -765,9 +777,8 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     uint32_t consumed = p;
     {
         const uint32_t top = 63u - (uint32_t)__builtin_clzll(S);
-        const uint64_t plain = FL_BALLOT(is_lit || is_match);
-        if (__builtin_expect(!((plain >> top) & 1), 0)) {
-            if ((FL_BALLOT(is_eob) >> top) & 1) {
+        if (__builtin_expect(!((m_plain >> top) & 1), 0)) {
+            if (((m_lok & FL_BALLOT(lsym == 256)) >> top) & 1) {
                 consumed = top + (uint32_t)__builtin_amdgcn_readlane((int)lcb, (int)top);
                 rc = 1;
             } else {
@@ -777,12 +788,12 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
         }
     }
     // ---- (3) where every token's bytes go; the first token that does not fit or reaches too far back ends the round ----
-    const uint32_t mylen = ((S >> lane) & 1) ? olen : 0u;
+    const uint32_t mylen = FL_INV(S) ? olen : 0u;
     const uint32_t incl = fl_wave_incl_scan_dpp(mylen);
     const uint32_t off = incl - mylen;
     uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (__builtin_expect(room0 < 64u * 258u || hist0 < 32768u, 0)) {  // (else everything fits and every distance has its history)
-        const uint64_t fm = FL_BALLOT(mylen != 0 && (off + mylen > room0 || (is_match && dist > hist0 + off)));
+        const uint64_t fm = S & m_plain & (FL_BALLOT(off + mylen > room0) | (m_match & FL_BALLOT(dist > hist0 + off)));
         if (fm) {
             const uint32_t f = (uint32_t)__builtin_ctzll(fm);
             S &= (1ull << f) - 1;
@@ -791,9 +802,10 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             T = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)f);
         }
     }
-    const bool in_s = ((S >> lane) & 1) && olen != 0;
+    const uint64_t m_in = S & m_plain;  // the tokens of this round that write something
     // ---- (4a) the tokens that read nothing of this round, together ----
-    const uint64_t qm = FL_BALLOT(in_s && ((is_match && dist < off + olen) || off + olen > FL_INF_PAR_MAX));
+    const uint32_t oend = off + olen;
+    const uint64_t qm = m_in & ((m_match & FL_BALLOT(dist < oend)) | FL_BALLOT(oend > FL_INF_PAR_MAX));
     const uint32_t q0 = qm ? (uint32_t)__builtin_ctzll(qm) : 64u;
     const uint32_t TP = qm ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)q0) : T;
 #ifdef FL_INF_COUNT
@@ -801,11 +813,14 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
 #endif
     if (TP) {
         FL_LDS uint8_t* own = ws->lens;  // free between two block headers, all zero between two rounds
-        if (in_s && lane < q0) own[off] = (uint8_t)(lane + 1);
+        if (FL_INV(qm ? m_in & ((1ull << q0) - 1) : m_in)) own[off] = (uint8_t)(lane + 1);
         fl_lds_order();
         const uint32_t tokinfo = is_lit ? ((lsym << 1) | 1u) : (dist << 1);
         uint32_t carry = 0;
-        uint64_t fenced0 = fl_uni64(o.fenced);
+        // bytes between the last fence and this round's output (saturated): what a far copy of pass b0 may read ends
+        // at most b0 + 64 - near_max bytes behind wp0
+        uint64_t gapq = wp0 - fl_uni64(o.fenced);
+        uint32_t fgap = (uint32_t)(gapq >> 32) ? 0xfffffff0u - 512u : min((uint32_t)gapq, 0xfffffff0u - 512u);
         const uint8_t* far_base = o.out + ((int64_t)wp0 - 32768);  // (pointer arithmetic: stays a global address)
         for (uint32_t b0 = 0; b0 < TP; b0 += 64) {
             const uint32_t b = b0 + lane;
@@ -816,22 +831,24 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             carry = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
             const uint32_t info = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1) << 2), (int)tokinfo);
             const uint32_t v = info >> 1;
-            const bool copy = live && !(info & 1);
-            const bool far = copy && v > near_max;
+            const uint64_t m_live = FL_BALLOT(live);
+            const uint64_t m_copy = m_live & FL_BALLOT((info & 1) == 0);
+            const uint64_t m_far = m_copy & FL_BALLOT(v > near_max);
             uint32_t byte = v;
-            if (FL_BALLOT(far)) {
+            if (m_far) {
                 // every far source of this pass ends at or before wp0 + b0 + 63 - near_max
-                if (__builtin_expect(wp0 + b0 + 64 > fenced0 + near_max, 0)) {
+                if (__builtin_expect(fgap + b0 + 64 > near_max, 0)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     o.fenced = o.flushed;
-                    fenced0 = fl_uni64(o.fenced);
+                    gapq = wp0 - fl_uni64(o.fenced);
+                    fgap = (uint32_t)(gapq >> 32) ? 0xfffffff0u - 512u : min((uint32_t)gapq, 0xfffffff0u - 512u);
                 }
                 // a far match reaches back 32768 at most: uniform base, unsigned 32-bit lane offset
-                if (far) byte = far_base[b + 32768u - v];
+                if (FL_INV(m_far)) byte = far_base[b + 32768u - v];
             }
-            if (copy && !far) byte = o.ring[(vp0 + b - v) & rmask];
+            if (FL_INV(m_copy & ~m_far)) byte = o.ring[(vp0 + b - v) & rmask];
             fl_lds_order();
-            if (live) o.ring[(vp0 + b) & rmask] = (uint8_t)byte;
+            if (FL_INV(m_live)) o.ring[(vp0 + b) & rmask] = (uint8_t)byte;
             fl_lds_order();
         }
     }
@@ -847,14 +864,14 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     // ---- (4b) from the first token that reads this round's output: one match at a time, literals by their lanes ----
     if (__builtin_expect(qm != 0, 0)) {
         const uint64_t rest = S & ~((1ull << q0) - 1);
-        uint64_t lq = FL_BALLOT(in_s && is_lit) & rest;
-        uint64_t mq = FL_BALLOT(in_s && is_match) & rest;
+        uint64_t lq = m_in & m_lit & rest;
+        uint64_t mq = m_in & m_match & rest;
         while (mq) {
             const uint32_t m = (uint32_t)__builtin_ctzll(mq);
             mq &= mq - 1;
             const uint64_t lb = lq & ((1ull << m) - 1);
             if (lb) {
-                if ((lb >> lane) & 1) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
+                if (FL_INV(lb)) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
                 lq &= ~lb;
                 fl_lds_order();
             }
@@ -904,7 +921,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
             }
         }
         if (lq) {
-            if ((lq >> lane) & 1) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
+            if (FL_INV(lq)) o.ring[(vp0 + off) & rmask] = (uint8_t)lsym;
             fl_lds_order();
         }
     }
