@@ -619,11 +619,12 @@ def e2e_host(torch, eng, data, job):
     return {"compress_MBps": round(hi / dt / 1e6, 1), "decompress_MBps": round(hi / dt2 / 1e6, 1),
             "compress_pinned_overlapped_MBps": round(hi / dt3 / 1e6, 1),
             "decompress_pinned_overlapped_MBps": round(hi / dt4 / 1e6, 1), "bytes": hi,
-            "note": "flate_hip_*_batch(MEM_HOST) over PCIe.  Pageable host memory: compress copies the input into a pinned "
-                    "mirror with a few host threads and runs the pinned path on the mirrors (round 3; before: one staged "
-                    "copy each way, nothing overlapped), inflate stages once each way; pinned: sub-batches of 1024 chunks "
-                    "with the copies on their own streams beside the kernels (inflate does the same from 16384 streams "
-                    "up: a sub-batch has to fill the chip)"}
+            "note": "flate_hip_*_batch(MEM_HOST) over PCIe (one 57 GB/s budget for both directions on this box).  Pinned: "
+                    "sub-batches of 1024 chunks, input and tables on a copy stream beside the kernels, the first half of every "
+                    "output slot home by the DMA engine's rectangle copy and what a chunk produced beyond it by a copy kernel "
+                    "into the caller's pinned memory.  Pageable: pinned mirrors, filled and emptied by host threads a "
+                    "sub-batch at a time beside the GPU's work; inflate stages once each way (pinned: sub-batches of at "
+                    "least 3072 streams: a sub-batch has to fill the chip)"}
 
 
 def other_workloads(args, torch, eng, device):
