@@ -1644,11 +1644,11 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         par_min_bytes = min_bytes;
     }
     // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
-    // many streams: the small ring keeps 13 per CU in flight
+    // many streams: the small ring keeps 20 per CU in flight
     const char* ering = getenv("FLATE_HIP_INFLATE_RING");
     const bool large = ering ? atoi(ering) >= (int)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // measured crossover
     if (pin_io) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
-    // (a wave per stream: a sub-batch must still fill the chip -- 13 streams per CU -- or the kernel's latency per
+    // (a wave per stream: a sub-batch must still fill the chip -- 20 streams per CU -- or the kernel's latency per
     // stream, not the copies, decides; measured: sub-batches of 1024 streams are slower than no overlap at all)
     // sub-batches of one size (4097 streams used to be 4096 + 1, and the launch for the one cost a stream's whole latency)
     uint32_t sub = n_chunks;

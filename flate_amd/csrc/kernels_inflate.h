@@ -6,13 +6,12 @@
 // container parse (container.zig:111-166).  The status returned for a bad stream is
 // the error name the reference returns (pinned by its 40-case table, inflate.zig:487-527).
 //
-// The symbol decode of one stream is serial, but a dynamic block is decoded in rounds: every
-// lane looks up the codes that would start at "current bit + lane", then the wave walks the
-// chain of real symbol starts with scalar reads of those results (fl_inf_fast_round); anything
-// unusual takes the symbol-at-a-time path, which keeps the reference's order of errors.
-// Output goes to an LDS ring and leaves in coalesced 8-byte stores; LZ77 copies and the
-// checksum are spread over the 64 lanes.  Throughput comes from many streams in flight
-// (16 per CU with the 2 KiB ring).
+// The symbol decode of one stream is serial, but a dynamic block is decoded in rounds (fl_inf_fast_round): every lane
+// decodes the whole token that would start at "current bit + lane", the wave walks the chain of real token starts with
+// one scalar read per token, output offsets come from a prefix sum and the tokens that read nothing of the round are
+// copied together; anything unusual takes the symbol-at-a-time path, which keeps the reference's order of errors.
+// Output goes to an LDS ring and leaves in coalesced 8-byte stores; the checksum is spread over the 64 lanes.
+// Throughput comes from many streams in flight: 20 per CU with the 2 KiB ring (6.5 KB of LDS per stream).
 #pragma once
 #include "kernels_common.h"
 
@@ -33,7 +32,7 @@ typedef fl_hdec_t<32> fl_hdec_small;  // distance (30) and code-length (19) alph
 #define FL_INF_LIT_BITS 10
 #define FL_INF_DST_BITS 8
 // Recent output kept in LDS (power of two); matches up to ring - 260 back are served from it.
-// Large batches run the small ring (13 streams per CU in flight); small batches, where the
+// Large batches run the small ring (20 streams per CU in flight); small batches, where the
 // latency of one stream is what counts, the large one: every match is then an LDS copy.
 #define FL_INF_RING_SMALL 2048u
 #define FL_INF_RING_LARGE 32768u
