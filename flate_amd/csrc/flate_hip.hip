@@ -1306,6 +1306,9 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         // goes with the one before it)
         size_t limit = pass_limit;
         if (pinned_passes && (size_t)(n_chunks - c0) < pass_limit + pass_limit / 2) limit = std::min(pass_chunk_limit(), (size_t)(n_chunks - c0));
+        // (the GPU idles until the first sub-batch has crossed the link: the first two are a quarter and a half)
+        static const bool ramp = getenv("FLATE_HIP_NO_RAMP") == nullptr;
+        if (ramp && pinned_passes && n_chunks >= 3 * pass_limit && pass_count < 2) limit = std::max<size_t>(64, pass_limit >> (2 - pass_count));
         for (nc = 0; c0 + nc < n_chunks; nc++) {
             const fl_chunk& c = chunks[c0 + nc];
             if ((mode >= 4 && (fs || c.in_len > FLATE_HIP_MAX_LZ_CHUNK)) != stream) break;

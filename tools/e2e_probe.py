@@ -22,6 +22,11 @@ def t(f, reps=4):
         t0 = time.perf_counter(); f(); best = min(best, time.perf_counter() - t0)
     return best
 only_pinned = bool(os.environ.get("E2E_PINNED_ONLY"))
+# what the link gives THIS process's pinned buffers (their placement differs from process to process)
+_d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+def _bw(f):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); return n / (time.perf_counter() - t0) / 1e9
+print("this process: pinned H2D %.1f GB/s, D2H into the pinned output buffer %.1f GB/s" % (_bw(lambda: _d.copy_(p_in, non_blocking=True)), _bw(lambda: p_out[:n].copy_(_d, non_blocking=True))))
 for sub in sys.argv[1:] or ["1024"]:
     os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = sub
     a = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
