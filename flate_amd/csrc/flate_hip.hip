@@ -106,6 +106,11 @@ struct flate_hip_ctx {
     // host-buffer calls with pinned memory: copy streams beside the compute stream, events between them
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> xfer_events;
+    // the container's checksum runs on a stream of its own beside the tokenizer (it reads the input and nothing else;
+    // k_offsets waits for it)
+    hipStream_t s_ck = nullptr;
+    hipEvent_t ck_ev0 = nullptr, ck_ev1 = nullptr;
+    bool ck_pending = false;
     // last level 4..9 call, for the debug seam
     uint32_t dbg_pass_chunks = 0;
     uint32_t dbg_first_chunk = 0;
@@ -172,21 +177,26 @@ hipEvent_t get_event(flate_hip_ctx* h) {
 struct ProfScope {
     flate_hip_ctx* h;
     int kid;
+    hipStream_t s;
     hipEvent_t a{}, b{};
-    ProfScope(flate_hip_ctx* h_, int kid_) : h(h_), kid(kid_) {
+    ProfScope(flate_hip_ctx* h_, int kid_, hipStream_t s_ = nullptr) : h(h_), kid(kid_), s(s_ ? s_ : h_->stream) {
         if (h->prof) {
             a = get_event(h);
             b = get_event(h);
-            (void)hipEventRecord(a, h->stream);
+            (void)hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
         if (h->prof) {
-            (void)hipEventRecord(b, h->stream);
+            (void)hipEventRecord(b, s);
             h->pending.push_back({kid, a, b});
         }
     }
 };
+
+// k_checksum beside the kernels that follow on the compute stream; enqueue_back_end joins it
+int launch_checksum_side(flate_hip_ctx* h, uint32_t nb, const uint8_t* d_in, const fl_chunk* dch, const uint32_t* dbc,
+                         const fl_sblock* dsb, const fl_params& prm);
 
 void fold_profile(flate_hip_ctx* h) {
     if (h->pending.empty()) return;
@@ -469,6 +479,27 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
 }
 
 // shared back end of every pass: block planner, offset scan, bit packer
+int launch_checksum_side(flate_hip_ctx* h, uint32_t nb, const uint8_t* d_in, const fl_chunk* dch, const uint32_t* dbc,
+                         const fl_sblock* dsb, const fl_params& prm) {
+    hipStream_t st = h->stream;
+    if (!h->s_ck) {
+        if (hipStreamCreateWithFlags(&h->s_ck, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ck_ev0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ck_ev1, hipEventDisableTiming) != hipSuccess)
+            return FLATE_HIP_E_ALLOC;
+    }
+    // behind everything enqueued so far (the pass's tables and input, the kernels that read the checksums of the pass before)
+    HIP_OK(h, hipEventRecord(h->ck_ev0, st));
+    HIP_OK(h, hipStreamWaitEvent(h->s_ck, h->ck_ev0, 0));
+    {
+        ProfScope ps(h, K_CHECKSUM, h->s_ck);
+        hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, h->s_ck, d_in, dch, dbc, dsb, prm, h->crc, (uint32_t*)h->cks.p);
+    }
+    HIP_OK(h, hipEventRecord(h->ck_ev1, h->s_ck));
+    h->ck_pending = true;
+    return FLATE_HIP_OK;
+}
+
 int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t nb, uint32_t c0, const fl_chunk* dch,
                      const uint32_t* dbc, const fl_sblock* dsb, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_outlen,
                      int32_t* d_status) {
@@ -484,6 +515,10 @@ int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32
         else
             hipLaunchKernelGGL(k_plan, dim3((nb + FL_PLAN_WAVES - 1) / FL_PLAN_WAVES), dim3(64 * FL_PLAN_WAVES), 0, st,
                                dch, dbc, dsb, prm, (const uint32_t*)dhist, dpl);
+    }
+    if (h->ck_pending) {  // the checksums of this pass (launch_checksum_side)
+        HIP_OK(h, hipStreamWaitEvent(st, h->ck_ev1, 0));
+        h->ck_pending = false;
     }
     {
         ProfScope ps(h, K_OFFSETS);
@@ -519,10 +554,13 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     int rc;
     fl_block_plan* dpl = (fl_block_plan*)h->plans.p;
     uint32_t* dhist = (uint32_t*)h->hist.p;
-    uint32_t* dcks = (uint32_t*)h->cks.p;
-    if (container != 0) {
+    // The container's checksum reads the input and nothing else.  Levels 4-7: on a stream of its own beside k_lz_parse, which
+    // lives in LDS (1 GiB gzip level 6: 30.1 -> 29.5 ms; the tokenizer pays 1.1 ms for a neighbour that takes 1.8) -- not
+    // beside k_lz_chain (2.98 ms instead of 1.26 with the checksum next to it) and not beside k_lz_walk, whose gathers
+    // wait for the same memory system (config #3: 9.95 -> 11.9 ms): there it runs first, on the compute stream.
+    if (container != 0 && (mode < 4 || prm.chain >= FL_BULK_MIN_CHAIN)) {
         ProfScope ps(h, K_CHECKSUM);
-        hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, dcks);
+        hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, (uint32_t*)h->cks.p);
     }
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
@@ -556,6 +594,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
                                    (uint32_t*)h->cflag.p);
             }
+            if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
             {
                 ProfScope ps(h, K_LZ_PARSE);
                 hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
@@ -1013,6 +1052,9 @@ int flate_hip_destroy(flate_hip_handle h) {
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->xfer_events) (void)hipEventDestroy(e);
+    if (h->ck_ev0) (void)hipEventDestroy(h->ck_ev0);
+    if (h->ck_ev1) (void)hipEventDestroy(h->ck_ev1);
+    if (h->s_ck) (void)hipStreamDestroy(h->s_ck);
     if (h->s_in) (void)hipStreamDestroy(h->s_in);
     if (h->s_out) (void)hipStreamDestroy(h->s_out);
     (void)hipStreamDestroy(h->own_stream);
