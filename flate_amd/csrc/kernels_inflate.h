@@ -31,6 +31,9 @@ typedef fl_hdec_t<32> fl_hdec_small;  // distance (30) and code-length (19) alph
 
 #define FL_INF_LIT_BITS 10
 #define FL_INF_DST_BITS 8
+#ifndef FL_INF16_DST_BITS
+#define FL_INF16_DST_BITS 9  // k_inflate's own distance table (fl_inflate_ws16): 7 KB of LDS per stream still hold 20 per CU; 8 bits 17.9 ms, 9: 17.6, 10: 19.1
+#endif
 // Recent output kept in LDS (power of two); matches up to ring - 260 back are served from it.
 // Large batches run the small ring (20 streams per CU in flight); small batches, where the
 // latency of one stream is what counts, the large one: every match is then an LDS copy.
@@ -38,6 +41,7 @@ typedef fl_hdec_t<32> fl_hdec_small;  // distance (30) and code-length (19) alph
 #define FL_INF_RING_LARGE 32768u
 
 struct fl_inflate_ws {
+    enum { DST_BITS = FL_INF_DST_BITS };
     fl_hdec lit;
     fl_hdec_small dst, cl;
     // symbol | code_bits << 9 | extra_bits << 13 | value << 17, 0 = not in the table.  value: the
@@ -58,6 +62,7 @@ struct fl_inflate_ws {
 //   lit_lut: symbol | code_bits << 9 | extra_bits << 13 (7 = not a valid length code), 0 = not in the table
 //   dst_lut: symbol | code_bits << 5 | extra_bits << 9 (15 = not a valid distance code), 0 = not in the table
 struct fl_inflate_ws16 {
+    enum { DST_BITS = FL_INF16_DST_BITS };
     fl_hdec lit;
     fl_hdec_small dst;
     union {
@@ -69,7 +74,7 @@ struct fl_inflate_ws16 {
             uint16_t cl_lut[128];
         };
     };
-    uint16_t dst_lut[1u << FL_INF_DST_BITS];
+    uint16_t dst_lut[1u << FL_INF16_DST_BITS];
     uint8_t lens[320];
 };
 // table entry of a symbol with a code of cb bits, by table type
@@ -629,7 +634,7 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS WS* ws, 
         FL_TRY(fl_hdec_generate(&ws->lit, ws->lens, ws->offs, 286, 286, 15, lane));
         FL_TRY(fl_hdec_generate(&ws->dst, ws->lens + 288, ws->offs, 30, 30, 15, lane));
         fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
-        fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+        fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, WS::DST_BITS, lane);
         return 0;
     }
     rc = (int)fl_uni((uint32_t)fl_inf_read_lens(r, ws, 0, hlit + hdist, hlit + hdist, hlit, crossed, lane));
@@ -650,7 +655,7 @@ __device__ __forceinline__ int fl_inf_dynamic_header(fl_bitr& r, FL_LDS WS* ws, 
     if (rc) return crossed ? 14 : rc;
     FL_HDR_T(23);
     fl_hdec_build_lut<false>(&ws->lit, ws->lit_lut, FL_INF_LIT_BITS, lane);
-    fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, FL_INF_DST_BITS, lane);
+    fl_hdec_build_lut<true>(&ws->dst, ws->dst_lut, WS::DST_BITS, lane);
     FL_HDR_T(24);
     return 0;
 }
@@ -731,7 +736,7 @@ __device__ __forceinline__ int fl_inf_fast_round(fl_bitr& r, FL_LDS fl_inflate_w
     const uint64_t m_lit = m_lok & FL_BALLOT(lsym < 256);
     const uint32_t lbits = lcb + leb;  // at most 10 + 5
     const uint32_t wd = __builtin_amdgcn_alignbit(w1, w0, lbits & 31);  // the 32 bits behind the length code
-    const uint32_t de = ws->dst_lut[wd & ((1u << FL_INF_DST_BITS) - 1)];
+    const uint32_t de = ws->dst_lut[wd & ((1u << FL_INF16_DST_BITS) - 1)];
     const uint32_t dsym = de & 31, dcb = (de >> 5) & 15, deb = de >> 9;
     const uint64_t m_match = m_lok & FL_BALLOT(lsym > 256) & FL_BALLOT(de != 0) & FL_BALLOT(deb != 15);
     const uint64_t m_plain = m_lit | m_match;
@@ -964,7 +969,7 @@ __device__ __forceinline__ int fl_inf_dynamic_symbol(fl_bitr& r, FL_LDS fl_infla
         FL_TRY(fl_inf_length(r, sym - 257, length));
         {
             const uint32_t pk = fl_br_peek(r, 15);
-            const uint16_t e = (uint16_t)fl_uni(ws->dst_lut[pk & ((1u << FL_INF_DST_BITS) - 1)]);
+            const uint16_t e = (uint16_t)fl_uni(ws->dst_lut[pk & ((1u << FL_INF16_DST_BITS) - 1)]);
             if (e) {
                 fl_dst_sym_cb(e, dsym, cb);
             } else {
