@@ -557,14 +557,23 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         }
                         // scalar walk over the real starts of this sub-window (kept to a handful of scalar
                         // instructions per token: the one scalar unit of the CU serves all 16 waves)
+                        // (four instructions per token, by hand, as in k_inflate: the position is kept as p - 64 mod 2^32 --
+                        // s_bitset1 and the lane select look at its low six bits only -- and its sum with the token's bits
+                        // carries exactly when the next start is beyond this sub-window; a terminator counts as 255 bits)
                         uint64_t mask = 0;
-                        uint32_t p = carry, nx;
-                        for (;;) {
-                            mask |= 1ull << p;
-                            nx = (uint32_t)__builtin_amdgcn_readlane((int)nextv, (int)p);
-                            if (nx >= 64) break;
-                            p = nx;
-                        }
+                        const uint32_t relv = nextv == 255u ? 255u : bits;
+                        uint32_t pb = carry - 64u, pn;
+                        asm volatile(
+                            "1:\n\t"
+                            "s_bitset1_b64 %[S], %[p]\n\t"
+                            "v_readlane_b32 %[n], %[nb], %[p]\n\t"
+                            "s_add_u32 %[p], %[p], %[n]\n\t"
+                            "s_cbranch_scc0 1b\n\t"
+                            : [S] "+s"(mask), [p] "+s"(pb), [n] "=&s"(pn)
+                            : [nb] "v"(relv)
+                            : "scc");
+                        const uint32_t p = pb + 64u - pn;   // the last token's start
+                        const uint32_t nx = pn == 255u ? 255u : pb + 64u;
                         const uint32_t term = nx == 255u ? p + 1 : 0u;  // the token at p ends the wave's path
                         if (lane == 0) {
                             sh->bitmap[wave][2 * s] = (uint32_t)mask;
