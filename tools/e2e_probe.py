@@ -26,10 +26,13 @@ only_pinned = bool(os.environ.get("E2E_PINNED_ONLY"))
 _d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
 def _bw(f):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); return n / (time.perf_counter() - t0) / 1e9
-print("this process: pinned H2D %.1f GB/s, D2H into the pinned output buffer %.1f GB/s" % (_bw(lambda: _d.copy_(p_in, non_blocking=True)), _bw(lambda: p_out[:n].copy_(_d, non_blocking=True))))
+if not os.environ.get("E2E_NO_TOUCH"): print("this process: pinned H2D %.1f GB/s, D2H into the pinned output buffer %.1f GB/s" % (_bw(lambda: _d.copy_(p_in, non_blocking=True)), _bw(lambda: p_out[:n].copy_(_d, non_blocking=True))))
 for sub in sys.argv[1:] or ["1024"]:
     os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = sub
     a = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
+    if os.environ.get("E2E_MIX"):
+        a1 = t(lambda: run(p_in.data_ptr(), g_out.ctypes.data)); a2 = t(lambda: run(data.ctypes.data, p_out.data_ptr()))
+        print("   pinned in + pageable out %.2f ms; pageable in + pinned out %.2f ms" % (a1 * 1e3, a2 * 1e3))
     b = 1.0 if only_pinned else t(lambda: run(data.ctypes.data, g_out.ctypes.data))
     print("sub-batches of %5s chunks: pinned %6.1f GB/s (%.2f ms)   pageable %6.1f GB/s (%.2f ms)" % (sub, n / a / 1e9, a * 1e3, n / b / 1e9, b * 1e3))
 po = p_out.numpy()
