@@ -561,10 +561,19 @@ def e2e_host(torch, eng, data, job):
                                         _capi.MEM_HOST)
         assert rc == 0 and not status.any()
 
-    comp()  # staging buffers
-    t0 = time.perf_counter()
-    comp()
-    dt = time.perf_counter() - t0
+    def best(f, warm=2, reps=3):
+        """a call takes 10-20 ms and follows seconds of host-side preparation: the first calls meet a GPU and a link that
+        have clocked down (one warm-up call: 15 GB/s; steady: 23-24).  Two untimed calls, the best of three timed ones."""
+        for _ in range(warm):
+            f()
+        ts = []
+        for _ in range(reps):
+            t_ = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t_)
+        return min(ts)
+
+    dt = best(comp)
     # inflate: the streams packed back to back, outputs into the original layout
     lens = out_len.astype(np.int64)
     c_off = np.zeros(k + 1, dtype=np.uint64)
@@ -579,10 +588,7 @@ def e2e_host(torch, eng, data, job):
                                           None, _capi.MEM_HOST)
         assert rc == 0 and not status.any()
 
-    decomp()
-    t1 = time.perf_counter()
-    decomp()
-    dt2 = time.perf_counter() - t1
+    dt2 = best(decomp)
     assert np.array_equal(dec[:hi], host)
     # the same call with pinned buffers: sub-batches, H2D / kernels / D2H overlapped on three streams
     p_in = torch.from_numpy(host).pin_memory()
@@ -594,10 +600,7 @@ def e2e_host(torch, eng, data, job):
                                         _capi.MEM_HOST)
         assert rc == 0 and not status.any()
 
-    comp_pinned()
-    t2 = time.perf_counter()
-    comp_pinned()
-    dt3 = time.perf_counter() - t2
+    dt3 = best(comp_pinned)
     po = p_out.numpy()
     for i in (0, k // 2, k - 1):
         a, b = int(out_off[i]), int(out_off[i]) + int(out_len[i])
@@ -611,10 +614,7 @@ def e2e_host(torch, eng, data, job):
                                           None, _capi.MEM_HOST)
         assert rc == 0 and not status.any()
 
-    decomp_pinned()
-    t3 = time.perf_counter()
-    decomp_pinned()
-    dt4 = time.perf_counter() - t3
+    dt4 = best(decomp_pinned)
     assert np.array_equal(pd.numpy()[:hi], host)
     return {"compress_MBps": round(hi / dt / 1e6, 1), "decompress_MBps": round(hi / dt2 / 1e6, 1),
             "compress_pinned_overlapped_MBps": round(hi / dt3 / 1e6, 1),

@@ -1157,12 +1157,11 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     // staged hipMemcpy each way moves about 10 GB/s and nothing overlaps.  Instead a few host threads copy the
     // input into a pinned mirror, the call runs on the mirrors (sub-batches, DMA copies on their own streams
     // beside the kernels: the pinned path below), and the threads copy the produced bytes out of the mirror.
-    // A caller's PINNED input is read where it lies; his pinned OUTPUT still goes through the mirror: in two processes
-    // of five the DMA engine (and a kernel alike) wrote a torch-pinned buffer at two thirds of the rate (where its pages
-    // live is not ours to choose: 16.6 against 10.1 ms for 256 MiB), our own mirror never (tools/e2e_probe.py).
-    const bool in_pinned = memkind == FLATE_HIP_MEM_HOST && in && is_pinned_host(in + in_lo);
+    // (Pinned buffers are used where they lie: no host thread touches the data.  On a shared host both ways have their
+    // bad minutes -- the direct one 16.6 instead of 10.1 ms in one process of five, the mirrors 17.6 instead of 11.3 when
+    // the neighbours keep the memory system busy -- and the direct one needs no CPU.)
     if (memkind == FLATE_HIP_MEM_HOST && !fs && !pl && (in_hi - in_lo) >= (8ull << 20) && in && out && !h->in_mirror &&
-        !getenv("FLATE_HIP_NO_PIN_MIRROR")) {
+        !is_pinned_host(in + in_lo) && !is_pinned_host(out + out_lo) && !getenv("FLATE_HIP_NO_PIN_MIRROR")) {
         auto grow = [&](void*& p, size_t& cap, size_t want) -> bool {
             if (want <= cap) return true;
             if (p) (void)hipHostFree(p);
@@ -1177,7 +1176,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             cap = sz;
             return true;
         };
-        if ((in_pinned || grow(h->pin_in, h->pin_in_cap, (in_hi - in_lo) + 16)) && grow(h->pin_out, h->pin_out_cap, (out_hi - out_lo) + 16)) {
+        if (grow(h->pin_in, h->pin_in_cap, (in_hi - in_lo) + 16) && grow(h->pin_out, h->pin_out_cap, (out_hi - out_lo) + 16)) {
             const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
             const unsigned nt = std::min(8u, hw);
             auto parallel = [&](uint64_t items, const std::function<void(uint64_t, uint64_t)>& fn) {
@@ -1195,11 +1194,10 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             const uint8_t* pout = (const uint8_t*)h->pin_out;
             // the mirrors take the place of the caller's buffers: same offsets.  A sub-batch's input is copied right before
             // its H2D copy is enqueued, its produced bytes leave the mirror as soon as they have landed.
-            if (!in_pinned)
-                h->mirror_in = [&](uint32_t c0, uint32_t nc) {
-                    const uint64_t a = hin[c0] - in_lo, b = hin[c0 + nc] - in_lo;
-                    parallel(b - a, [&](uint64_t x, uint64_t y) { memcpy(pin + a + x, src + a + x, y - x); });
-                };
+            h->mirror_in = [&](uint32_t c0, uint32_t nc) {
+                const uint64_t a = hin[c0] - in_lo, b = hin[c0 + nc] - in_lo;
+                parallel(b - a, [&](uint64_t x, uint64_t y) { memcpy(pin + a + x, src + a + x, y - x); });
+            };
             bool landed = false;
             h->mirror_out = [&](uint32_t c0, uint32_t nc) {
                 landed = true;
@@ -1211,7 +1209,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 });
             };
             h->in_mirror = true;
-            rc = compress_impl(h, in_pinned ? in : pin - in_lo, in_off, n_chunks, container, mode, (uint8_t*)h->pin_out - out_lo,
+            rc = compress_impl(h, pin - in_lo, in_off, n_chunks, container, mode, (uint8_t*)h->pin_out - out_lo,
                                out_off, out_len, status, memkind, nullptr, nullptr);
             h->in_mirror = false;
             auto take_out = h->mirror_out;

@@ -122,7 +122,7 @@ size_t flate_hip_compress_bound(size_t n, int container, int mode);
  * The bytes of chunk i are exactly what the reference writes for the same
  * input with the same container and level/mode.
  * Host buffers (FLATE_HIP_MEM_HOST): a slot's bytes beyond out_len[i] are unspecified (zeros or
- * what the caller had there).
+ * what the caller had there; a pinned `out` is written in place by the DMA engine and a kernel).
  */
 int flate_hip_compress_batch(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                              uint32_t n_chunks, int container, int mode, uint8_t* out,

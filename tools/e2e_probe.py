@@ -27,13 +27,24 @@ _d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
 def _bw(f):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); return n / (time.perf_counter() - t0) / 1e9
 if not os.environ.get("E2E_NO_TOUCH"): print("this process: pinned H2D %.1f GB/s, D2H into the pinned output buffer %.1f GB/s" % (_bw(lambda: _d.copy_(p_in, non_blocking=True)), _bw(lambda: p_out[:n].copy_(_d, non_blocking=True))))
+def throttled():
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(l.split() for l in open(f).read().strip().splitlines())
+            return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", d.get("throttled_time", 0)))
+        except Exception:
+            pass
+    return (-1, -1)
 for sub in sys.argv[1:] or ["1024"]:
     os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = sub
+    th0 = throttled()
     a = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
     if os.environ.get("E2E_MIX"):
         a1 = t(lambda: run(p_in.data_ptr(), g_out.ctypes.data)); a2 = t(lambda: run(data.ctypes.data, p_out.data_ptr()))
         print("   pinned in + pageable out %.2f ms; pageable in + pinned out %.2f ms" % (a1 * 1e3, a2 * 1e3))
     b = 1.0 if only_pinned else t(lambda: run(data.ctypes.data, g_out.ctypes.data))
+    th1 = throttled()
+    print("   cgroup cpu.stat while timing: throttled %d times, %d us" % (th1[0] - th0[0], th1[1] - th0[1]))
     print("sub-batches of %5s chunks: pinned %6.1f GB/s (%.2f ms)   pageable %6.1f GB/s (%.2f ms)" % (sub, n / a / 1e9, a * 1e3, n / b / 1e9, b * 1e3))
 po = p_out.numpy()
 ok = only_pinned or all(np.array_equal(po[int(oo[i]):int(oo[i]) + int(out_len[i])], g_out[int(oo[i]):int(oo[i]) + int(out_len[i])]) for i in range(0, k, 97))
