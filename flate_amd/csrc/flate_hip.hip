@@ -25,6 +25,8 @@
 #include "kernels_lz.h"
 #include "kernels_parse.h"
 #include "kernels_walk.h"
+#include "kernels_rank.h"
+#include "kernels_parse6.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -38,6 +40,9 @@ enum KernelId {
     K_LZ_MATCH,
     K_LZ_CHAIN,
     K_LZ_PARSE,
+    K_LZ_RANK,
+    K_LZ_LINK6,
+    K_LZ_PARSE6,
     K_LZ_LINKS,
     K_LZ_WALK,
     K_LZ_EMIT,
@@ -54,7 +59,7 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_chain", "k_lz_parse", "k_lz_links", "k_lz_walk", "k_lz_emit",
+                                           "k_lz_chain", "k_lz_parse", "k_lz_rank", "k_lz_link6", "k_lz_parse6", "k_lz_links", "k_lz_walk", "k_lz_emit",
                                            "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_span_scan", "k_inflate_span",
                                            "k_gather"};
@@ -90,6 +95,7 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
+    DevBuf l6, bnd, ent;  // k_lz_parse6: the chain on six bytes, the budget bounds, phase A's entries (kernels_parse6.h)
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     void* pin_len = nullptr;  // out_len of a sub-batch on its way home (mirror_out reads it before the call ends)
@@ -470,6 +476,11 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
         if ((rc = ensure(h, h->links, per * 4 * sizeof(uint16_t)))) return rc;  // per chunk [L4 | L6 | L8 | RK] (kernels_walk.h)
     } else {
         if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;          // chain links (kernels_parse.h)
+        if (chain >= FL_PARSE6_MIN_CHAIN) {
+            if ((rc = ensure(h, h->l6, per * sizeof(uint16_t)))) return rc;     // links on six bytes (kernels_parse6.h)
+            if ((rc = ensure(h, h->bnd, per * sizeof(uint32_t)))) return rc;    // budget bounds (kernels_rank.h)
+            if ((rc = ensure(h, h->ent, per * sizeof(uint32_t)))) return rc;    // (E4, E5) of phase A
+        }
     }
     if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
     if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
@@ -483,11 +494,21 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
 int launch_checksum_side(flate_hip_ctx* h, uint32_t nb, const uint8_t* d_in, const fl_chunk* dch, const uint32_t* dbc,
                          const fl_sblock* dsb, const fl_params& prm) {
     hipStream_t st = h->stream;
-    if (!h->s_ck) {
-        if (hipStreamCreateWithFlags(&h->s_ck, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ck_ev0, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ck_ev1, hipEventDisableTiming) != hipSuccess)
+    if (!h->s_ck) {  // (all three or none: a half-made set would be skipped by every later call)
+        hipStream_t s = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (s) (void)hipStreamDestroy(s);
+            (void)hipGetLastError();
             return FLATE_HIP_E_ALLOC;
+        }
+        h->s_ck = s;
+        h->ck_ev0 = e0;
+        h->ck_ev1 = e1;
     }
     // behind everything enqueued so far (the pass's tables and input, the kernels that read the checksums of the pass before)
     HIP_OK(h, hipEventRecord(h->ck_ev0, st));
@@ -589,6 +610,26 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
             }
         } else {
+            if (prm.chain >= FL_PARSE6_MIN_CHAIN) {
+                // the chain on six bytes in LDS, the reference's own chain for what it cannot see (kernels_parse6.h)
+                {
+                    ProfScope ps(h, K_LZ_RANK);
+                    hipLaunchKernelGGL(k_lz_rank, dim3(nc), dim3(RK_THREADS), 0, st, d_in, dch, prm, (uint16_t*)h->S.p,
+                                       (uint32_t*)h->bnd.p, (uint32_t*)h->cflag.p);
+                }
+                {
+                    ProfScope ps(h, K_LZ_LINK6);
+                    hipLaunchKernelGGL((k_lz_links<2, 1>), dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->l6.p,
+                                       (uint32_t*)h->cflag.p);
+                }
+                if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
+                {
+                    ProfScope ps(h, K_LZ_PARSE6);
+                    hipLaunchKernelGGL(k_lz_parse6, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
+                                       (const uint16_t*)h->l6.p, (const uint32_t*)h->bnd.p, (uint32_t*)h->ent.p,
+                                       (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+                }
+            } else {
             // levels 4..7: the reference's chain in LDS, the automaton per segment (kernels_parse.h)
             {
                 ProfScope ps(h, K_LZ_CHAIN);
@@ -600,6 +641,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 ProfScope ps(h, K_LZ_PARSE);
                 hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+            }
             }
         }
         {
@@ -1046,7 +1088,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})
@@ -1333,6 +1375,19 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     size_t pass_count = 0;
     std::deque<std::vector<uint32_t>> keep_blk;
     std::deque<std::vector<fl_sblock>> keep_sb;
+    // On the pinned path the passes are enqueued without a host wait in between and the copies on the input stream read the
+    // vectors above: whichever way this function is left (an error in the middle included), they are outlived by the copies.
+    struct PassGuard {
+        flate_hip_ctx* h;
+        bool on;
+        ~PassGuard() {
+            if (on) {
+                if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+                (void)hipStreamSynchronize(h->stream);
+            }
+            h->ck_pending = false;  // (an error between the checksum launch and the back end must not leave a stale wait)
+        }
+    } pass_guard{h, pinned_passes};
     std::vector<uint32_t> pass_c0;  // first chunk of every pass (mirror_out)
     const bool landing = pin_out && (bool)h->mirror_out;
     if (landing && h->pin_len_cap < sizeof(uint64_t) * (size_t)n_chunks) {
@@ -1356,7 +1411,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         if (pinned_passes && (size_t)(n_chunks - c0) < pass_limit + pass_limit / 2) limit = std::min(pass_chunk_limit(), (size_t)(n_chunks - c0));
         // (the GPU idles until the first sub-batch has crossed the link: the first two are a quarter and a half)
         static const bool ramp = getenv("FLATE_HIP_NO_RAMP") == nullptr;
-        if (ramp && pinned_passes && n_chunks >= 3 * pass_limit && pass_count < 2) limit = std::max<size_t>(64, pass_limit >> (2 - pass_count));
+        if (ramp && pinned_passes && n_chunks >= 3 * pass_limit && pass_count < 2) limit = std::min(pass_limit, std::max<size_t>(64, pass_limit >> (2 - pass_count)));  // (never above the configured bound: FLATE_HIP_MAX_PASS_CHUNKS)
         for (nc = 0; c0 + nc < n_chunks; nc++) {
             const fl_chunk& c = chunks[c0 + nc];
             if ((mode >= 4 && (fs || c.in_len > FLATE_HIP_MAX_LZ_CHUNK)) != stream) break;
@@ -1371,7 +1426,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         const bool sliced = pinned_passes && !stream;  // this pass's tables: a slice of their own, filled on the input stream
         if (pin_in && !sliced) {  // this sub-batch's input: in flight while the previous sub-batch is computed
             const uint64_t a = hin[c0], b = hin[c0 + nc];
-            if ((rc = xfer_event(h, 3 * pass_index, &ev_in))) return rc;
+            if ((rc = xfer_event(h, 4 * pass_index, &ev_in))) return rc;
             if (b > a)
                 HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
             HIP_OK(h, hipEventRecord(ev_in, h->s_in));
@@ -1448,7 +1503,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             const uint64_t a = hin[c0], b = hin[c0 + nc];
             if (pin_in && b > a)
                 HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
-            if ((rc = xfer_event(h, 3 * pass_index, &ev_in))) return rc;
+            if ((rc = xfer_event(h, 4 * pass_index, &ev_in))) return rc;
             HIP_OK(h, hipEventRecord(ev_in, h->s_in));
         } else {
             HIP_OK(h, hipMemcpyAsync(tab_chunks, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, st));
@@ -1496,13 +1551,22 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             h->dbg_chunks.assign(chunks.begin() + c0, chunks.begin() + c0 + nc);
             h->dbg_pieces = tabs.pieces;
             if ((rc = enqueue_back_end(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
+            if (pinned_passes) {
+                // A whole-stream pass keeps its tables at the START of the table buffers (its block count is not known when
+                // the slices are laid out), where the slices of the chunk passes lie: its kernels are only enqueued here, so
+                // the input stream -- which fills the next chunk pass's slice -- waits for them first.
+                hipEvent_t ev_tab;
+                if ((rc = xfer_event(h, 4 * pass_index + 3, &ev_tab))) return rc;
+                HIP_OK(h, hipEventRecord(ev_tab, st));
+                HIP_OK(h, hipStreamWaitEvent(h->s_in, ev_tab, 0));
+            }
         } else {
             if ((rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
         }
         HIP_OK(h, hipGetLastError());
         if (pin_out) {  // this sub-batch's output slots go home while the next sub-batch is computed
             hipEvent_t ev_out;
-            if ((rc = xfer_event(h, 3 * pass_index + 1, &ev_out))) return rc;
+            if ((rc = xfer_event(h, 4 * pass_index + 1, &ev_out))) return rc;
             HIP_OK(h, hipEventRecord(ev_out, st));
             HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
             const uint64_t a = hout[c0], b = hout[c0 + nc];
@@ -1533,7 +1597,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             }
             if (landing) {  // this pass's lengths and an event behind its way home
                 hipEvent_t ev_done;
-                if ((rc = xfer_event(h, 3 * pass_index + 2, &ev_done))) return rc;
+                if ((rc = xfer_event(h, 4 * pass_index + 2, &ev_done))) return rc;
                 HIP_OK(h, hipMemcpyAsync((uint64_t*)h->pin_len + c0, d_outlen + c0, sizeof(uint64_t) * nc, hipMemcpyDeviceToHost, h->s_out));
                 HIP_OK(h, hipEventRecord(ev_done, h->s_out));
             }
@@ -1544,7 +1608,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         for (size_t k = 0; k < pass_c0.size(); k++) {
             const uint32_t a = pass_c0[k], b = k + 1 < pass_c0.size() ? pass_c0[k + 1] : n_chunks;
             hipEvent_t ev_done;
-            if ((rc = xfer_event(h, 3 * k + 2, &ev_done))) return rc;
+            if ((rc = xfer_event(h, 4 * k + 2, &ev_done))) return rc;
             HIP_OK(h, hipEventSynchronize(ev_done));
             memcpy(out_len + a, (const uint64_t*)h->pin_len + a, sizeof(uint64_t) * (b - a));
             h->mirror_out(a, b - a);

@@ -52,7 +52,8 @@ __device__ __forceinline__ uint32_t fl_lds_add_rtn(uint32_t* lds_word, uint32_t 
 // take turns with the table, so that it sees the positions in ascending order; a lane that was overtaken (a head
 // above its own position, a count that is not the number of earlier bucket members) sends the chunk to the
 // one-position-at-a-time path.
-template <int WHICH>
+// NARR 4: a chunk's four arrays are one block [L4 | L6 | L8 | RK] (levels 8-9); NARR 1: an array of its own (k_lz_parse6's L6).
+template <int WHICH, int NARR = 4>
 __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_links(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ out_all,
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
     if (Mpos == 0) return;
     const uint8_t* src = in + ck.in_off;
     // a chunk's four arrays are one block of 4 x 65536 entries: [L4 | L6 | L8 | RK]
-    uint16_t* pv = out_all + (uint64_t)c * (4u * FL_CHUNK_STRIDE) + (WHICH == 0 ? 0u : WHICH == 1 ? 3u : WHICH == 2 ? 1u : 2u) * FL_CHUNK_STRIDE;
+    uint16_t* pv = NARR == 1 ? out_all + (uint64_t)c * FL_CHUNK_STRIDE
+                             : out_all + (uint64_t)c * (4u * FL_CHUNK_STRIDE) + (WHICH == 0 ? 0u : WHICH == 1 ? 3u : WHICH == 2 ? 1u : 2u) * FL_CHUNK_STRIDE;
     const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
     const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk

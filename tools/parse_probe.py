@@ -32,3 +32,4 @@ print("cycles per fast step+share of slow: %.1f" % (t[46] / max(t[40], 1)))
 print("per wave cycles: fast loop %.0f, slow block %.0f (of which measure part, lanes that measure only: %.0f)" % (t[50] / nw, t[52] / nw, t[51] / nw))
 print("lane 0 of each wave: measure iterations %.1f, transitions %.1f per wave" % (t[53] / nw, t[54] / nw))
 print("per wave cycles: staging (incl. barrier) %.0f, path following incl. the wait for the slowest wave %.0f" % (t[55] / nw, t[56] / nw))
+print("per wave cycles (k_lz_parse6 only): phase A %.0f" % (t[57] / nw))
