@@ -26,7 +26,7 @@ SYMBOLS = [
     "flate_hip_compress_flush", "flate_hip_debug_write_block",
     "flate_hip_compress_batch_sharded", "flate_hip_decompress_batch_sharded",
     "flate_hip_plan_compress", "flate_hip_compress_planned", "flate_hip_plan_destroy",
-    "flate_hip_checksum", "flate_hip_checksum_combine",
+    "flate_hip_checksum", "flate_hip_checksum_combine", "flate_hip_debug_reload_env",
 ]
 
 
@@ -39,11 +39,13 @@ _lib = None
 
 def _share_torchs_hip_runtime():
     """A process that also runs PyTorch-ROCm must have ONE HIP runtime: torch ships its own libamdhip64, and if this
-    library were loaded first it would bring in /opt/rocm's -- the second runtime to come up then finds no usable device
-    (measured: flate_hip_create fails with NO_DEVICE after `import torch`).  So torch's copy, if there is one, is
-    loaded first (same SONAME: the library below binds to it).  torch itself is not imported."""
+    library is loaded first it brings in /opt/rocm's -- the second runtime to come up then finds no usable device
+    (measured: flate_hip_create fails with NO_DEVICE after `import torch`).  When torch is imported already, its runtime
+    is the one the library binds to (same SONAME) and nothing is to do.  Otherwise torch's copy is loaded first ONLY when
+    FLATE_HIP_PRELOAD_TORCH_HIP=1 asks for it (bench.py and the test suite set it: they import torch later); a process
+    that never imports torch gets /opt/rocm's runtime and no side effect.  torch itself is never imported here."""
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("FLATE_HIP_PRELOAD_TORCH_HIP", "0") in ("", "0"):
         return
     try:
         import importlib.util
@@ -93,6 +95,8 @@ def lib():
     L.flate_hip_gather_streams.restype = C.c_int
     L.flate_hip_debug_phase_cycles.argtypes = [vp, u64p, C.c_int]
     L.flate_hip_debug_phase_cycles.restype = C.c_int
+    L.flate_hip_debug_reload_env.argtypes = [vp]
+    L.flate_hip_debug_reload_env.restype = C.c_int
     L.flate_hip_compress_flush.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vp,
                                            C.c_uint64, vp, vp, C.c_int]
     L.flate_hip_compress_flush.restype = C.c_int

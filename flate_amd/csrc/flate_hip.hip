@@ -86,8 +86,25 @@ struct flate_hip_plan {
     bool ready = false;
 };
 
+// The tuning knobs of the environment, read ONCE when the handle is made -- no getenv on any call path
+// (flate_hip_debug_reload_env reads them again: the test suite's seam).
+struct fl_knobs {
+    size_t max_pass_chunks = 32768;       // FLATE_HIP_MAX_PASS_CHUNKS
+    size_t host_pass_chunks = 1024;       // FLATE_HIP_HOST_PASS_CHUNKS
+    uint64_t stream_pass_bytes = 4096ull << 20;  // FLATE_HIP_MAX_STREAM_PASS_MIB
+    uint64_t span_min_bytes = 0;          // FLATE_HIP_INFLATE_SPANS (0 = never); set to the default below
+    bool span_debug = false;              // FLATE_HIP_SPAN_DEBUG
+    int span_twin = -1;                   // FLATE_HIP_SPAN_TWIN: -1 unset, 0 never, 2..950 where to cut
+    bool no_pin_mirror = false;           // FLATE_HIP_NO_PIN_MIRROR
+    bool no_ramp = false;                 // FLATE_HIP_NO_RAMP
+    int rect = -1;                        // FLATE_HIP_RECT: 1 = half of every slot goes home by the DMA engine's rectangle copy (off by default: see there)
+    int64_t inflate_par = -1;             // FLATE_HIP_INFLATE_PAR: -1 unset, 0 never, else the minimum stream size
+    int64_t inflate_ring = -1;            // FLATE_HIP_INFLATE_RING: -1 unset
+};
+
 struct flate_hip_ctx {
     int device = 0;
+    fl_knobs knobs;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool sync = true;
@@ -99,6 +116,8 @@ struct flate_hip_ctx {
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     void* pin_len = nullptr;  // out_len of a sub-batch on its way home (mirror_out reads it before the call ends)
+    void* pin_tab = nullptr;  // the pinned path's per-pass tables on their way to the device (a copy from PAGEABLE memory is staged by the runtime)
+    size_t pin_tab_cap = 0;
     bool in_mirror = false;   // compress_impl is running on the mirrors (no second level of them)
     size_t pin_in_cap = 0, pin_out_cap = 0, pin_len_cap = 0;
     // pageable callers: a sub-batch's input is copied into the mirror right before its H2D copy is enqueued, its produced
@@ -239,19 +258,26 @@ bool level_args(int mode, fl_params& p) {  // deflate.zig:41-52
     }
 }
 
-size_t pass_chunk_limit() {
-    const char* e = getenv("FLATE_HIP_MAX_PASS_CHUNKS");
-    if (e && atoi(e) > 0) return (size_t)atoi(e);
-    return 32768;
+void read_knobs(fl_knobs& k, uint64_t span_default) {
+    k = fl_knobs();
+    const char* e;
+    if ((e = getenv("FLATE_HIP_MAX_PASS_CHUNKS")) && atoi(e) > 0) k.max_pass_chunks = (size_t)atoi(e);
+    if ((e = getenv("FLATE_HIP_HOST_PASS_CHUNKS")) && atoi(e) > 0) k.host_pass_chunks = (size_t)atoi(e);
+    if ((e = getenv("FLATE_HIP_MAX_STREAM_PASS_MIB")) && atoll(e) > 0) k.stream_pass_bytes = (uint64_t)atoll(e) << 20;
+    e = getenv("FLATE_HIP_INFLATE_SPANS");
+    k.span_min_bytes = e ? (uint64_t)atoll(e) : span_default;
+    k.span_debug = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
+    if ((e = getenv("FLATE_HIP_SPAN_TWIN"))) k.span_twin = atoi(e);
+    k.no_pin_mirror = getenv("FLATE_HIP_NO_PIN_MIRROR") != nullptr;
+    k.no_ramp = getenv("FLATE_HIP_NO_RAMP") != nullptr;
+    if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
+    if ((e = getenv("FLATE_HIP_INFLATE_PAR"))) k.inflate_par = atoll(e);
+    if ((e = getenv("FLATE_HIP_INFLATE_RING"))) k.inflate_ring = atoll(e);
 }
-
+size_t pass_chunk_limit(const flate_hip_ctx* h) { return h->knobs.max_pass_chunks; }
 // host-buffer calls whose buffers are pinned run in sub-batches of this many chunks, so that the H2D copy of
 // sub-batch k + 1 and the D2H copy of k - 1 overlap the kernels of k
-size_t host_pass_chunk_limit() {
-    const char* e = getenv("FLATE_HIP_HOST_PASS_CHUNKS");
-    if (e && atoi(e) > 0) return (size_t)atoi(e);
-    return 1024;
-}
+size_t host_pass_chunk_limit(const flate_hip_ctx* h) { return h->knobs.host_pass_chunks; }
 bool is_pinned_host(const void* p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -260,6 +286,21 @@ bool is_pinned_host(const void* p) {
     }
     return a.type == hipMemoryTypeHost;
 }
+// The copy streams of the host-buffer paths.  HIP multiplexes the streams of one priority onto a few hardware queues (four by
+// default), torch's and the caller's included, and two streams that land on one queue run IN ORDER: with the input stream and the
+// output stream on one queue, the input copy of sub-batch k + 1 sits behind the output copy of k, which waits for the kernels of
+// k -- nothing overlaps any more (rocprofv3 timeline, profiles/r05_host_path.txt: H2D 1.19 + kernels 2.15 + D2H 0.6 ms one after
+// the other, 16.6 ms per 256 MiB instead of 10.4; which way a process went was luck).  Queues are pooled per PRIORITY: the
+// input stream gets the highest, the output stream the lowest, the kernels stay on the caller's (normal): three pools.
+hipError_t create_copy_stream(hipStream_t* s, bool input) {
+    int least = 0, greatest = 0;  // (numerically: greatest priority = lowest number)
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, input ? greatest : least);
+}
+
 int xfer_event(flate_hip_ctx* h, size_t k, hipEvent_t* ev) {
     while (h->xfer_events.size() <= k) {
         hipEvent_t e;
@@ -271,11 +312,7 @@ int xfer_event(flate_hip_ctx* h, size_t k, hipEvent_t* ev) {
 }
 
 // whole-stream passes: uncompressed bytes per pass (about 30 bytes of scratch per input byte)
-uint64_t stream_pass_byte_limit() {
-    const char* e = getenv("FLATE_HIP_MAX_STREAM_PASS_MIB");
-    if (e && atoll(e) > 0) return (uint64_t)atoll(e) << 20;
-    return 4096ull << 20;
-}
+uint64_t stream_pass_byte_limit(const flate_hip_ctx* h) { return h->knobs.stream_pass_bytes; }
 
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
 // histograms and the block table for the shared back end.
@@ -285,7 +322,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     int rc;
     const uint32_t nseg = (uint32_t)t.segs.size(), npc = (uint32_t)t.pieces.size();
     const uint64_t npos = t.npos;
-    const size_t tile_limit = pass_chunk_limit();
+    const size_t tile_limit = pass_chunk_limit(h);
     const size_t tiles_per_launch = std::min(t.tiles.size(), tile_limit);
     if ((rc = ensure(h, h->tiles, sizeof(fl_tile) * t.tiles.size()))) return rc;
     if ((rc = ensure(h, h->segs, sizeof(fl_seg) * (t.segs.size() + 1)))) return rc;
@@ -544,7 +581,8 @@ int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32
     }
     {
         ProfScope ps(h, K_OFFSETS);
-        hipLaunchKernelGGL(k_offsets, dim3(nc), dim3(64), 0, st, dch, prm, h->crc, dpl, (const uint32_t*)dcks,
+        // (a wave per chunk; sixteen when the chunks are long streams of many blocks: config #4's one stream has 2049)
+        hipLaunchKernelGGL(k_offsets, dim3(nc), dim3((uint64_t)nb >= 32ull * nc ? 64 * FL_OFFS_MAX_WAVES : 64), 0, st, dch, prm, h->crc, dpl, (const uint32_t*)dcks,
                            d_out, d_outlen + c0, d_status + c0);
     }
     {
@@ -580,10 +618,12 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     // lives in LDS (1 GiB gzip level 6: 30.1 -> 29.5 ms; the tokenizer pays 1.1 ms for a neighbour that takes 1.8) -- not
     // beside k_lz_chain (2.98 ms instead of 1.26 with the checksum next to it) and not beside k_lz_walk, whose gathers
     // wait for the same memory system (config #3: 9.95 -> 11.9 ms): there it runs first, on the compute stream.
-    if (container != 0 && (mode < 4 || prm.chain >= FL_BULK_MIN_CHAIN)) {
+    if (container != 0 && mode >= 4 && prm.chain >= FL_BULK_MIN_CHAIN) {
         ProfScope ps(h, K_CHECKSUM);
         hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, (uint32_t*)h->cks.p);
     }
+    // simple modes: beside the histograms and the planner, which are short chains of latency (config #4: 0.15 of 1.2 ms in line)
+    if (container != 0 && mode < 4 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
         HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // the parse kernels OR / store the anchors in
@@ -676,10 +716,9 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
 int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std::vector<fl_chunk>& chunks, int container,
                      int flags, uint8_t* d_out, uint64_t* d_outlen, int32_t* d_status, uint64_t* d_consumed) {
     const uint32_t n_chunks = (uint32_t)chunks.size();
-    const char* e = getenv("FLATE_HIP_INFLATE_SPANS");  // 0: never; else the minimum stream size in bytes
-    const uint64_t min_bytes = e ? (uint64_t)atoll(e) : FL_SPAN_MIN_BYTES;
+    const uint64_t min_bytes = h->knobs.span_min_bytes;  // FLATE_HIP_INFLATE_SPANS -- 0: never; else the minimum stream size in bytes
     if (!min_bytes || (flags & 1)) return 0;
-    const bool dbg = getenv("FLATE_HIP_SPAN_DEBUG") != nullptr;
+    const bool dbg = h->knobs.span_debug;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     // Worth it (every span is decoded twice) when the long streams of the batch are too few to fill the chip with
@@ -699,8 +738,8 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // without a place to cut at is one span, decoded in place by run A: as before, but in the same launch.  Config #5,
     // cut at 56 / 62 / 66.6 / 72 / 78 % of the compressed bytes: 11.7 / 7.9 / 6.3 / 6.9 / 7.1 ms -- second spans that
     // are too long cost more than first spans that are: 1.5 % are added to f.
-    const char* etw = getenv("FLATE_HIP_SPAN_TWIN");  // 0: never; 2..950: where to cut, in thousandths of the stream (tuning)
-    const bool twin = n_long > FL_SPAN_STREAMS && !(etw && atoi(etw) == 0) && (size_t)n_long * 20 <= (size_t)h->n_cu * 11;  // (40 / 64 / 96 / 160 / 200 one-MiB members: 7.9 / 7.9 / 13.0 / 13.0 / 13.0 ms a workgroup each, 6.1 / 6.1 / 9.1 / 13.3 / 13.4 this way)
+    const int etw = h->knobs.span_twin;  // FLATE_HIP_SPAN_TWIN -- -1: unset; 0: never; 2..950: where to cut, in thousandths of the stream (tuning)
+    const bool twin = n_long > FL_SPAN_STREAMS && etw != 0 && (size_t)n_long * 20 <= (size_t)h->n_cu * 11;  // (40 / 64 / 96 / 160 / 200 one-MiB members: 7.9 / 7.9 / 13.0 / 13.0 / 13.0 ms a workgroup each, 6.1 / 6.1 / 9.1 / 13.3 / 13.4 this way)
     if (n_long > FL_SPAN_STREAMS && !twin) return 0;
     const uint64_t elig_bytes = twin ? std::min<uint64_t>(min_bytes, 32768u) : min_bytes;
     for (uint32_t i = 0; i < n_chunks; i++)
@@ -728,7 +767,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         const uint32_t P = twin ? 2u : (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
-            pt.from_bit = twin ? bits / 1000 * ((etw && atoi(etw) > 1) ? (uint64_t)std::min(950, atoi(etw)) : std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()) + 15))) : bits / P * j;
+            pt.from_bit = twin ? bits / 1000 * (etw > 1 ? (uint64_t)std::min(950, etw) : std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()) + 15))) : bits / P * j;
             pt.limit_bit = j + 1 < P ? bits / P * (j + 1) : bits;
             pt.stream = elig[k];
             pt.pad = 0;
@@ -1071,7 +1110,15 @@ int flate_hip_create(int device, flate_hip_handle* out) {
     }
     h->stream = h->own_stream;
     init_crc_consts(h->crc);
+    read_knobs(h->knobs, FL_SPAN_MIN_BYTES);
     *out = h;
+    return FLATE_HIP_OK;
+}
+
+// Debug / test seam: read the FLATE_HIP_* tuning variables again (they are read once, when the handle is made).
+int flate_hip_debug_reload_env(flate_hip_handle h) {
+    if (!h) return FLATE_HIP_E_INVALID_ARG;
+    read_knobs(h->knobs, FL_SPAN_MIN_BYTES);
     return FLATE_HIP_OK;
 }
 
@@ -1082,6 +1129,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     fold_profile(h);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_len) (void)hipHostFree(h->pin_len);
+    if (h->pin_tab) (void)hipHostFree(h->pin_tab);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
                       &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff, &h->sp_pool, &h->sp_pooltab, &h->sp_poolctl, &h->sp_items,
@@ -1203,7 +1251,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     // bad minutes -- the direct one 16.6 instead of 10.1 ms in one process of five, the mirrors 17.6 instead of 11.3 when
     // the neighbours keep the memory system busy -- and the direct one needs no CPU.)
     if (memkind == FLATE_HIP_MEM_HOST && !fs && !pl && (in_hi - in_lo) >= (8ull << 20) && in && out && !h->in_mirror &&
-        !is_pinned_host(in + in_lo) && !is_pinned_host(out + out_lo) && !getenv("FLATE_HIP_NO_PIN_MIRROR")) {
+        !is_pinned_host(in + in_lo) && !is_pinned_host(out + out_lo) && !h->knobs.no_pin_mirror) {
         auto grow = [&](void*& p, size_t& cap, size_t want) -> bool {
             if (want <= cap) return true;
             if (p) (void)hipHostFree(p);
@@ -1290,8 +1338,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         // and run on their own streams, a sub-batch at a time (below).  Pageable: one staged copy each way.
         pin_in = !fs && is_pinned_host(in + in_lo);
         pin_out = !fs && is_pinned_host(out + out_lo);
-        if ((pin_in && !h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) ||
-            (pin_out && !h->s_out && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess))
+        if ((pin_in && !h->s_in && create_copy_stream(&h->s_in, true) != hipSuccess) ||
+            (pin_out && !h->s_out && create_copy_stream(&h->s_out, false) != hipSuccess))
             return FLATE_HIP_E_ALLOC;
         if (in_hi > in_lo && !pin_in)
             HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
@@ -1335,8 +1383,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
 
     // A pass is a run of consecutive chunks of one kind: at levels 4..9 inputs of up to 65535 bytes
     // take the chunk path (kernels_lz.h), longer ones the whole-stream path (kernels_stream.h).
-    const size_t pass_limit = (pin_in || pin_out) ? std::min(pass_chunk_limit(), host_pass_chunk_limit()) : pass_chunk_limit();
-    const uint64_t stream_pass_bytes = stream_pass_byte_limit();
+    const size_t pass_limit = (pin_in || pin_out) ? std::min(pass_chunk_limit(h), host_pass_chunk_limit(h)) : pass_chunk_limit(h);
+    const uint64_t stream_pass_bytes = stream_pass_byte_limit(h);
     if (pin_out) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
     // Pinned output: the link is shared by both directions (57 GB/s one way, 28.6 each way at once: tools/pcie_probe.py),
     // so what must not cross it is the unused part of the slots.  A copy kernel on the output stream writes the
@@ -1364,12 +1412,26 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     const bool pinned_passes = (pin_in || pin_out) && !pl;
     uint64_t blk_total = 0, blk_base = 0;
     if (pinned_passes) {
-        if (!h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) return FLATE_HIP_E_ALLOC;
+        if (!h->s_in && create_copy_stream(&h->s_in, true) != hipSuccess) return FLATE_HIP_E_ALLOC;
         for (uint32_t i = 0; i < n_chunks; i++)
             blk_total += mode >= 4 ? 2u : (uint64_t)(chunks[i].in_len / FL_BLOCK_BYTES + 1);
         if ((rc = ensure(h, h->chunks, sizeof(fl_chunk) * (size_t)n_chunks))) return rc;
         if ((rc = ensure(h, h->blk_chunk, sizeof(uint32_t) * (size_t)std::max<uint64_t>(blk_total, 1)))) return rc;
         HIP_OK(h, hipStreamSynchronize(h->s_in));  // (nothing of an earlier call may still write the tables)
+        // the tables leave from pinned memory: [fl_chunk x n_chunks | uint32 x blk_total]
+        const size_t tab_need = sizeof(fl_chunk) * (size_t)n_chunks + sizeof(uint32_t) * (size_t)std::max<uint64_t>(blk_total, 1);
+        if (h->pin_tab_cap < tab_need) {
+            if (h->pin_tab) (void)hipHostFree(h->pin_tab);
+            h->pin_tab = nullptr;
+            h->pin_tab_cap = 0;
+            const size_t sz = tab_need + tab_need / 4 + 4096;
+            if (hipHostMalloc(&h->pin_tab, sz, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h->pin_tab = nullptr;
+                return FLATE_HIP_E_ALLOC;
+            }
+            h->pin_tab_cap = sz;
+        }
     }
     uint32_t nc = 0;
     size_t pass_count = 0;
@@ -1408,9 +1470,9 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         // (a sub-batch of the pinned path costs about 0.9 ms whatever it holds: a tail of less than half a sub-batch
         // goes with the one before it)
         size_t limit = pass_limit;
-        if (pinned_passes && (size_t)(n_chunks - c0) < pass_limit + pass_limit / 2) limit = std::min(pass_chunk_limit(), (size_t)(n_chunks - c0));
+        if (pinned_passes && (size_t)(n_chunks - c0) < pass_limit + pass_limit / 2) limit = std::min(pass_chunk_limit(h), (size_t)(n_chunks - c0));
         // (the GPU idles until the first sub-batch has crossed the link: the first two are a quarter and a half)
-        static const bool ramp = getenv("FLATE_HIP_NO_RAMP") == nullptr;
+        const bool ramp = !h->knobs.no_ramp;
         if (ramp && pinned_passes && n_chunks >= 3 * pass_limit && pass_count < 2) limit = std::min(pass_limit, std::max<size_t>(64, pass_limit >> (2 - pass_count)));  // (never above the configured bound: FLATE_HIP_MAX_PASS_CHUNKS)
         for (nc = 0; c0 + nc < n_chunks; nc++) {
             const fl_chunk& c = chunks[c0 + nc];
@@ -1498,8 +1560,14 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         if (sliced) {
             if (blk_base + nb > blk_total) return FLATE_HIP_E_LAUNCH;
             blk_base += nb;
-            HIP_OK(h, hipMemcpyAsync(tab_chunks, &chunks[c0], sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, h->s_in));
-            HIP_OK(h, hipMemcpyAsync(tab_blk, blk_chunk.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, h->s_in));
+            // (through the pinned table buffer: a copy from a pageable vector is staged by the runtime, and the staged copy of
+            // sub-batch k + 1 did not start before the way home of sub-batch k was over -- rocprofv3 timeline, round 5)
+            fl_chunk* pt_chunks = (fl_chunk*)h->pin_tab + c0;
+            uint32_t* pt_blk = (uint32_t*)((fl_chunk*)h->pin_tab + n_chunks) + (blk_base - nb);
+            memcpy(pt_chunks, &chunks[c0], sizeof(fl_chunk) * nc);
+            memcpy(pt_blk, blk_chunk.data(), sizeof(uint32_t) * nb);
+            HIP_OK(h, hipMemcpyAsync(tab_chunks, pt_chunks, sizeof(fl_chunk) * nc, hipMemcpyHostToDevice, h->s_in));
+            HIP_OK(h, hipMemcpyAsync(tab_blk, pt_blk, sizeof(uint32_t) * nb, hipMemcpyHostToDevice, h->s_in));
             const uint64_t a = hin[c0], b = hin[c0 + nc];
             if (pin_in && b > a)
                 HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
@@ -1570,6 +1638,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             HIP_OK(h, hipEventRecord(ev_out, st));
             HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
             const uint64_t a = hout[c0], b = hout[c0 + nc];
+            bool len_by_kernel = false;
             if (b > a && zc_out) {
                 // Slots of one size (the usual case: compress_bound of one chunk size): the first half of every slot goes
                 // home by the DMA engine's rectangle copy -- what lies beyond out_len[i] there is the zeros the slots were
@@ -1584,13 +1653,25 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                     pitch = hout[c0 + 1] - hout[c0];
                     for (urows = 1; urows < nc && hout[c0 + urows + 1] - hout[c0 + urows] == pitch; urows++) {}
                     half = (pitch / 2) & ~(uint64_t)15;
-                    if (urows < 64 || half < 4096) urows = 0;
+                    // (Round 5: OFF unless FLATE_HIP_RECT=1.  The rectangle copy is a DMA copy that waits for the sub-batch's kernels
+                    // -- and the input copy of the NEXT sub-batch, submitted behind it, lands in the same in-order DMA queue in most
+                    // calls of a process: then nothing overlaps any more, 16.6 ms per 256 MiB instead of 10.4 (rocprofv3 timelines,
+                    // profiles/r05_host_path.txt: the 10.4 only ever showed in the second call of a process).  The copy kernel
+                    // alone is 11.4 ms in every call.)
+                    if (urows < 64 || half < 4096 || h->knobs.rect != 1) urows = 0;
                 }
                 if (urows)
                     HIP_OK(h, hipMemcpy2DAsync(out + a, pitch, d_out + (a - out_shift), pitch, half, urows, hipMemcpyDeviceToHost, h->s_out));
+                uint64_t* len_dev = nullptr;  // device view of pin_len + c0 (the mirror path reads the lengths as the passes land)
+                if (landing) {
+                    void* dp = nullptr;
+                    if (hipHostGetDevicePointer(&dp, (uint64_t*)h->pin_len + c0, 0) == hipSuccess && dp) len_dev = (uint64_t*)dp;
+                    else (void)hipGetLastError();
+                }
+                len_by_kernel = len_dev != nullptr;
                 hipLaunchKernelGGL(k_copy_slots, dim3(std::min(64u, nc)), dim3(256), 0, h->s_out, d_out,
                                    (const uint64_t*)h->st_slot.p + c0, (const uint64_t*)d_outlen + c0, zc_out,
-                                   (const uint64_t*)h->st_slot.p + c0, nc, urows, half);
+                                   (const uint64_t*)h->st_slot.p + c0, nc, urows, half, len_dev);
                 HIP_OK(h, hipGetLastError());
             } else if (b > a) {
                 HIP_OK(h, hipMemcpyAsync(out + a, d_out + (a - out_shift), b - a, hipMemcpyDeviceToHost, h->s_out));
@@ -1598,7 +1679,8 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             if (landing) {  // this pass's lengths and an event behind its way home
                 hipEvent_t ev_done;
                 if ((rc = xfer_event(h, 4 * pass_index + 2, &ev_done))) return rc;
-                HIP_OK(h, hipMemcpyAsync((uint64_t*)h->pin_len + c0, d_outlen + c0, sizeof(uint64_t) * nc, hipMemcpyDeviceToHost, h->s_out));
+                if (!len_by_kernel)
+                    HIP_OK(h, hipMemcpyAsync((uint64_t*)h->pin_len + c0, d_outlen + c0, sizeof(uint64_t) * nc, hipMemcpyDeviceToHost, h->s_out));
                 HIP_OK(h, hipEventRecord(ev_done, h->s_out));
             }
         }
@@ -1693,9 +1775,9 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         // the sizes): sub-batches with the copies on their own streams, as in compress_impl.  Otherwise one
         // staged copy in, and only the produced bytes come back (copy_out_host).
         pin_io = is_pinned_host(in + in_lo) && is_pinned_host(out + out_lo) &&
-                 (out_hi - out_lo) <= 8 * (in_hi - in_lo) + (1ull << 20) && n_chunks > 4 * host_pass_chunk_limit();
-        if (pin_io && ((!h->s_in && hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) != hipSuccess) ||
-                       (!h->s_out && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) != hipSuccess)))
+                 (out_hi - out_lo) <= 8 * (in_hi - in_lo) + (1ull << 20) && n_chunks > 4 * host_pass_chunk_limit(h);
+        if (pin_io && ((!h->s_in && create_copy_stream(&h->s_in, true) != hipSuccess) ||
+                       (!h->s_out && create_copy_stream(&h->s_out, false) != hipSuccess)))
             return FLATE_HIP_E_ALLOC;
         if (in_hi > in_lo && !pin_io)
             HIP_OK(h, hipMemcpyAsync(h->st_in.p, in + in_lo, in_hi - in_lo, hipMemcpyHostToDevice, st));
@@ -1750,8 +1832,7 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     bool use_par = false;
     uint32_t par_min_bytes = 0;
     {
-        const char* e = getenv("FLATE_HIP_INFLATE_PAR");  // 0: never; else the minimum stream size in bytes
-        const uint32_t min_bytes = e ? (uint32_t)atoi(e) : 32768u;
+        const uint32_t min_bytes = h->knobs.inflate_par >= 0 ? (uint32_t)h->knobs.inflate_par : 32768u;  // FLATE_HIP_INFLATE_PAR -- 0: never; else the minimum stream size in bytes
         uint32_t n_big = 0;
         for (uint32_t i = 0; i < n_chunks; i++)  // long input, or an output slot that says the output is long
             n_big += (chunks[i].in_len >= min_bytes || chunks[i].out_cap >= 16ull * min_bytes) ? 1u : 0u;
@@ -1760,8 +1841,7 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     }
     // few streams: the latency of one stream decides, give each the large LDS ring (3 per CU);
     // many streams: the small ring keeps 20 per CU in flight
-    const char* ering = getenv("FLATE_HIP_INFLATE_RING");
-    const bool large = ering ? atoi(ering) >= (int)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // measured crossover
+    const bool large = h->knobs.inflate_ring >= 0 ? h->knobs.inflate_ring >= (int64_t)FL_INF_RING_LARGE : n_chunks <= 4u * 256u;  // (FLATE_HIP_INFLATE_RING; measured crossover)
     if (pin_io) HIP_OK(h, hipStreamSynchronize(h->s_out));  // (nothing of an earlier call may still read st_out)
     // (a wave per stream: a sub-batch must still fill the chip -- 20 streams per CU -- or the kernel's latency per
     // stream, not the copies, decides; measured: sub-batches of 1024 streams are slower than no overlap at all)
@@ -1770,7 +1850,7 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
     if (pin_io) {
         // (a sub-batch has to fill the chip -- 20 streams per CU -- or the latency of a stream decides: two sub-batches of
         // 2049 streams take as long as one batch, five of 3277 are 33 GB/s against 24, tools/e2e_inflate_probe.py)
-        const uint32_t target = 3u * (uint32_t)host_pass_chunk_limit();
+        const uint32_t target = 3u * (uint32_t)host_pass_chunk_limit(h);
         const uint32_t nsub = std::max(1u, n_chunks / target);
         sub = (n_chunks + nsub - 1) / nsub;
     }

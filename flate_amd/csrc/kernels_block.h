@@ -51,41 +51,52 @@ __device__ __forceinline__ void fl_plan_marker(fl_block_plan* plan) {
 
 // ------------------------------------------------------------------ histograms
 // huffman-only mode: 256-bin byte histogram of each 65535-byte block
-// (block_writer.zig:575-585).  One workgroup (256 threads) per block; per-wave
-// LDS sub-histograms reduced at the end.
+// (block_writer.zig:575-585).  One workgroup (256 threads) per block, 16-byte loads; every wave keeps FL_HIST_COPIES
+// sub-histograms in LDS, a lane adds to copy (lane mod FL_HIST_COPIES): lanes that meet in one counter are served one after the
+// other, and on runs of one byte (zero padding, sparse zeros) all 64 lanes of an instruction used to meet.
+#define FL_HIST_COPIES 8
 __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ in,
                                                    const fl_chunk* __restrict__ chunks,
                                                    const uint32_t* __restrict__ blk_chunk,
                                                    const fl_sblock* __restrict__ sblocks,
                                                    uint32_t* __restrict__ hist /* [n_blocks][320] */) {
-    __shared__ uint32_t sh[4][256];
+    __shared__ uint32_t sh[4 * FL_HIST_COPIES][256];
     const uint32_t b = blockIdx.x;
     const fl_chunk ck = chunks[blk_chunk[b]];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    for (uint32_t i = tid; i < 4 * 256; i += 256) (&sh[0][0])[i] = 0;
+    const uint32_t cp = wave * FL_HIST_COPIES + (tid & (FL_HIST_COPIES - 1));  // (indexed, not through a pointer: the atomics stay LDS instructions)
+    for (uint32_t i = tid; i < 4 * FL_HIST_COPIES * 256; i += 256) (&sh[0][0])[i] = 0;
     __syncthreads();
     if (!ck.skip) {
         const fl_sb sb = fl_simple_block(ck, sblocks, b);
         const uint32_t len = sb.len;
         const uint8_t* src = in + ck.in_off + sb.start;
-        // head bytes up to 4-byte alignment, then dword loads
-        const uint32_t mis = (uint32_t)((4 - ((uintptr_t)src & 3)) & 3);
+        // head bytes up to 16-byte alignment, then 16-byte loads
+        const uint32_t mis = (uint32_t)((16 - ((uintptr_t)src & 15)) & 15);
         const uint32_t head = mis < len ? mis : len;
-        if (tid < head) atomicAdd(&sh[wave][src[tid]], 1u);
-        const uint32_t body = (len - head) >> 2;
-        const uint32_t* src32 = (const uint32_t*)(src + head);
+        if (tid < head) atomicAdd(&sh[cp][src[tid]], 1u);
+        const uint32_t body = (len - head) >> 4;
+        const uint4* src16 = (const uint4*)(src + head);
         for (uint32_t i = tid; i < body; i += 256) {
-            const uint32_t w = src32[i];
-            atomicAdd(&sh[wave][w & 0xff], 1u);
-            atomicAdd(&sh[wave][(w >> 8) & 0xff], 1u);
-            atomicAdd(&sh[wave][(w >> 16) & 0xff], 1u);
-            atomicAdd(&sh[wave][w >> 24], 1u);
+            const uint4 v = src16[i];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = w4[k];
+                atomicAdd(&sh[cp][w & 0xff], 1u);
+                atomicAdd(&sh[cp][(w >> 8) & 0xff], 1u);
+                atomicAdd(&sh[cp][(w >> 16) & 0xff], 1u);
+                atomicAdd(&sh[cp][w >> 24], 1u);
+            }
         }
-        const uint32_t tail0 = head + (body << 2);
-        if (tail0 + tid < len) atomicAdd(&sh[wave][src[tail0 + tid]], 1u);
+        const uint32_t tail0 = head + (body << 4);
+        if (tail0 + tid < len) atomicAdd(&sh[cp][src[tail0 + tid]], 1u);
     }
     __syncthreads();
-    hist[(uint64_t)b * 320 + tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4 * FL_HIST_COPIES; k++) v += sh[k][tid];
+    hist[(uint64_t)b * 320 + tid] = v;
 }
 
 // debug seam (flate_hip_debug_write_block): histogram of a caller-supplied token list, as the
@@ -380,78 +391,101 @@ __device__ __forceinline__ uint64_t fl_offmap_apply(fl_offmap f, uint64_t off) {
     return f.has ? (((off + f.a + 7) & ~7ull) + f.c) : off + f.a;
 }
 
-// One wave per chunk: block offsets, container header / footer bytes, out_len, status.
-__global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chunks, fl_params prm,
+// One workgroup per chunk: block offsets, container header / footer bytes, out_len, status.  A chunk of the chunk path has two
+// blocks and gets one wave; a long huffman-only / store-only stream has thousands (config #4: 2049) and gets 16 -- every wave a
+// contiguous range of the blocks: its composed map first, the waves' maps composed in order through LDS, then the range again
+// with what lies before it applied (one wave over 2049 blocks: 0.19 ms of a 1.2 ms step, most of it the checksum fold: 33
+// blocks per lane, a 32-step polynomial product each).
+#define FL_OFFS_MAX_WAVES 16
+__global__ __launch_bounds__(64 * FL_OFFS_MAX_WAVES) void k_offsets(const fl_chunk* __restrict__ chunks, fl_params prm,
                                                 fl_crc_consts cc, fl_block_plan* __restrict__ plans,
                                                 const uint32_t* __restrict__ cks_part,
                                                 uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                 int32_t* __restrict__ status) {
+    __shared__ fl_offmap wtot[FL_OFFS_MAX_WAVES];
+    __shared__ uint32_t wx[FL_OFFS_MAX_WAVES], wy[FL_OFFS_MAX_WAVES];
+    __shared__ uint64_t wl[FL_OFFS_MAX_WAVES];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     if (ck.skip) return;  // host already wrote status / out_len
     const uint32_t hdr_bytes = prm.container == 1 ? 10u : (prm.container == 2 ? 2u : 0u);
     const uint32_t ftr_bytes = ck.unfinished ? 0u : (prm.container == 1 ? 8u : (prm.container == 2 ? 4u : 0u));
     const uint64_t base = (ck.out_off + hdr_bytes) * 8;
+    // this wave's blocks: [r0, r1), a multiple of 64 per wave
+    const uint32_t R = (((ck.n_blocks + W - 1) / W) + 63u) & ~63u;
+    const uint32_t r0 = min(wave * R, ck.n_blocks), r1 = min(r0 + R, ck.n_blocks);
 
-    fl_offmap run;  // composition of all blocks before the current batch
-    run.a = 0;
-    run.c = 0;
-    run.has = 0;
-    for (uint32_t b0 = 0; b0 < ck.n_blocks; b0 += 64) {
-        const uint32_t j = b0 + lane;
-        fl_offmap m;
-        m.a = 0;
-        m.c = 0;
-        m.has = 0;
-        fl_block_plan* plan = nullptr;
-        if (j < ck.n_blocks) {
-            plan = &plans[ck.first_block + j];
-            if (plan->valid) {
-                if (plan->type == FL_BLOCK_STORED) {
-                    m.a = 3;
-                    m.c = 32 + 8ull * plan->in_len;
-                    m.has = 1;
-                } else {
-                    m.a = plan->size_bits;
+    fl_offmap ident;
+    ident.a = 0;
+    ident.c = 0;
+    ident.has = 0;
+    // the composition of the range's blocks behind `pre`; with `write`, every block gets its bit offset on the way
+    auto pass = [&](fl_offmap pre, bool write) {
+        fl_offmap run = pre;
+        for (uint32_t b0 = r0; b0 < r1; b0 += 64) {
+            const uint32_t j = b0 + lane;
+            fl_offmap m = ident;
+            fl_block_plan* plan = nullptr;
+            if (j < r1) {
+                plan = &plans[ck.first_block + j];
+                if (plan->valid) {
+                    if (plan->type == FL_BLOCK_STORED) {
+                        m.a = 3;
+                        m.c = 32 + 8ull * plan->in_len;
+                        m.has = 1;
+                    } else {
+                        m.a = plan->size_bits;
+                    }
                 }
             }
-        }
-        // inclusive scan of the composition across lanes
-        fl_offmap inc = m;
+            // inclusive scan of the composition across lanes
+            fl_offmap inc = m;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            fl_offmap o;
-            o.a = __shfl_up(inc.a, d, 64);
-            o.c = __shfl_up(inc.c, d, 64);
-            o.has = __shfl_up(inc.has, d, 64);
-            if (lane >= (uint32_t)d) inc = fl_offmap_compose(o, inc);
+            for (int d = 1; d < 64; d <<= 1) {
+                fl_offmap o;
+                o.a = __shfl_up(inc.a, d, 64);
+                o.c = __shfl_up(inc.c, d, 64);
+                o.has = __shfl_up(inc.has, d, 64);
+                if (lane >= (uint32_t)d) inc = fl_offmap_compose(o, inc);
+            }
+            if (write) {
+                // exclusive = inclusive of the previous lane
+                fl_offmap exc;
+                exc.a = __shfl_up(inc.a, 1, 64);
+                exc.c = __shfl_up(inc.c, 1, 64);
+                exc.has = __shfl_up(inc.has, 1, 64);
+                if (lane == 0) exc = ident;
+                if (plan && plan->valid) plan->bit_off = fl_offmap_apply(fl_offmap_compose(run, exc), base);
+            }
+            fl_offmap last;
+            last.a = __shfl(inc.a, 63, 64);
+            last.c = __shfl(inc.c, 63, 64);
+            last.has = __shfl(inc.has, 63, 64);
+            run = fl_offmap_compose(run, last);
         }
-        // exclusive = inclusive of the previous lane
-        fl_offmap exc;
-        exc.a = __shfl_up(inc.a, 1, 64);
-        exc.c = __shfl_up(inc.c, 1, 64);
-        exc.has = __shfl_up(inc.has, 1, 64);
-        if (lane == 0) {
-            exc.a = 0;
-            exc.c = 0;
-            exc.has = 0;
-        }
-        if (plan && plan->valid) plan->bit_off = fl_offmap_apply(fl_offmap_compose(run, exc), base);
-        fl_offmap last;
-        last.a = __shfl(inc.a, 63, 64);
-        last.c = __shfl(inc.c, 63, 64);
-        last.has = __shfl(inc.has, 63, 64);
-        run = fl_offmap_compose(run, last);
+        return run;
+    };
+    fl_offmap run;
+    if (W == 1) {
+        run = pass(ident, true);
+    } else {
+        const fl_offmap mine = pass(ident, false);
+        if (lane == 0) wtot[wave] = mine;
+        __syncthreads();
+        fl_offmap pre = ident;
+        for (uint32_t x = 0; x < wave; x++) pre = fl_offmap_compose(pre, wtot[x]);
+        run = pass(pre, true);  // (the fields come from L2 this time)
+        for (uint32_t x = wave + 1; x < W; x++) run = fl_offmap_compose(run, wtot[x]);  // every wave: the whole chunk
     }
     const uint64_t end_bits = fl_offmap_apply(run, base);
     const uint64_t body_end = (end_bits + 7) >> 3;  // bit_writer.flush pads the last byte (bit_writer.zig:46-61)
     const uint64_t total = body_end + ftr_bytes - ck.out_off;
     const bool fits = total <= ck.out_cap;
 
-    // checksum over the whole chunk: fold the per-block parts (lane 0, serial Horner)
+    // checksum over the whole chunk: fold the per-block parts
     uint32_t cks = 0;
-    if (prm.container != 0 && lane == 0) {
+    if (prm.container != 0 && threadIdx.x == 0) {
         if (prm.mode >= 4 && !prm.stream) {
             cks = cks_part[2 * (uint64_t)ck.first_block];
             if (prm.container == 2) {
@@ -463,15 +497,64 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
         }
     }
     if (prm.container != 0 && !(prm.mode >= 4 && !prm.stream)) {
-        const uint32_t v = fl_fold_checksums(cks_part, ck.first_block, ck.n_blocks, prm.container, cc, lane);
-        if (lane == 0) cks = v;
+        // Every lane folds a run of consecutive blocks (Horner: one polynomial product per block), then moves its result to
+        // the END of the chunk -- crc(A || B) = crc(A) x^(8 |B|) + crc(B): the run's part of the chunk's CRC is
+        // crc(run) x^(8 * bytes behind the run); Adler-32: A = sum of the A's, B = sum of (B + A * bytes behind) -- and the
+        // parts are simply added up: no scan of polynomial products (a 6-step scan of up-to-27-product powers was most of
+        // this kernel's 0.19 ms on a stream of 2049 blocks).
+        const uint32_t nbw = r1 - r0, per = (nbw + 63) / 64;
+        const uint32_t j0 = r0 + min(lane * per, nbw), j1 = min(j0 + per, r1);
+        uint32_t x = 0, y = 0, len = 0;  // crc | (A, B) and bytes of this lane's run (a chunk has fewer than 2^32 bytes)
+        for (uint32_t j = j0; j < j1; j++) {
+            const uint32_t pc = cks_part[2 * (uint64_t)(ck.first_block + j)];
+            const uint32_t pl = cks_part[2 * (uint64_t)(ck.first_block + j) + 1];
+            if (prm.container == 1) {
+                const uint32_t shf = pl == FL_BLOCK_BYTES ? cc.pow65535 : fl_crc_xpow8n(cc.xpow8, pl);
+                x = fl_crc_mulmod(x, shf) ^ pc;
+            } else {
+                y = (uint32_t)(((uint64_t)y + (uint64_t)x * pl + (pc >> 16)) % 65521u);
+                x = (x + (pc & 0xffff)) % 65521u;
+            }
+            len += pl;
+        }
+        const uint32_t incl = fl_wave_incl_scan_dpp(len);  // bytes of the wave's range up to and including this lane's run
+        if (lane == 63) wl[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < W; w++) {
+            if (w < wave) before += (uint32_t)wl[w];
+            all += (uint32_t)wl[w];
+        }
+        const uint32_t behind = all - (before + incl);
+        uint32_t px, py = 0;
+        if (prm.container == 1) {
+            px = fl_wave_xor(len ? fl_crc_mulmod(x, fl_crc_xpow8n(cc.xpow8, behind)) : 0u);
+        } else {
+            px = fl_wave_sum(x);                                                                  // (64 terms below 65521 each)
+            py = fl_wave_sum((uint32_t)(((uint64_t)y + (uint64_t)x * (behind % 65521u)) % 65521u));
+        }
+        if (lane == 0) {
+            wx[wave] = px;
+            wy[wave] = py;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t fx = 0, fy = 0;
+            for (uint32_t w = 0; w < W; w++) {
+                if (prm.container == 1) {
+                    fx ^= wx[w];
+                } else {
+                    fx = (fx + wx[w]) % 65521u;
+                    fy = (fy + wy[w]) % 65521u;
+                }
+            }
+            cks = prm.container == 1 ? fx : (((1u + fx) % 65521u) | ((uint32_t)((all % 65521u + fy) % 65521u) << 16));  // a = 1 + A, b = n + B
+        }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         out_len[c] = fits ? total : 0;
         status[c] = fits ? 0 : 100;  // FLATE_HIP_ST_OUTPUT_TOO_SMALL
-        if (!fits) {
-            for (uint32_t j = 0; j < ck.n_blocks; j++) plans[ck.first_block + j].valid = 0;
-        } else {
+        if (fits) {
             uint8_t* o = out + ck.out_off;
             if (prm.container == 1) {  // container.zig:64
                 const uint8_t h[10] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 0x03};
@@ -487,6 +570,9 @@ __global__ __launch_bounds__(64) void k_offsets(const fl_chunk* __restrict__ chu
             }
         }
     }
+    if (W > 1) __syncthreads();  // (no wave clears a plan another wave's second pass still reads)
+    if (!fits)  // (the same verdict in every thread)
+        for (uint32_t j = threadIdx.x; j < ck.n_blocks; j += blockDim.x) plans[ck.first_block + j].valid = 0;
 }
 
 // ------------------------------------------------------------------ encode
@@ -868,8 +954,13 @@ __global__ __launch_bounds__(256) void k_gather_copy(const uint8_t* __restrict__
 // floods the write path with stores that wait for the link stalls every other kernel's stores behind them (the next
 // sub-batch's kernels did not start before the copy had ended: rocprofv3 timeline, tools/e2e_timeline.py).
 // Of the first `urows` slots the DMA engine's rectangle copy has taken the first `skip` bytes: only what lies behind them.
+// `len_dst` (may be null): the streams' lengths go home the same way (pinned host memory the device can write), so that no
+// DMA copy that waits for this sub-batch sits in the engine's queue in front of the next sub-batch's input.
 __global__ __launch_bounds__(256) void k_copy_slots(const uint8_t* __restrict__ out, const uint64_t* __restrict__ out_off,
                                                     const uint64_t* __restrict__ out_len, uint8_t* __restrict__ dst,
-                                                    const uint64_t* __restrict__ dst_off, uint32_t n, uint32_t urows, uint64_t skip) {
+                                                    const uint64_t* __restrict__ dst_off, uint32_t n, uint32_t urows, uint64_t skip,
+                                                    uint64_t* __restrict__ len_dst) {
     for (uint32_t c = blockIdx.x; c < n; c += gridDim.x) fl_gather_one(out, out_off, out_len, dst, dst_off, c, 0, 1, c < urows ? skip : 0);
+    if (len_dst)
+        for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) len_dst[c] = out_len[c];
 }

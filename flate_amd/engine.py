@@ -5,6 +5,7 @@ bytes; device entry points take raw device pointers (e.g. torch tensors'
 `data_ptr()`), keep everything resident in HBM and run on the caller's stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -39,6 +40,19 @@ class Engine:
             raise FlateHipError("%s failed with %d (%s)" % (what, rc, err))
 
     # ---- configuration ----
+    _KNOBS = ("FLATE_HIP_MAX_PASS_CHUNKS", "FLATE_HIP_HOST_PASS_CHUNKS", "FLATE_HIP_MAX_STREAM_PASS_MIB",
+              "FLATE_HIP_INFLATE_SPANS", "FLATE_HIP_SPAN_DEBUG", "FLATE_HIP_SPAN_TWIN", "FLATE_HIP_NO_PIN_MIRROR",
+              "FLATE_HIP_NO_RAMP", "FLATE_HIP_INFLATE_PAR", "FLATE_HIP_INFLATE_RING", "FLATE_HIP_RECT")
+
+    def _sync_env(self):
+        """The library reads its FLATE_HIP_* tuning variables once, when the handle is made.  Tests and probes change them
+        between calls of one engine: when this process's view of them has changed, the handle is told to read them again."""
+        now = tuple(os.environ.get(k) for k in self._KNOBS)
+        if now != getattr(self, "_knob_state", None):
+            if getattr(self, "_knob_state", None) is not None or any(v is not None for v in now):
+                self._L.flate_hip_debug_reload_env(self._h)
+            self._knob_state = now
+
     def set_stream(self, stream_ptr):
         self._L.flate_hip_set_stream(self._h, C.c_void_p(stream_ptr or 0))
 
@@ -51,6 +65,7 @@ class Engine:
     # ---- host buffers ----
     def compress_many(self, chunks, container=0, mode=6):
         """chunks: sequence of bytes-like.  Returns (list of bytes, list of status codes)."""
+        self._sync_env()
         n = len(chunks)
         if n == 0:
             return [], []
@@ -76,6 +91,7 @@ class Engine:
     def compress_flush(self, data, flush_points, finish=True, container=0, mode=6):
         """One stream with sync-flush points (Compressor.write / flush / finish, deflate.zig:335-367).
         Returns (bytes, status)."""
+        self._sync_env()
         blob = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
         fp = np.array(list(flush_points), dtype=np.uint64)
         cap = (self.compress_bound(len(data), container, mode) + 64 * (len(fp) + 1) + 7) & ~7
@@ -105,6 +121,7 @@ class Engine:
         OutputTooSmall (more members behind the first, a damaged footer) is decoded again with the worst
         case of 1100 output bytes per input byte; raw / zlib streams get the worst case at once.
         Returns (list of bytes, list of status codes, list of consumed input bytes)."""
+        self._sync_env()
         n = len(streams)
         if n == 0:
             return [], [], []
@@ -144,6 +161,7 @@ class Engine:
     # ---- device buffers (raw pointers; everything already in HBM) ----
     def compress_device(self, in_ptr, in_off_ptr, n_chunks, container, mode, out_ptr, out_off_ptr, out_len_ptr,
                         status_ptr):
+        self._sync_env()
         rc = self._L.flate_hip_compress_batch(self._h, in_ptr, in_off_ptr, n_chunks, container, mode, out_ptr,
                                               out_off_ptr, out_len_ptr, status_ptr, MEM_DEVICE)
         self._check(rc, "flate_hip_compress_batch")
@@ -151,6 +169,7 @@ class Engine:
     def plan_compress(self, in_off, out_off, container, mode):
         """Plan a device batch whose layout repeats (host offset arrays, n + 1 entries each); returns a
         handle for compress_planned / plan_destroy."""
+        self._sync_env()
         a = np.ascontiguousarray(in_off, dtype=np.uint64)
         b = np.ascontiguousarray(out_off, dtype=np.uint64)
         plan = C.c_void_p()
@@ -169,6 +188,7 @@ class Engine:
 
     def decompress_device(self, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr, out_off_ptr, out_len_ptr,
                           status_ptr, consumed_ptr=None):
+        self._sync_env()
         rc = self._L.flate_hip_decompress_batch(self._h, in_ptr, in_off_ptr, n_chunks, container, flags, out_ptr,
                                                 out_off_ptr, out_len_ptr, status_ptr, consumed_ptr, MEM_DEVICE)
         self._check(rc, "flate_hip_decompress_batch")

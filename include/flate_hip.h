@@ -265,6 +265,10 @@ int flate_hip_debug_write_block(flate_hip_handle h, const uint32_t* tokens, uint
  * phase boundaries during the last call (slots: sort 0-7, match 8-10, parse 16-23). */
 int flate_hip_debug_phase_cycles(flate_hip_handle h, uint64_t* out, int n);
 
+/* The FLATE_HIP_* tuning variables are read once, in flate_hip_create: no call path reads the
+ * environment.  This reads them again (the test suite changes them between calls of one handle). */
+int flate_hip_debug_reload_env(flate_hip_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -476,14 +476,19 @@ def test_planned_batches_only_enqueue():
     eng.close()
 
 
-def test_pinned_output_slots_of_one_size_rectangle_copy_and_the_rest():
-    """Pinned (and pageable: pinned mirrors) output with slots of one size: the first half of every slot comes home by the DMA
-    engine's rectangle copy, what a chunk produced beyond it by the copy kernel.  Chunks that compress well, chunks that do
+@pytest.mark.parametrize("rect", [None, "1"])
+def test_pinned_output_slots_of_one_size_rectangle_copy_and_the_rest(rect, monkeypatch):
+    """Pinned (and pageable: pinned mirrors) output with slots of one size: the produced bytes of every slot come home by the
+    copy kernel (the default since round 5), or -- FLATE_HIP_RECT=1 -- the first half of every slot by the DMA engine's
+    rectangle copy and what a chunk produced beyond it by the copy kernel.  Chunks that compress well, chunks that do
     not (the second half of the slot is needed), empty ones; three sub-batches; every stream against the oracle."""
     import torch
     from flate_amd import _capi, synth
     eng = engine()
     L = _capi.lib()
+    if rect:
+        monkeypatch.setenv("FLATE_HIP_RECT", rect)
+    eng._sync_env()
     rng = np.random.default_rng(99)
     csz, n = 16384, 2500
     text = synth.text(synth.SEED_TEXT + 9, n * csz)
@@ -568,15 +573,68 @@ def test_pinned_host_buffers_take_the_overlapped_path():
         status = np.ones(n, dtype=np.int32)
         cons = np.zeros(n, dtype=np.uint64)
         os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = "256"  # (inflate overlaps in sub-batches of 4 x this many streams)
+        eng._sync_env()  # (the library reads its knobs once per handle: this call goes past the Engine's methods)
         try:
             rc = L.flate_hip_decompress_batch(eng._h, p_in.data_ptr(), c_off.ctypes.data, n, container, 0,
                                               p_out.data_ptr(), off.ctypes.data, dlen.ctypes.data, status.ctypes.data,
                                               cons.ctypes.data, _capi.MEM_HOST)
         finally:
             del os.environ["FLATE_HIP_HOST_PASS_CHUNKS"]
+            eng._sync_env()
         assert rc == 0 and not status.any()
         assert np.array_equal(dlen.astype(np.int64), sizes) and np.array_equal(cons.astype(np.int64), lens)
         assert np.array_equal(p_out.numpy()[: len(data)], data)
+
+
+@pytest.mark.parametrize("mode", [6, 9])
+def test_pinned_batches_that_mix_long_and_short_inputs(mode):
+    """on the pinned path the passes are enqueued without a host wait in between, and a whole-stream
+    pass (an input longer than 65535 bytes) keeps its block table at the START of the table buffer, where the chunk
+    passes' slices lie.  A 200 KB stream has 7 blocks, a 1 MiB stream 33: the next chunk pass's slice used to be copied
+    over them while the stream pass's kernels were only enqueued.  Batches like [long, short, short, ..., long, short ...]
+    from pinned buffers and from pageable ones of more than 8 MiB (the pinned mirrors): every stream == the oracle's."""
+    import torch
+    from flate_amd import _capi, synth
+    eng = engine()
+    L = _capi.lib()
+    rng = np.random.default_rng(1234 + mode)
+    text = synth.text(synth.SEED_TEXT + 9, 24 << 20)
+    sizes = [200_000] + [int(x) for x in rng.integers(1, 3000, 300)] + [1 << 20] + [int(x) for x in rng.integers(1000, 65535, 40)] + \
+            [70_000] + [int(x) for x in rng.integers(1, 500, 200)] + [300_000, 5, 65535, 65536]
+    if mode == 6:  # (level 6 also as a pageable batch of more than 8 MiB: the pinned mirrors)
+        sizes = sizes + [65535] * 90 + [150_000] + [int(x) for x in rng.integers(1, 9000, 150)]
+    sizes = np.array(sizes, dtype=np.int64)
+    n = len(sizes)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(sizes, out=off[1:].view(np.int64))
+    assert mode != 6 or int(off[-1]) > (8 << 20)
+    pad = 1 if mode == 6 else 0
+    data = text[: int(off[-1])]
+    caps = np.array([(eng.compress_bound(int(x), O.GZIP, mode) + 7) & ~7 for x in sizes], dtype=np.uint64)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(caps, out=out_off[1:])
+    want = [O.compress(data[int(off[i]): int(off[i + 1])].tobytes(), O.GZIP, mode) for i in range(n)]
+    os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = "128"  # (several chunk passes between and behind the streams)
+    eng._sync_env()
+    try:
+        for pinned in ((True, False) if pad else (True,)):
+            mk = (lambda k: torch.zeros(k, dtype=torch.uint8).pin_memory()) if pinned else (lambda k: torch.zeros(k, dtype=torch.uint8))
+            h_in = mk(len(data) + 8)
+            h_in[: len(data)] = torch.from_numpy(data)
+            h_out = mk(int(out_off[-1]) + 8)
+            for rep in range(2):  # (twice: the second call finds the buffers of the first)
+                out_len = np.zeros(n, dtype=np.uint64)
+                status = np.ones(n, dtype=np.int32)
+                rc = L.flate_hip_compress_batch(eng._h, h_in.data_ptr(), off.ctypes.data, n, O.GZIP, mode, h_out.data_ptr(),
+                                                out_off.ctypes.data, out_len.ctypes.data, status.ctypes.data, _capi.MEM_HOST)
+                assert rc == 0 and not status.any()
+                o = h_out.numpy()
+                for i in range(n):
+                    got = o[int(out_off[i]): int(out_off[i]) + int(out_len[i])].tobytes()
+                    assert got == want[i], (pinned, rep, i, int(sizes[i]))
+    finally:
+        del os.environ["FLATE_HIP_HOST_PASS_CHUNKS"]
+        eng._sync_env()
 
 
 def test_runny_windows_take_their_variant_and_match_the_oracle():

@@ -157,3 +157,83 @@ def test_bench_spawns_the_ranks_itself():
             os.environ.pop("WORLD_SIZE", None)
         else:
             os.environ["WORLD_SIZE"] = old_ws
+
+
+def _nsw_worker(rank, world, port, q):
+    """bench.py's N > 1 workloads with two CPU ranks: the compress job, the inflate job and the timer are stand-ins (the oracle
+    on a few chunks; barrier + MAX over the ranks on CPU tensors) -- what is under test is that every rank takes part, that
+    the values are whole-job rates and that the keys the north star names are in the dict."""
+    import argparse
+    import importlib.util
+    import time
+    from conftest import ROOT
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+
+        class Job:
+            def __init__(self, d):
+                self.d = d.numpy()[: 3 * 65535]
+                self.lens = None
+
+            def step(self):
+                b = self.d.tobytes()
+                self.lens = np.array([len(O.compress(b[i:i + 65535], O.RAW, 6)) for i in range(0, len(b), 65535)])
+
+            def results(self):
+                return self.lens
+
+        class Inf:
+            def step(self):
+                pass
+
+        def timer(step, steps, warmup):
+            for _ in range(warmup):
+                step()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0 + 0.001 * rank], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()), {"k_lz_parse": (1.0, steps)}
+
+        # (small stand-ins for the 256 / 128 MiB buffers: the sizes in the keys are the bench's, the tensors here are not)
+        real_zeros, real_sil = torch.zeros, synth.silesia_like
+        torch.zeros = lambda n, **kw: real_zeros(min(n, 4 * 65535), dtype=torch.uint8)
+        synth.silesia_like = lambda seed, n: real_sil(seed, min(n, 4 * 65535))
+        try:
+            args = argparse.Namespace(no_decompress=False, no_verify=True)
+            res = bench.north_star_workloads(args, torch, dist, None, world, rank, torch.device("cpu"), make_job=Job, timer=timer,
+                                             make_inflate=lambda job, lens, d: Inf())
+        finally:
+            torch.zeros, synth.silesia_like = real_zeros, real_sil
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_line_carries_the_north_stars_workloads_at_world_2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nsw_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        res = got[r]
+        assert set(res) == {"zeros_256MiB_64KiB_chunks", "silesia_like_128MiB_64KiB_chunks"}
+        for v in res.values():
+            assert v["n_gpus"] == world and v["MBps"] > 0 and v["decompress_MBps"] > 0 and "roofline_frac" in v and "ratio_rank0" in v
+    # whole-job rates from the slowest rank's time: every rank reports the same value
+    assert got[0]["zeros_256MiB_64KiB_chunks"]["MBps"] == got[1]["zeros_256MiB_64KiB_chunks"]["MBps"]

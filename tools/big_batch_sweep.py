@@ -3,6 +3,7 @@
 many-blocks variants: k_encode_wave) through levels 4-7 against the oracle, every chunk.
 Usage: big_batch_sweep.py [seed] [n_chunks]"""
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """Host-buffer inflate of the benchmark's 16385 streams (1 GiB): pageable, pinned with the overlapped sub-batches,
 pinned as one batch."""
 import sys, os, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth, _capi
@@ -27,6 +28,8 @@ def run(pin, tag):
 run(False, "pageable")
 for lim in (sys.argv[2:] or ["1024"]):
     os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = lim
+    eng._sync_env()  # (the library reads its knobs once per handle)
     run(True, "pinned overlapped (sub-batches of about 4 x %s streams)" % lim)
 os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = "100000"
+eng._sync_env()  # (the library reads its knobs once per handle)
 run(True, "pinned, one batch")

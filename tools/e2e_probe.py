@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-buffer compress (level 6, 256 MiB text, 65535-byte chunks) through the C ABI: pinned and pageable, by sub-batch size."""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth, _capi
@@ -16,17 +17,26 @@ g_out = np.zeros(int(oo[-1]) + 8, dtype=np.uint8)
 def run(inp, outp):
     rc = L.flate_hip_compress_batch(eng._h, inp, off.ctypes.data, k, 0, 6, outp, oo.ctypes.data, out_len.ctypes.data, status.ctypes.data, _capi.MEM_HOST)
     assert rc == 0 and not status.any()
-def t(f, reps=4):
-    f(); best = 1e9
+def t(f, reps=6):
+    # the MEDIAN of the calls after two warm-up calls (round 5: the best call of a few used to be the second call of the
+    # process, the only one in which the engine's copies overlapped: profiles/r05_host_path.txt)
+    f(); f(); ts = []
     for _ in range(reps):
-        t0 = time.perf_counter(); f(); best = min(best, time.perf_counter() - t0)
-    return best
+        t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
 only_pinned = bool(os.environ.get("E2E_PINNED_ONLY"))
 # what the link gives THIS process's pinned buffers (their placement differs from process to process)
 _d = torch.empty(n, dtype=torch.uint8, device="cuda:0")
 def _bw(f):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); return n / (time.perf_counter() - t0) / 1e9
 if not os.environ.get("E2E_NO_TOUCH"): print("this process: pinned H2D %.1f GB/s, D2H into the pinned output buffer %.1f GB/s" % (_bw(lambda: _d.copy_(p_in, non_blocking=True)), _bw(lambda: p_out[:n].copy_(_d, non_blocking=True))))
+# ... and both directions at once on two streams: the engine's copies of one process either overlap (about 48 GB/s each way)
+# or take turns (28.6 = half of one direction's 57): profiles/r05_host_path.txt
+_d2 = torch.empty(n, dtype=torch.uint8, device="cuda:0"); _s1, _s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def _both():
+    with torch.cuda.stream(_s1): _d.copy_(p_in, non_blocking=True)
+    with torch.cuda.stream(_s2): p_out[:n].copy_(_d2, non_blocking=True)
+if not os.environ.get("E2E_NO_TOUCH"): print("this process: both directions at once %.1f GB/s each way" % _bw(_both))
 def throttled():
     for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
         try:
@@ -37,11 +47,18 @@ def throttled():
     return (-1, -1)
 for sub in sys.argv[1:] or ["1024"]:
     os.environ["FLATE_HIP_HOST_PASS_CHUNKS"] = sub
+    eng._sync_env()  # (the library reads its knobs once per handle)
     th0 = throttled()
     a = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
     if os.environ.get("E2E_MIX"):
         a1 = t(lambda: run(p_in.data_ptr(), g_out.ctypes.data)); a2 = t(lambda: run(data.ctypes.data, p_out.data_ptr()))
         print("   pinned in + pageable out %.2f ms; pageable in + pinned out %.2f ms" % (a1 * 1e3, a2 * 1e3))
+    os.environ["FLATE_HIP_RECT"] = "0"; eng._sync_env()   # the produced bytes by the copy kernel alone (no rectangle copy by the DMA engine)
+    a0 = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
+    os.environ["FLATE_HIP_RECT"] = "1"; eng._sync_env()
+    a1r = t(lambda: run(p_in.data_ptr(), p_out.data_ptr()))
+    del os.environ["FLATE_HIP_RECT"]; eng._sync_env()
+    print("   pinned, D2H by the copy kernel alone %.2f ms (%.1f GB/s); with the rectangle copy forced %.2f ms (%.1f GB/s)" % (a0 * 1e3, n / a0 / 1e9, a1r * 1e3, n / a1r / 1e9))
     b = 1.0 if only_pinned else t(lambda: run(data.ctypes.data, g_out.ctypes.data))
     th1 = throttled()
     print("   cgroup cpu.stat while timing: throttled %d times, %d us" % (th1[0] - th0[0], th1[1] - th0[1]))

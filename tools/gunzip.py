@@ -3,6 +3,7 @@
 (`gzip.decompress(br.reader(), output_file.writer())`; refuses names without the .gz suffix, :15-19).
 Concatenated members are decoded one after the other (Inflate.reset, inflate.zig:301-309)."""
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -4,6 +4,7 @@
 Options beyond the reference's tool: -l LEVEL (4..9), --huffman, --store."""
 import argparse
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

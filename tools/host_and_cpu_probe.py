@@ -5,6 +5,7 @@
   * the CPU oracle on all host cores (one process per core over the same independent chunks)."""
 import multiprocessing as mp
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 import time
 

@@ -3,6 +3,7 @@
 kinds, whole and damaged (truncations, bit flips, byte splices, tails), through k_inflate alone (both rings) and through the
 library's own choice of kernels.  Status name, bytes and consumed count must agree.  Usage: inflate_fuzz.py [seed] [rounds]"""
 import os, sys, zlib
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,6 +2,7 @@
 """Inflate (k_inflate, device resident) of 64 MiB of every data kind, compressed at level argv[1] (6) in 65535-byte chunks:
 MB/s of output per kind; the result is compared with the input."""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth

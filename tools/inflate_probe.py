@@ -2,6 +2,7 @@
 """Batched gunzip probe: N members of M KiB each (made by the GPU compressor, whole-stream gzip
 level 6), inflated in one call; prints the time per call.  Usage: inflate_probe.py [N] [KiB] [reps]"""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

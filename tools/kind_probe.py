@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel time of compress (level 6, or argv[1]) for each segment type of the Silesia-like mix (128 MiB each)."""
 import os, sys
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """k_inflate_par against zlib-made streams: which streams it finishes itself, bytes equal, time."""
 import os, sys, time, zlib
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from flate_amd import Engine, synth

@@ -3,6 +3,7 @@
 random structured inputs through the chunk path, the whole-stream path, sync flushes and inflate,
 all levels / containers, against the oracle.  Usage: parity_sweep.py [seed] [rounds]"""
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """Counters of k_lz_parse (library built with EXTRA=-DPZ_PROF): wave-level loop statistics per 64 KiB chunk.
 usage: FLATE_HIP_LIB=flate_amd/lib/libflate_hip_prof.so python tools/parse_probe.py [n_chunks] [level] [workload]"""
 import sys, os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from flate_amd import Engine, synth

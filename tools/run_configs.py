@@ -6,6 +6,7 @@
 Each prints one JSON line with throughput and the parity check performed."""
 import json
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 import time
 

@@ -4,6 +4,7 @@ segments of kernels_walk.h and the deferred re-parse of kernels_parse.h must get
 runs of one byte (every length), junk, repeated blocks, sparse zeros and text, levels 4-9, against the oracle.
 Usage: runny_sweep.py [seed] [rounds]   (one round = 48 inputs x 6 levels)"""
 import os
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,7 @@
 """k_span_scan's counters (library built with -DFP_SCAN_PROF): windows, survivors of the cheap tests, headers that
 decode, cycles of thread 0 per step.  usage: FLATE_HIP_LIB=... python tools/scan_probe.py [MiB] [mode] [text|silesia]"""
 import os, sys
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from flate_amd import Engine, synth

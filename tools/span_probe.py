@@ -2,6 +2,7 @@
 """One long stream through the inflater: time, kernels, bytes (tuning aid for the span path).
 usage: python tools/span_probe.py [MiB=64] [mode=6] [container=1] [text|silesia] [streams=1]  (MiB in all, cut into equal streams)"""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth
@@ -22,6 +23,7 @@ for env in ("0", os.environ.get("SPAN_PROBE_MIN")):  # (SPAN_PROBE_MIN: the libr
         os.environ.pop("FLATE_HIP_INFLATE_SPANS", None)
     else:
         os.environ["FLATE_HIP_INFLATE_SPANS"] = env
+        eng._sync_env()  # (the library reads its knobs once per handle)
     eng.profile_reset(); eng.profile_enable(True)
     t0 = time.time()
     outs, st, used = eng.decompress_many(comps, container, caps=[len(d) for d in datas])

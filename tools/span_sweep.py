@@ -6,6 +6,7 @@ count -- for damaged streams as well -- and undamaged ones must give the input b
 usage: python tools/span_sweep.py [seed=1] [rounds=20] [big|many]   (big: stretches of up to 8 MiB instead of 1 MiB;
 many: batches of 34-70 streams -- every stream cut once, both runs in one launch)"""
 import os, sys, zlib
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from flate_amd import Engine, synth
@@ -82,9 +83,11 @@ for rd in range(rounds):
         else:
             streams.append(c); caps.append(max(8, len(d) - int(rng.integers(1, 5000)))); truth.append(None)
     os.environ["FLATE_HIP_INFLATE_SPANS"] = "0"
+    eng._sync_env()  # (the library reads its knobs once per handle)
     ref = eng.decompress_many(streams, container, caps=caps)
     bound = str(int(rng.choice([64, 2000, 40000, 131072])))
     os.environ["FLATE_HIP_INFLATE_SPANS"] = bound
+    eng._sync_env()  # (the library reads its knobs once per handle)
     got = eng.decompress_many(streams, container, caps=caps)
     for i in range(len(streams)):
         same = got[1][i] == ref[1][i] and (got[1][i] != 0 or (got[0][i] == ref[0][i] and got[2][i] == ref[2][i]))

@@ -2,6 +2,7 @@
 """Would two halves of the batch on two streams (two engines) fill each other's kernel tails?  Level 6, 1 GiB of the
 benchmark text: one engine over the whole batch against two engines over a half each, enqueued together."""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth

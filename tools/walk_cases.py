@@ -2,6 +2,7 @@
 """Each input of tests/test_gpu_compress.py's case table on its own through compress (levels 4..9), against the
 oracle's token list, with the time each call takes -- printed before and after, so that a call that hangs is the last line."""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

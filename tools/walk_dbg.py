@@ -2,6 +2,7 @@
 """Debug: one input through compress with the WK_PROF build, counters of k_lz_walk printed.
 usage: FLATE_HIP_LIB=flate_amd/lib/var/lib_wkprof.so python tools/walk_dbg.py level name [size]"""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -2,6 +2,7 @@
 """Counters of k_lz_walk (WK_PROF build) under load: n chunks of an input kind at a level, one pass.
 usage: FLATE_HIP_LIB=flate_amd/lib/var/lib_wkprof.so python tools/walk_load_probe.py kind level [n_chunks]"""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

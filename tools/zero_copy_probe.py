@@ -2,6 +2,7 @@
 """Can a kernel write the produced bytes straight into pinned host memory at link speed?  256 MiB of text compressed on the
 device, then k_gather_copy with a pinned host buffer as destination, against the DMA copy of the packed bytes."""
 import os, sys, time
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")  # one HIP runtime per process: torch, imported later, brings its own (flate_amd/_capi.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from flate_amd import Engine, synth
