@@ -97,6 +97,7 @@ struct fl_knobs {
     int span_twin = -1;                   // FLATE_HIP_SPAN_TWIN: -1 unset, 0 never, 2..950 where to cut
     bool no_pin_mirror = false;           // FLATE_HIP_NO_PIN_MIRROR
     bool no_ramp = false;                 // FLATE_HIP_NO_RAMP
+    int stream_windows = -1;              // FLATE_HIP_STREAM_WINDOWS: -1 unset (by estimate), 0 never, 1 whenever possible (kernels_parse.h, k_lz_parse<true>)
     int rect = -1;                        // FLATE_HIP_RECT: 1 = half of every slot goes home by the DMA engine's rectangle copy (off by default: see there)
     int64_t inflate_par = -1;             // FLATE_HIP_INFLATE_PAR: -1 unset, 0 never, else the minimum stream size
     int64_t inflate_ring = -1;            // FLATE_HIP_INFLATE_RING: -1 unset
@@ -112,6 +113,7 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
+    DevBuf wchunks, swins;  // whole-stream passes on k_lz_parse<true>: the streams' windows as chunks, a table entry per stream
     DevBuf l6, bnd, ent;  // k_lz_parse6: the chain on six bytes, the budget bounds, phase A's entries (kernels_parse6.h)
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
@@ -271,6 +273,7 @@ void read_knobs(fl_knobs& k, uint64_t span_default) {
     k.no_pin_mirror = getenv("FLATE_HIP_NO_PIN_MIRROR") != nullptr;
     k.no_ramp = getenv("FLATE_HIP_NO_RAMP") != nullptr;
     if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
+    if ((e = getenv("FLATE_HIP_STREAM_WINDOWS"))) k.stream_windows = atoi(e) != 0;
     if ((e = getenv("FLATE_HIP_INFLATE_PAR"))) k.inflate_par = atoll(e);
     if ((e = getenv("FLATE_HIP_INFLATE_RING"))) k.inflate_ring = atoll(e);
 }
@@ -317,7 +320,7 @@ uint64_t stream_pass_byte_limit(const flate_hip_ctx* h) { return h->knobs.stream
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
 // histograms and the block table for the shared back end.
 int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
-                         const StreamTables& t) {
+                         const StreamTables& t, const fl_chunk* hch /* the pass's chunks, host copy */) {
     hipStream_t st = h->stream;
     int rc;
     const uint32_t nseg = (uint32_t)t.segs.size(), npc = (uint32_t)t.pieces.size();
@@ -361,7 +364,65 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     const fl_seg* dsg = (const fl_seg*)h->segs.p;
     const fl_piece* dpc = (const fl_piece*)h->pieces.p;
     const uint32_t* dfp = (const uint32_t*)h->fpts.p;
-    for (size_t t0 = 0; t0 < t.tiles.size(); t0 += tiles_per_launch) {
+    // Round 5: many streams, none of them with flush points, levels 4-7: the demand-driven tokenizer of the chunk path walks
+    // every stream's windows in order, a workgroup per stream (kernels_parse.h, k_lz_parse<true>) -- no sort, no records for
+    // every position.  A window costs a workgroup about 0.28 ms, the sort / match pair about 0.061 ms per MiB of all CUs.
+    bool windows = !t.any_flush && prm.chain < FL_BULK_MIN_CHAIN && h->knobs.stream_windows != 0 && nseg;
+    std::vector<fl_chunk> wch;
+    std::vector<fl_swin> sws;
+    if (windows) {
+        uint64_t bytes = 0;
+        uint32_t max_win = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            const fl_chunk& c = hch[i];
+            fl_swin sw{i, (uint32_t)wch.size(), c.n_slides + 1u, 0u};
+            for (uint32_t j = 0; j <= c.n_slides; j++) {
+                fl_chunk w{};
+                w.in_off = c.in_off + (uint64_t)FL_SEG * j;
+                w.in_len = (uint32_t)std::min<uint64_t>(65536u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j);
+                w.pad_ = 1u;  // (a window: k_lz_chain builds its chains whatever it holds)
+                wch.push_back(w);
+            }
+            sws.push_back(sw);
+            bytes += c.in_len;
+            max_win = std::max(max_win, sw.nwin);
+        }
+        if (h->n_cu == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
+            h->n_cu = (uint32_t)v;
+        }
+        const double est_new = (double)((nc + h->n_cu - 1) / h->n_cu) * max_win * 0.28, est_old = (double)bytes / 1048576.0 * 0.061;
+        if (h->knobs.stream_windows < 0 && est_new >= est_old) windows = false;
+        if (wch.size() > tile_limit) windows = false;  // (the chain links of all windows at once: 128 KiB each)
+    }
+    if (windows) {
+        const uint32_t nw = (uint32_t)wch.size();
+        if ((rc = ensure(h, h->wchunks, sizeof(fl_chunk) * nw))) return rc;
+        if ((rc = ensure(h, h->swins, sizeof(fl_swin) * nc))) return rc;
+        if ((rc = ensure(h, h->S, (size_t)nw * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
+        if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nw))) return rc;
+        HIP_OK(h, hipMemcpyAsync(h->wchunks.p, wch.data(), sizeof(fl_chunk) * nw, hipMemcpyHostToDevice, st));
+        HIP_OK(h, hipMemcpyAsync(h->swins.p, sws.data(), sizeof(fl_swin) * nc, hipMemcpyHostToDevice, st));
+        HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
+        {
+            ProfScope ps(h, K_LZ_CHAIN);
+            hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, (const fl_chunk*)h->wchunks.p,
+                               (uint16_t*)h->S.p, (uint32_t*)h->cflag.p);
+        }
+        {
+            ProfScope ps(h, K_LZ_PARSE);
+            hipLaunchKernelGGL(k_lz_parse<true>, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
+                               (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
+                               (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p);
+        }
+        {
+            ProfScope ps(h, K_ST_PARSE);
+            hipLaunchKernelGGL(k_st_count, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg, (const uint32_t*)h->desc.p,
+                               (const uint32_t*)h->marks.p, (uint32_t*)h->segtok.p);
+        }
+    }
+    for (size_t t0 = 0; !windows && t0 < t.tiles.size(); t0 += tiles_per_launch) {
         const uint32_t nt = (uint32_t)std::min(tiles_per_launch, t.tiles.size() - t0);
         const fl_tile* dti = (const fl_tile*)h->tiles.p + t0;
         {
@@ -382,7 +443,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                                (uint32_t*)h->NC.p, (uint32_t*)h->rec.p, cf);
         }
     }
-    if (nseg) {
+    if (nseg && !windows) {
         ProfScope ps(h, K_ST_PARSE);
         hipLaunchKernelGGL(k_st_parse1, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg, prm,
                            (const uint32_t*)h->rec.p, (uint32_t*)h->desc.p, (uint16_t*)h->jmp.p,
@@ -679,8 +740,9 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
             {
                 ProfScope ps(h, K_LZ_PARSE);
-                hipLaunchKernelGGL(k_lz_parse, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
-                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+                hipLaunchKernelGGL(k_lz_parse<false>, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
+                                   (const fl_swin*)nullptr, (const fl_chunk*)nullptr, (const uint32_t*)nullptr);
             }
             }
         }
@@ -1136,7 +1198,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->wchunks, &h->swins, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})
@@ -1612,7 +1674,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc,
                                    (uint32_t*)h->cks.p);
             }
-            if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, tabs))) return rc;
+            if ((rc = compress_stream_pass(h, d_in, prm, nc, nb, tabs, &chunks[c0]))) return rc;
             h->dbg_pass_chunks = nc;
             h->dbg_first_chunk = c0;
             h->dbg_pos_off.clear();

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
     // A chunk of ONE repeated byte (a run of zeros, say) needs no chains: k_lz_parse writes its anchors directly
     // (every position matches its predecessor over the whole lookahead).  Looked for granule by granule; the
     // scan of an ordinary chunk ends in its first step.
-    if (N >= 64) {
+    if (N >= 64 && !ck.pad_) {  // (pad_ != 0: a WINDOW of a long stream -- k_lz_parse<true> enters it anywhere: chains always)
         const uint32_t b0 = src[0] * 0x01010101u;
         bool same = true;
         for (uint32_t g0 = 0; g0 < n_gran; g0 += 64 * FL_CHAIN_WAVES) {
@@ -256,6 +256,21 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #endif
 #define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
 #define PZ_SEG_B 32u
+// STREAM: sub-pass A of a window has only the targets [32506, 49152): smaller segments, so that every lane has one
+#ifndef PZ_SEG_AS
+#define PZ_SEG_AS 24u  // (256 x 1 MiB of text, k_lz_parse<true>: 48 / 32 / 24 / 17 bytes 9.91 / 9.29 / 9.04 / 9.57 ms)
+#endif
+#if PZ_SEG_AS == 17
+#define PZ_SEG_AS_OF(D) (((D) * 61681u) >> 20)   // 61681 / 2^20 = 1 / 17.00002: exact below 2^16
+#elif PZ_SEG_AS == 24
+#define PZ_SEG_AS_OF(D) (((D) * 43691u) >> 20)
+#elif PZ_SEG_AS == 32
+#define PZ_SEG_AS_OF(D) ((D) >> 5)
+#elif PZ_SEG_AS == 48
+#define PZ_SEG_AS_OF(D) (((D) * 43691u) >> 21)
+#else
+#error PZ_SEG_AS: 17, 24, 32 or 48
+#endif
 
 // tuning counters (compiled in with -DPZ_PROF; read with tools/parse_probe.py): per wave, summed over the grid
 #ifdef PZ_PROF
@@ -269,12 +284,30 @@ __device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off)
     return __builtin_amdgcn_alignbyte(w[1], w[0], off);
 }
 
+// STREAM (round 5): the whole-stream path on this tokenizer.  The reference's window after slide j IS a chunk: 65536 bytes from
+// stream position 32768 j, its chain the window's own (Lookup.zig:43-51 drops what lies at or below the window start: relative
+// position 0 is the chain's null there as here), its targets the positions the tokenizer visits before the next slide --
+// [first position visited after slide j, first one visited after slide j + 1) (SlidingWindow.zig:56-60, deflate.zig:304-321),
+// window-relative [32506, 65274) for every window but the first and the last.  One workgroup per stream walks its windows in
+// order (`swins`), the anchor the path leaves a window at is where it enters the next.  Chains: k_lz_chain on the windows as
+// chunks (`chunks` holds one fl_chunk per WINDOW then, `schunks` the streams).  Descriptors and anchor bits go to the stream's
+// arrays at absolute positions, a literal's descriptor is 0 there (k_st_emit, kernels_stream.h).
+struct fl_swin {
+    uint32_t chunk;   // the stream (index into schunks)
+    uint32_t win0;    // its first window (index into chunks / the chain links)
+    uint32_t nwin;    // windows: slides + 1
+    uint32_t pad_;
+};
+template <bool STREAM>
 __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const uint8_t* __restrict__ in,
                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                            const uint16_t* __restrict__ prev_all,
                                                            const uint32_t* __restrict__ cflag,
                                                            uint32_t* __restrict__ desc_all,
-                                                           uint32_t* __restrict__ true_all) {
+                                                           uint32_t* __restrict__ true_all,
+                                                           const fl_swin* __restrict__ swins,
+                                                           const fl_chunk* __restrict__ schunks,
+                                                           const uint32_t* __restrict__ zones) {
     __shared__ uint32_t win32[PZ_WIN_DW];
     __shared__ uint16_t prv[PZ_PRV_N];
     __shared__ uint16_t tX[PZ_THREADS];       // exit of a lane's own parse, as soon as it is known
@@ -283,18 +316,42 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     __shared__ uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
     __shared__ uint16_t tMark[PZ_THREADS];    // segment is on the path
     __shared__ uint32_t sh_next_entry;
-    const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
-    if (ck.skip) return;
+    __shared__ uint32_t sh_exit;              // STREAM: where the path leaves the window (window-relative)
+    constexpr uint32_t LITD = STREAM ? 0u : PZ_DESC_LIT;  // descriptor of an anchor that emits one literal
     const uint32_t tid = threadIdx.x;
+    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    const uint32_t prv_lds = (uint32_t)(size_t)(fl_lds_u32*)prv, win_lds = (uint32_t)(size_t)(fl_lds_u32*)win32;  // LDS byte addresses
+    fl_swin sw;
+    sw.chunk = 0;
+    sw.win0 = blockIdx.x;
+    sw.nwin = 1;
+    fl_chunk sck = chunks[0];
+    if (STREAM) {
+        sw = swins[blockIdx.x];
+        sck = schunks[sw.chunk];
+        if (sck.skip) return;
+    }
+    uint32_t carry = 0;  // STREAM: the anchor at which the path enters the window (window-relative)
+    for (uint32_t wi = 0; wi < sw.nwin; wi++) {
+    const uint32_t c = sw.win0 + wi;
+    const fl_chunk ck = chunks[c];
+    if (!STREAM && ck.skip) return;
     const uint32_t N = ck.in_len;
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* pvg = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
-    uint32_t* descg = desc_all + ck.pos_off;
-    uint32_t* trueg = true_all + (ck.pos_off >> 5);
-    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
-    const uint32_t prv_lds = (uint32_t)(size_t)(fl_lds_u32*)prv, win_lds = (uint32_t)(size_t)(fl_lds_u32*)win32;  // LDS byte addresses
+    const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * wi : ck.pos_off;
+    uint32_t* descg = desc_all + pos_off;
+    uint32_t* trueg = true_all + (pos_off >> 5);
+    // the window's targets [t_first, t_last)
+    uint32_t t_first = 0, t_last = N;
+    if (STREAM) {
+        const uint32_t* zone = zones + sck.zone_off;
+        if (wi) t_first = zone[wi - 1] - FL_MAX_DIST * wi;
+        if (wi + 1 < sw.nwin) t_last = zone[wi] - FL_MAX_DIST * wi;
+        if (wi) __syncthreads();  // the window before is done with the LDS tables
+        if (t_first >= t_last) continue;
+    }
     if (cflag[c] == 1u) {
         // The chunk is one repeated byte (k_lz_chain saw it and built no chains).  Positions 0 and 1 are
         // literals (the only candidate of position 1 is position 0, the chain's null: deflate.zig:248); from
@@ -307,7 +364,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             if (k == 0) {
                 uint32_t w = 0;
                 for (uint32_t p = 0; p < min(N, 2u); p++) {
-                    descg[p] = PZ_DESC_LIT;
+                    descg[p] = LITD;
                     w |= 1u << p;
                 }
                 if (w) atomicOr(&trueg[0], w);
@@ -321,7 +378,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 // (the next anchor is a + len: the next step's, or the end of the chunk)
             } else {
                 for (uint32_t p = a; p < N; p++) {
-                    descg[p] = PZ_DESC_LIT;
+                    descg[p] = LITD;
                     atomicOr(&trueg[p >> 5], 1u << (p & 31u));
                 }
             }
@@ -334,14 +391,16 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #endif
 
     for (uint32_t sub = 0; sub < 2; sub++) {
-        const uint32_t t0 = sub ? PZ_TA : 0u;
-        if (t0 >= N) break;
-        const uint32_t end = min(N, sub ? 65536u : PZ_TA);  // targets [t0, end)
+        const uint32_t t0 = sub ? max(PZ_TA, t_first) : t_first;
+        const uint32_t end = min(t_last, sub ? 65536u : PZ_TA);  // targets [t0, end)
+        if (t0 >= end) break;  // (a window's first target lies below PZ_TA: sub-pass B never runs without A's staging)
         const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
-        const uint32_t S = sub ? PZ_SEG_B : PZ_SEG_A;
+        // (STREAM: small segments when the sub-pass's targets leave a lane for each; a stream's first window starts at 0)
+        const bool small = STREAM && !sub && min(t_last, (uint32_t)PZ_TA) - t_first <= PZ_THREADS * PZ_SEG_AS;
+        const uint32_t S = sub ? PZ_SEG_B : (small ? PZ_SEG_AS : PZ_SEG_A);
         // segment of a relative target position x - t0r (< 65536): a shift, or a multiplication by 1 / 48
         // (43691 / 2^21 = 1 / 47.99997: exact for arguments below 2^16)
-#define PZ_SEG_OF(D) (sub ? ((D) >> 5) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))
+#define PZ_SEG_OF(D) (sub ? ((D) >> 5) : (small ? PZ_SEG_AS_OF(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21))))
         const uint32_t nseg = PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
@@ -473,12 +532,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #ifdef PZ_PROF
         c_tstage += __builtin_readcyclecounter() - c_ts0;
 #endif
-        const uint32_t y0 = sub ? sh_next_entry : 0u;  // the sub-pass is entered at this anchor (relative)
+        const uint32_t y0 = sub ? sh_next_entry : carry;  // the sub-pass is entered at this anchor (relative)
         const uint32_t m = tid;                         // this lane's segment
         const uint32_t seg0 = t0r + m * S;
         const uint32_t seg_end = min(seg0 + S, endr);
         if (y0 >= endr) {  // the path jumps over the whole sub-pass: no anchors (the bitmap is zero already)
-            if (tid == 0) sh_next_entry = y0;
+            if (tid == 0) {
+                sh_exit = y0 + r0;
+                sh_next_entry = sub ? y0 : y0 - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);  // (y0 >= 49152 - 16320 here)
+            }
             continue;
         }
         const uint32_t me = PZ_SEG_OF(y0 - t0r);
@@ -924,7 +986,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                 emit = plen >= lazy;  // deflate.zig:171-173
                             }
                             if (emit) {
-                                uint32_t desc = PZ_DESC_LIT, next = a + 1;
+                                uint32_t desc = LITD, next = a + 1;
                                 if (plen) {
                                     desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
                                     next = a + j + plen;
@@ -1005,8 +1067,16 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         }
         __syncthreads();
         // the next sub-pass counts from its own r0
-        if (tid == 0 && sub == 0) sh_next_entry = sh_next_entry - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);
+        if (tid == 0) {
+            sh_exit = sh_next_entry + r0;
+            if (sub == 0) sh_next_entry = sh_next_entry - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);
+        }
     }
+    if (STREAM) {
+        __syncthreads();
+        carry = sh_exit - FL_MAX_DIST;  // (a window that is not the stream's last is left at or beyond 65274)
+    }
+    }  // windows
 #ifdef PZ_PROF
     if ((tid & 63) == 0) {
         // (c_meas / c_trans are per-lane counters of lane 0's view: only the wave-uniform ones are exact)

@@ -255,6 +255,44 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chun
     }
 }
 
+// ------------------------------------------------------------------ k_st_count
+// Round 5: when the anchors come from k_lz_parse<true> (kernels_parse.h: the demand-driven tokenizer walking the stream's windows),
+// all that is left of k_st_parse2 is its count: the tokens of the segment's marked anchors.
+__global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_count(const fl_chunk* __restrict__ chunks,
+                                                                   const fl_piece* __restrict__ pieces,
+                                                                   const fl_seg* __restrict__ segs,
+                                                                   const uint32_t* __restrict__ desc_all,
+                                                                   const uint32_t* __restrict__ marks_all,
+                                                                   uint32_t* __restrict__ segtok) {
+    __shared__ uint32_t wsum[FL_PARSE_THREADS / 64];
+    const fl_seg sg = segs[blockIdx.x];
+    const fl_piece pc = pieces[sg.piece];
+    const fl_chunk ck = chunks[pc.chunk];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t h0 = sg.h0, lo = max(h0, pc.start), h1 = min(h0 + FL_SEG, pc.end);
+    const uint32_t rlo = lo - h0, len = h1 - h0;
+    const uint32_t* desc = desc_all + ck.pos_off + h0;
+    const uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
+    uint32_t cnt = 0;
+    // a lane per position, 64 consecutive positions per wave and step: the marked lanes' descriptors lie in two or three lines
+    for (uint32_t r0 = tid & ~63u; r0 < len; r0 += FL_PARSE_THREADS) {
+        const uint32_t r = r0 + lane;
+        const uint64_t mk = (uint64_t)gmarks[r0 >> 5] | ((uint64_t)gmarks[(r0 >> 5) + 1] << 32);  // (wave-uniform)
+        if (((mk >> lane) & 1ull) && r >= rlo && r < len) {
+            const uint32_t d = desc[r];
+            cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
+        }
+    }
+    cnt = fl_wave_sum(cnt);
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < FL_PARSE_THREADS / 64; w++) t += wsum[w];
+        segtok[blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------ k_st_scan
 // One wave per piece: index of every segment's first token, and the piece's token count.
 __global__ __launch_bounds__(64) void k_st_scan(const fl_piece* __restrict__ pieces,

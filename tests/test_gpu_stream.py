@@ -272,3 +272,47 @@ def test_whole_stream_tokens_match_the_independent_slide_fixtures():
         assert len(toks) == fix[key]["tokens"], key
         assert hashlib.sha256(np.ascontiguousarray(toks, dtype="<u4").tobytes()).hexdigest() == fix[key]["sha256"], key
         assert pyzlib.decompress(outs[0], -15) == data
+
+
+def test_whole_stream_path_on_the_chunk_tokenizer():
+    """Round 5: batches of many long streams (levels 4-7, no flush points) take k_lz_chain / k_lz_parse<true> -- the reference's
+    window after every slide handled as a chunk, a workgroup per stream walking its windows in order -- instead of the sort /
+    match pair.  The library picks that path by an estimate (many streams); FLATE_HIP_STREAM_WINDOWS=1 forces it for every
+    whole-stream pass without flush points: the token lists, the bytes (incl. the slide fixtures written from the Zig sources,
+    the adversarial streams, the fuzz inputs) must be the oracle's all the same (its own process: the knob is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    me = os.path.abspath(__file__)
+    env = dict(os.environ, FLATE_HIP_STREAM_WINDOWS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", me + "::test_stream_tokens_match_oracle",
+                        me + "::test_stream_bytes_match_oracle", me + "::test_stream_containers",
+                        me + "::test_mixed_batch_of_chunks_and_streams", me + "::test_stream_fuzz_against_oracle",
+                        me + "::test_config1_vector_on_gpu", me + "::test_stream_passes_are_split_by_bytes",
+                        me + "::test_adversarial_long_streams_match_oracle",
+                        me + "::test_whole_stream_tokens_match_the_independent_slide_fixtures"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_many_long_streams_take_the_chunk_tokenizer_by_default():
+    """300 streams of 70-400 KB at level 6 (the estimate picks the new path: many streams, few windows each): bytes == oracle."""
+    from flate_amd import synth
+    eng = engine()
+    rng = np.random.default_rng(5)
+    text = synth.text(synth.SEED_TEXT + 21, 8 << 20).tobytes()
+    sil = synth.silesia_like(synth.SEED_SILESIA + 3, 8 << 20).tobytes()
+    streams = []
+    for i in range(300):
+        src = text if i % 3 else sil
+        n = int(rng.integers(65536, 400_000)) if i % 7 else int(rng.choice([65536, 65537, 98042, 98043, 131072, 131073, 163840]))
+        a = int(rng.integers(0, len(src) - n))
+        streams.append(src[a:a + n])
+    streams[5] = bytes(200_000)                      # one repeated byte: the windows get chains all the same
+    streams[6] = bytes(70_000) + text[:100_000]
+    outs, st = eng.compress_many(streams, O.GZIP, 6)
+    assert st == [0] * len(streams)
+    for i in list(range(0, 300, 11)) + [5, 6, 299]:
+        assert outs[i] == O.compress(streams[i], O.GZIP, 6), (i, len(streams[i]))
+    back, st2, _ = eng.decompress_many(outs, O.GZIP, caps=[len(s) for s in streams])
+    assert st2 == [0] * len(streams) and back == streams
