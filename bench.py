@@ -435,7 +435,7 @@ def measured_traffic(args, n_in, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, two separate
     rocprofv3 --pmc runs of this very command; profiles/r0N_hbm_traffic_1gib.json), when the workload matches;
     PMC counters cannot be read from inside an un-profiled run, so otherwise null."""
-    for name in ("r04_hbm_traffic_1gib.json", "r03_hbm_traffic_1gib.json"):
+    for name in ("r05_hbm_traffic_1gib.json", "r04_hbm_traffic_1gib.json", "r03_hbm_traffic_1gib.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -732,6 +732,15 @@ def baseline_configs(args, torch, eng, device):
     def compress_case(name, data, chunk, container, mode, steps=2, sample=2):
         job = CompressJob(torch, eng, data, chunk, container, mode)
         dt, prof = timed(torch, None, eng, job.step, steps, 2 if steps >= 10 else 1, 1)
+        method = "%d steps" % steps
+        if steps >= 10:
+            # a step of about a millisecond, timed right after seconds of host-side preparation: the GPU's clocks are still on
+            # their way up during the first run (measured: every kernel 10-15 % slower than in the runs that follow)
+            for _ in range(2):
+                dt2, prof2 = timed(torch, None, eng, job.step, steps, 1, 1)
+                if dt2 < dt:
+                    dt, prof = dt2, prof2
+            method = "fastest of three runs of %d steps" % steps
         lens = job.results()
         n, n_out = data.numel(), int(lens.sum())
         ok = None
@@ -743,7 +752,7 @@ def baseline_configs(args, torch, eng, device):
         res[name] = {"MBps": round(n / ms / 1e3, 1), "ms": round(ms, 3), "ratio": round(n_out / n, 4), "kernel": k,
                      "kernel_ms": round(kms, 3), "roofline_frac": _frac(n + n_out, kms),
                      "kernels_ms": {kk: round(v[0] / steps, 3) for kk, v in sorted(prof.items())},
-                     "sampled_chunks_equal_oracle": ok}
+                     "sampled_chunks_equal_oracle": ok, "method": method}
         return job, lens
 
     # configs[2]: gzip level 9 of the TAR-like buffer (177,244,160 bytes: the size of the reference's ziglang.tar), 65535-byte members

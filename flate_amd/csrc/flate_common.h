@@ -172,13 +172,15 @@ struct fl_plan_ws {
     uint16_t list_sym[FL_NUM_LIT + 1];
     uint16_t list_freq[FL_NUM_LIT + 1];
     uint32_t bit_count[17];
-    fl_level_info levels[18];  // the reference's lazy loop (run by the CPU build only: cross-check of the package-merge form)
-    uint32_t leaf_counts[17][16];
+#if !FL_PLAN_PARALLEL
+    fl_level_info levels[18];  // the reference's lazy loop (the CPU build only: cross-check of the package-merge form; on the
+    uint32_t leaf_counts[17][16];  // device they would cost a wave 1.5 KB of LDS: 16 instead of 20 planner waves per CU)
+#endif
     // package-merge form of the same computation (fl_huff_bit_counts_pm)
     uint32_t pm_w[2 * FL_NUM_LIT];   // weights of the current level's list (2n - 2 items)
     uint32_t pm_p[FL_NUM_LIT];       // packages = pair sums of the previous level's list
     uint32_t pm_mask[16][18];        // per level: bit r = item r of the list is a leaf
-    uint32_t pm_c[17];               // per level: leaves among the items the solution takes
+    uint32_t pm_c[16];               // per level (<= 15 bits: 0..15): leaves among the items the solution takes (16, not 17: the struct is 8192 bytes on the device, 20 planner waves per CU)
 };
 
 // what the planner hands to the encode kernel (global memory, one per block)

@@ -98,6 +98,7 @@ struct fl_knobs {
     bool no_pin_mirror = false;           // FLATE_HIP_NO_PIN_MIRROR
     bool no_ramp = false;                 // FLATE_HIP_NO_RAMP
     int stream_windows = -1;              // FLATE_HIP_STREAM_WINDOWS: -1 unset (by estimate), 0 never, 1 whenever possible (kernels_parse.h, k_lz_parse<true>)
+    bool simple_ck_inline = false;        // FLATE_HIP_SIMPLE_CK_INLINE: the simple modes' checksum on the compute stream (round 4's way)
     int rect = -1;                        // FLATE_HIP_RECT: 1 = half of every slot goes home by the DMA engine's rectangle copy (off by default: see there)
     int64_t inflate_par = -1;             // FLATE_HIP_INFLATE_PAR: -1 unset, 0 never, else the minimum stream size
     int64_t inflate_ring = -1;            // FLATE_HIP_INFLATE_RING: -1 unset
@@ -273,6 +274,7 @@ void read_knobs(fl_knobs& k, uint64_t span_default) {
     k.no_pin_mirror = getenv("FLATE_HIP_NO_PIN_MIRROR") != nullptr;
     k.no_ramp = getenv("FLATE_HIP_NO_RAMP") != nullptr;
     if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
+    k.simple_ck_inline = getenv("FLATE_HIP_SIMPLE_CK_INLINE") != nullptr;
     if ((e = getenv("FLATE_HIP_STREAM_WINDOWS"))) k.stream_windows = atoi(e) != 0;
     if ((e = getenv("FLATE_HIP_INFLATE_PAR"))) k.inflate_par = atoll(e);
     if ((e = getenv("FLATE_HIP_INFLATE_RING"))) k.inflate_ring = atoll(e);
@@ -679,12 +681,12 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     // lives in LDS (1 GiB gzip level 6: 30.1 -> 29.5 ms; the tokenizer pays 1.1 ms for a neighbour that takes 1.8) -- not
     // beside k_lz_chain (2.98 ms instead of 1.26 with the checksum next to it) and not beside k_lz_walk, whose gathers
     // wait for the same memory system (config #3: 9.95 -> 11.9 ms): there it runs first, on the compute stream.
-    if (container != 0 && mode >= 4 && prm.chain >= FL_BULK_MIN_CHAIN) {
+    if (container != 0 && ((mode >= 4 && prm.chain >= FL_BULK_MIN_CHAIN) || (mode < 4 && h->knobs.simple_ck_inline))) {
         ProfScope ps(h, K_CHECKSUM);
         hipLaunchKernelGGL(k_checksum, dim3(nb), dim3(64), 0, st, d_in, dch, dbc, dsb, prm, h->crc, (uint32_t*)h->cks.p);
     }
     // simple modes: beside the histograms and the planner, which are short chains of latency (config #4: 0.15 of 1.2 ms in line)
-    if (container != 0 && mode < 4 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
+    if (container != 0 && mode < 4 && !h->knobs.simple_ck_inline && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
         HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // the parse kernels OR / store the anchors in
@@ -1917,15 +1919,26 @@ int flate_hip_decompress_batch(flate_hip_handle h, const uint8_t* in, const uint
         sub = (n_chunks + nsub - 1) / nsub;
     }
     size_t pass_index = 0;
-    for (uint32_t c0 = 0; c0 < n_chunks; c0 += sub, pass_index++) {
-        const uint32_t nc = std::min(sub, n_chunks - c0);
-        if (pin_io) {  // this sub-batch's input: in flight while the previous sub-batch is decoded
+    if (pin_io) {
+        // Every sub-batch's input copy is submitted BEFORE any output copy: an output copy waits for its sub-batch's kernels,
+        // and an input copy submitted behind it can land in the same in-order DMA queue and wait with it -- then nothing
+        // overlaps (round 5, profiles/r05_host_path.txt: what happened to the compress path's rectangle copy).
+        size_t k = 0;
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += sub, k++) {
+            const uint32_t nc = std::min(sub, n_chunks - c0);
             hipEvent_t ev_in;
-            if ((rc = xfer_event(h, 2 * pass_index, &ev_in))) return rc;
+            if ((rc = xfer_event(h, 2 * k, &ev_in))) return rc;
             const uint64_t a = hin[c0], b = hin[c0 + nc];
             if (b > a)
                 HIP_OK(h, hipMemcpyAsync((uint8_t*)h->st_in.p + (a - in_lo), in + a, b - a, hipMemcpyHostToDevice, h->s_in));
             HIP_OK(h, hipEventRecord(ev_in, h->s_in));
+        }
+    }
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += sub, pass_index++) {
+        const uint32_t nc = std::min(sub, n_chunks - c0);
+        if (pin_io) {  // this sub-batch's input: it came in while the sub-batches before it were decoded
+            hipEvent_t ev_in;
+            if ((rc = xfer_event(h, 2 * pass_index, &ev_in))) return rc;
             HIP_OK(h, hipStreamWaitEvent(st, ev_in, 0));
         }
         const fl_chunk* dch = (const fl_chunk*)h->chunks.p + c0;

@@ -271,6 +271,19 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #else
 #error PZ_SEG_AS: 17, 24, 32 or 48
 #endif
+// ... and sub-pass B of a window (16122 targets)
+#ifndef PZ_SEG_BS
+#define PZ_SEG_BS 32u
+#endif
+#if PZ_SEG_BS == 32
+#define PZ_SEG_BS_OF(D) ((D) >> 5)
+#elif PZ_SEG_BS == 24
+#define PZ_SEG_BS_OF(D) (((D) * 43691u) >> 20)
+#elif PZ_SEG_BS == 16
+#define PZ_SEG_BS_OF(D) ((D) >> 4)
+#else
+#error PZ_SEG_BS: 16, 24 or 32
+#endif
 
 // tuning counters (compiled in with -DPZ_PROF; read with tools/parse_probe.py): per wave, summed over the grid
 #ifdef PZ_PROF
@@ -397,10 +410,10 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
         // (STREAM: small segments when the sub-pass's targets leave a lane for each; a stream's first window starts at 0)
         const bool small = STREAM && !sub && min(t_last, (uint32_t)PZ_TA) - t_first <= PZ_THREADS * PZ_SEG_AS;
-        const uint32_t S = sub ? PZ_SEG_B : (small ? PZ_SEG_AS : PZ_SEG_A);
+        const uint32_t S = sub ? (STREAM ? PZ_SEG_BS : PZ_SEG_B) : (small ? PZ_SEG_AS : PZ_SEG_A);
         // segment of a relative target position x - t0r (< 65536): a shift, or a multiplication by 1 / 48
         // (43691 / 2^21 = 1 / 47.99997: exact for arguments below 2^16)
-#define PZ_SEG_OF(D) (sub ? ((D) >> 5) : (small ? PZ_SEG_AS_OF(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21))))
+#define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : ((D) >> 5)) : (small ? PZ_SEG_AS_OF(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21))))
         const uint32_t nseg = PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;

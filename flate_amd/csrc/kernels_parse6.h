@@ -59,7 +59,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse6(cons
     __shared__ uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
     __shared__ uint16_t tMark[PZ_THREADS];    // segment is on the path
     __shared__ uint32_t sh_next_entry;
-    constexpr bool small = false;  // (PZ_SEG_OF of kernels_parse.h asks: small segments are the whole-stream path's, k_lz_parse<true>)
+    constexpr bool small = false, STREAM = false;  // (PZ_SEG_OF of kernels_parse.h asks: other segment sizes are the whole-stream path's, k_lz_parse<true>)
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
