@@ -969,7 +969,9 @@ __device__ __forceinline__ uint32_t fl_win_byte(const uint32_t* win32, uint32_t 
 // k_lz_emit (kernels_parse.h) handles a chunk in parts of 8192 positions; wave w owns positions
 // [h0 + 512 w, h0 + 512 (w + 1)) of a part.  (k_lz_tok -- parse and emit of the round-2 chunk path in one kernel over the
 // records of k_lz_match -- went with round 4: levels 8 and 9 take kernels_walk.h.)
+#ifndef FL_TOK_PART
 #define FL_TOK_PART 8192u
+#endif
 #define FL_TOK_SPAN (FL_TOK_PART / 16u)  // positions per wave per part
 #define FL_TOK_R (FL_TOK_SPAN / 64u)     // positions per lane per part
 #define FL_TOK_LOOK 256u                 // literals of an anchor may reach this far past its part (j < 256)

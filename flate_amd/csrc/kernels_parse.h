@@ -65,6 +65,9 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 #ifndef FL_CHAIN_WAVES
 #define FL_CHAIN_WAVES 8
 #endif
+#ifndef FL_CHAIN_TB
+#define FL_CHAIN_TB 1  // blocks per wave and turn
+#endif
 __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ prev_all,
@@ -126,66 +129,84 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
     __syncthreads();
     // block b = chunk bytes [1024 b, 1024 b + 1024) plus what its last position needs: granules
     // 64 b .. 64 b + 65 (sh + 1023 + 3 < 1056 = 66 granules); lane l loads granule 64 b + l, lanes 0..1 two more
-    auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {
+    auto load_block = [&](uint32_t b, uint4& g0, uint4& g1) {  // (granules beyond the chunk: zeros)
         const uint32_t ga = 64 * b + lane, gb = 64 * b + 64 + lane;
         g0 = ga < n_gran ? src16[ga] : make_uint4(0, 0, 0, 0);
         g1 = (lane < 2 && gb < n_gran) ? src16[gb] : make_uint4(0, 0, 0, 0);
     };
     const uint32_t n_blocks = (Mpos + 1023) >> 10;
-    uint4 ga0, ga1;  // the wave's next block, in flight
-    load_block(wave, ga0, ga1);
     bool overtaken = false;
-    for (uint32_t b0 = 0; b0 < n_blocks; b0 += FL_CHAIN_WAVES) {  // (uniform trip count: every wave meets every barrier)
-        const uint32_t b = b0 + wave;
-        ((uint4*)sb)[lane] = ga0;
-        if (lane < 2) ((uint4*)sb)[64 + lane] = ga1;
-        if (b + FL_CHAIN_WAVES < n_blocks) load_block(b + FL_CHAIN_WAVES, ga0, ga1);
-        fl_lds_order();
-        // the 16 x 64 hashes of the block
-        uint32_t hw[16];   // word of the table, or the lane's dummy word for a position past the end
-        uint32_t odd = 0;  // bit s: the hash of step s is odd (its head is the upper half of the word)
-        uint32_t val = 0;  // bit s: position of step s exists
+    // FL_CHAIN_TB consecutive blocks per wave and turn (round 5): a turn is mostly its barrier and the wait for the exchanges to
+    // drain, whatever their number -- with two blocks per turn a chunk has 32 turns instead of 64.
+    uint4 ga0[FL_CHAIN_TB], ga1[FL_CHAIN_TB];  // the wave's next blocks, in flight
 #pragma unroll
-        for (uint32_t s = 0; s < 16; s++) {
-            const uint32_t p = (b << 10) + (s << 6) + lane;
-            const uint32_t off = (s << 6) + lane + sh;
-            const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
-            const uint32_t h = fl_hash_le(v);
-            const bool valid = p < Mpos;
-            odd |= (h & 1u) << s;
-            val |= (valid ? 1u : 0u) << s;
-            hw[s] = valid ? (h >> 1) : 16384u + lane;
+    for (uint32_t u = 0; u < FL_CHAIN_TB; u++) load_block(FL_CHAIN_TB * wave + u, ga0[u], ga1[u]);
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += FL_CHAIN_TB * FL_CHAIN_WAVES) {  // (uniform trip count: every wave meets every barrier)
+        const uint32_t bw = b0 + FL_CHAIN_TB * wave;  // this wave's first block of the turn
+        uint32_t hw[16 * FL_CHAIN_TB];   // word of the table, or the lane's dummy word for a position past the end
+        uint32_t odd[FL_CHAIN_TB], val[FL_CHAIN_TB];  // bit s: the hash of step s is odd (its head is the upper half of the word); the position exists
+#pragma unroll
+        for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
+            const uint32_t b = bw + u;
+            ((uint4*)sb)[lane] = ga0[u];
+            if (lane < 2) ((uint4*)sb)[64 + lane] = ga1[u];
+            load_block(b + FL_CHAIN_TB * FL_CHAIN_WAVES, ga0[u], ga1[u]);  // (nothing beyond the chunk: load_block clamps)
+            fl_lds_order();
+            odd[u] = 0;
+            val[u] = 0;
+#pragma unroll
+            for (uint32_t s = 0; s < 16; s++) {
+                const uint32_t p = (b << 10) + (s << 6) + lane;
+                const uint32_t off = (s << 6) + lane + sh;
+                const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
+                const uint32_t h = fl_hash_le(v);
+                const bool valid = p < Mpos;
+                odd[u] |= (h & 1u) << s;
+                val[u] |= (valid ? 1u : 0u) << s;
+                hw[16 * u + s] = valid ? (h >> 1) : 16384u + lane;
+            }
+            fl_lds_order();  // (the staging buffer is written again for the next block)
         }
-        uint32_t old[16];
+        uint32_t old[16 * FL_CHAIN_TB];
 #pragma unroll 1
         for (uint32_t t = 0; t < FL_CHAIN_WAVES; t++) {
             if (t == wave) {
                 // all exchanges are issued before the first result is looked at (no branch around the instruction)
 #pragma unroll
-                for (uint32_t s = 0; s < 16; s++) {
-                    const uint32_t p = (b << 10) + (s << 6) + lane;
-                    const uint32_t hs = ((odd >> s) & 1u) << 4;
-                    const bool valid = (val >> s) & 1u;
-                    old[s] = fl_lds_mskor_rtn(&head32[hw[s]], valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+                for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
+#pragma unroll
+                    for (uint32_t s = 0; s < 16; s++) {
+                        const uint32_t p = ((bw + u) << 10) + (s << 6) + lane;
+                        const uint32_t hs = ((odd[u] >> s) & 1u) << 4;
+                        const bool valid = (val[u] >> s) & 1u;
+                        old[16 * u + s] = fl_lds_mskor_rtn(&head32[hw[16 * u + s]], valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
+                    }
                 }
                 // the results exist from here on (listed as operands so that no use of them is scheduled above the wait)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]),
-                               "+v"(old[6]), "+v"(old[7]), "+v"(old[8]), "+v"(old[9]), "+v"(old[10]), "+v"(old[11]),
-                               "+v"(old[12]), "+v"(old[13]), "+v"(old[14]), "+v"(old[15])
-                             :
-                             : "memory");
+#pragma unroll
+                for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
+                    uint32_t* o = old + 16 * u;
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]),
+                                   "+v"(o[6]), "+v"(o[7]), "+v"(o[8]), "+v"(o[9]), "+v"(o[10]), "+v"(o[11]),
+                                   "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15])
+                                 :
+                                 : "memory");
+                }
             }
             __syncthreads();
         }
         // the links: the half of the returned word this position's hash selects
 #pragma unroll
-        for (uint32_t s = 0; s < 16; s++) {
-            const uint32_t p = (b << 10) + (s << 6) + lane;
-            if ((val >> s) & 1u) {
-                const uint32_t o = ((odd >> s) & 1u) ? (old[s] >> 16) : (old[s] & 0xffffu);
-                overtaken = overtaken || o > p;
-                pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
+        for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
+#pragma unroll
+            for (uint32_t s = 0; s < 16; s++) {
+                const uint32_t p = ((bw + u) << 10) + (s << 6) + lane;
+                if ((val[u] >> s) & 1u) {
+                    const uint32_t o = ((odd[u] >> s) & 1u) ? (old[16 * u + s] >> 16) : (old[16 * u + s] & 0xffffu);
+                    overtaken = overtaken || o > p;
+                    pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
+                }
             }
         }
     }
@@ -399,6 +420,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         return;
     }
 #ifdef PZ_PROF
+    uint64_t c_tb_le2 = 0, c_tb_le8 = 0, c_tb_le24 = 0, c_tb_more = 0, c_nb_le2 = 0;
     uint32_t c_fast = 0, c_walk = 0, c_slow = 0, c_meas = 0, c_measl = 0, c_trans = 0, c_transl = 0, c_rounds = 0, c_loops = 0;
     uint64_t c_t0 = __builtin_readcyclecounter(), c_tspec = 0, c_tstitch = 0, c_tfast = 0, c_tmeas = 0, c_ttrans = 0, c_tstage = 0, c_tjump = 0;
 #endif
@@ -710,6 +732,10 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                     if (mw == 0 || __popcll(serve & ~mw) >= PZ_NEED) break;
                     PZ_CNT(c_fast, 1);
                     PZ_CNT(c_walk, __popcll(mw));
+#ifdef PZ_PROF
+                    const uint64_t c_tb0 = __builtin_readcyclecounter();
+                    const uint32_t c_nw = (uint32_t)__popcll(mw);
+#endif
                     if (cnt != 0) {
                         // PZ_UNROLL steps written out by hand.  Per step and wave the serial chain is: the link of the
                         // candidate arrives -> its LDS address -> the load of ITS link; the candidate itself is judged
@@ -919,6 +945,13 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             cnt = 0;
                         }
                     }
+#ifdef PZ_PROF
+                    {
+                        const uint64_t dtb = __builtin_readcyclecounter() - c_tb0;
+                        if (c_nw <= 2) c_tb_le2 += dtb; else if (c_nw <= 8) c_tb_le8 += dtb; else if (c_nw <= 24) c_tb_le24 += dtb; else c_tb_more += dtb;
+                        if (c_nw <= 2) c_nb_le2++;
+                    }
+#endif
                 }
                 // ---- slow block: lanes that are not walking
 #ifdef PZ_PROF
@@ -1089,7 +1122,6 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         __syncthreads();
         carry = sh_exit - FL_MAX_DIST;  // (a window that is not the stream's last is left at or beyond 65274)
     }
-    }  // windows
 #ifdef PZ_PROF
     if ((tid & 63) == 0) {
         // (c_meas / c_trans are per-lane counters of lane 0's view: only the wave-uniform ones are exact)
@@ -1110,9 +1142,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         atomicAdd((unsigned long long*)&g_fl_prof[54], (unsigned long long)c_trans);
         atomicAdd((unsigned long long*)&g_fl_prof[55], (unsigned long long)c_tstage);
         atomicAdd((unsigned long long*)&g_fl_prof[56], (unsigned long long)c_tjump);
+        atomicAdd((unsigned long long*)&g_fl_prof[58], (unsigned long long)c_tb_le2);
+        atomicAdd((unsigned long long*)&g_fl_prof[59], (unsigned long long)c_tb_le8);
+        atomicAdd((unsigned long long*)&g_fl_prof[60], (unsigned long long)c_tb_le24);
+        atomicAdd((unsigned long long*)&g_fl_prof[61], (unsigned long long)c_tb_more);
+        atomicAdd((unsigned long long*)&g_fl_prof[62], (unsigned long long)c_nb_le2);
     }
     (void)c_meas; (void)c_trans; (void)c_transl;
 #endif
+    }  // windows
 }
 
 // ------------------------------------------------------------------ k_lz_emit
@@ -1159,7 +1197,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     if (tid == 0) v1_sh = N;
     uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
     uint32_t tw_next = 0;  // the wave's 16 words of anchor bits of the next part
-    if (lane < 16 && wave * FL_TOK_SPAN + 32 * lane < min((uint32_t)FL_TOK_PART, N)) tw_next = trueg[((wave * FL_TOK_SPAN) >> 5) + lane];
+    if (lane < FL_TOK_SPAN / 32u && wave * FL_TOK_SPAN + 32 * lane < min((uint32_t)FL_TOK_PART, N)) tw_next = trueg[((wave * FL_TOK_SPAN) >> 5) + lane];
     for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
         const uint32_t h1 = min(h0 + FL_TOK_PART, N);
         const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
@@ -1169,7 +1207,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
         {
             const uint32_t h0n = h0 + FL_TOK_PART, h1n = min(h0n + FL_TOK_PART, N), s0n = h0n + wave * FL_TOK_SPAN;
             tw_next = 0;
-            if (h0n < N && lane < 16 && s0n + 32 * lane < h1n) tw_next = trueg[(s0n >> 5) + lane];
+            if (h0n < N && lane < FL_TOK_SPAN / 32u && s0n + 32 * lane < h1n) tw_next = trueg[(s0n >> 5) + lane];
         }
         uint32_t na = 0;  // anchors of the span (wave-uniform)
 #pragma unroll

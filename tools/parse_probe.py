@@ -34,3 +34,4 @@ print("per wave cycles: fast loop %.0f, slow block %.0f (of which measure part, 
 print("lane 0 of each wave: measure iterations %.1f, transitions %.1f per wave" % (t[53] / nw, t[54] / nw))
 print("per wave cycles: staging (incl. barrier) %.0f, path following incl. the wait for the slowest wave %.0f" % (t[55] / nw, t[56] / nw))
 print("per wave cycles (k_lz_parse6 only): phase A %.0f" % (t[57] / nw))
+print("per wave cycles in bursts by lanes walking when the burst starts: <= 2 lanes %.0f (%.0f bursts), 3-8 %.0f, 9-24 %.0f, more %.0f" % (t[58] / nw, t[62] / nw, t[59] / nw, t[60] / nw, t[61] / nw))
