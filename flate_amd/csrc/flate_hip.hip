@@ -97,6 +97,7 @@ struct fl_knobs {
     int span_twin = -1;                   // FLATE_HIP_SPAN_TWIN: -1 unset, 0 never, 2..950 where to cut
     bool no_pin_mirror = false;           // FLATE_HIP_NO_PIN_MIRROR
     bool no_ramp = false;                 // FLATE_HIP_NO_RAMP
+    uint32_t stream_group = 0;            // FLATE_HIP_STREAM_GROUP: windows per group of the whole-stream path (0: by the number of streams; tuning / tests)
     int stream_windows = -1;              // FLATE_HIP_STREAM_WINDOWS: -1 unset (by estimate), 0 never, 1 whenever possible (kernels_parse.h, k_lz_parse<true>)
     bool simple_ck_inline = false;        // FLATE_HIP_SIMPLE_CK_INLINE: the simple modes' checksum on the compute stream (round 4's way)
     int rect = -1;                        // FLATE_HIP_RECT: 1 = half of every slot goes home by the DMA engine's rectangle copy (off by default: see there)
@@ -114,6 +115,7 @@ struct flate_hip_ctx {
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
+    DevBuf wexit;  // per window and sub-pass: where the path left it; per group: its exit, its entry; a flag (kernels_parse.h, fix launch)
     DevBuf wchunks, swins;  // whole-stream passes on k_lz_parse<true>: the streams' windows as chunks, a table entry per stream
     DevBuf l6, bnd, ent;  // k_lz_parse6: the chain on six bytes, the budget bounds, phase A's entries (kernels_parse6.h)
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
@@ -276,6 +278,7 @@ void read_knobs(fl_knobs& k, uint64_t span_default) {
     if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
     k.simple_ck_inline = getenv("FLATE_HIP_SIMPLE_CK_INLINE") != nullptr;
     if ((e = getenv("FLATE_HIP_STREAM_WINDOWS"))) k.stream_windows = atoi(e) != 0;
+    if ((e = getenv("FLATE_HIP_STREAM_GROUP")) && atoi(e) > 0) k.stream_group = (uint32_t)atoi(e);
     if ((e = getenv("FLATE_HIP_INFLATE_PAR"))) k.inflate_par = atoll(e);
     if ((e = getenv("FLATE_HIP_INFLATE_RING"))) k.inflate_ring = atoll(e);
 }
@@ -372,40 +375,72 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     bool windows = !t.any_flush && prm.chain < FL_BULK_MIN_CHAIN && h->knobs.stream_windows != 0 && nseg;
     std::vector<fl_chunk> wch;
     std::vector<fl_swin> sws;
+    bool grouped = false;  // some stream is split into groups of windows: a fix launch follows (kernels_parse.h)
     if (windows) {
-        uint64_t bytes = 0;
-        uint32_t max_win = 0;
+        if (h->n_cu == 0) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
+            h->n_cu = (uint32_t)v;
+        }
+        uint64_t bytes = 0, total_win = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            bytes += hch[i].in_len;
+            total_win += hch[i].n_slides + 1u;
+        }
+        // Many streams: a workgroup walks a whole stream (no guess, no fix).  Few: groups of G windows, about four groups per
+        // CU, at least four windows each (the fix launch parses one sub-pass per group again: an eighth of the work at G = 4).
+        uint32_t G = ~0u;
+        if (nc < h->n_cu) G = (uint32_t)std::max<uint64_t>(4, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
+        if (h->knobs.stream_group) G = h->knobs.stream_group;
         for (uint32_t i = 0; i < nc; i++) {
             const fl_chunk& c = hch[i];
-            fl_swin sw{i, (uint32_t)wch.size(), c.n_slides + 1u, 0u};
-            for (uint32_t j = 0; j <= c.n_slides; j++) {
+            const uint32_t nw = c.n_slides + 1u, w0 = (uint32_t)wch.size();
+            for (uint32_t j = 0; j < nw; j++) {
                 fl_chunk w{};
                 w.in_off = c.in_off + (uint64_t)FL_SEG * j;
                 w.in_len = (uint32_t)std::min<uint64_t>(65536u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j);
                 w.pad_ = 1u;  // (a window: k_lz_chain builds its chains whatever it holds)
                 wch.push_back(w);
             }
-            sws.push_back(sw);
-            bytes += c.in_len;
-            max_win = std::max(max_win, sw.nwin);
+            uint32_t prev = ~0u;
+            for (uint32_t j = 0; j < nw; j += G) {
+                fl_swin sw{};
+                sw.chunk = i;
+                sw.win0 = w0 + j;
+                sw.nwin = std::min(G, nw - j);
+                sw.wfirst = j;
+                sw.prev = prev;
+                prev = (uint32_t)sws.size();
+                if (j) grouped = true;
+                sws.push_back(sw);
+                if (G == ~0u) break;
+            }
         }
-        if (h->n_cu == 0) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || v <= 0) v = 256;
-            h->n_cu = (uint32_t)v;
-        }
-        const double est_new = (double)((nc + h->n_cu - 1) / h->n_cu) * max_win * 0.28, est_old = (double)bytes / 1048576.0 * 0.061;
+        const uint32_t ng = (uint32_t)sws.size();
+        const uint32_t gmax = G == ~0u ? (uint32_t)0 : G;
+        uint32_t max_win = 0;
+        for (const fl_swin& sw : sws) max_win = std::max(max_win, sw.nwin);
+        (void)gmax;
+        // a window costs a workgroup about 0.28 ms; sort / match cost about 0.061 ms per MiB on all CUs (and about a millisecond
+        // of kernel latencies whatever the size)
+        const double est_new = (double)((ng + h->n_cu - 1) / h->n_cu) * max_win * 0.28 + (grouped ? 0.5 : 0.0);
+        const double est_old = (double)bytes / 1048576.0 * 0.061 + 1.0;
         if (h->knobs.stream_windows < 0 && est_new >= est_old) windows = false;
         if (wch.size() > tile_limit) windows = false;  // (the chain links of all windows at once: 128 KiB each)
     }
     if (windows) {
-        const uint32_t nw = (uint32_t)wch.size();
+        const uint32_t nw = (uint32_t)wch.size(), ng = (uint32_t)sws.size();
         if ((rc = ensure(h, h->wchunks, sizeof(fl_chunk) * nw))) return rc;
-        if ((rc = ensure(h, h->swins, sizeof(fl_swin) * nc))) return rc;
+        if ((rc = ensure(h, h->swins, sizeof(fl_swin) * ng))) return rc;
         if ((rc = ensure(h, h->S, (size_t)nw * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
         if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nw))) return rc;
+        if ((rc = ensure(h, h->wexit, sizeof(uint32_t) * (2 * (size_t)nw + 2 * (size_t)ng + 4)))) return rc;
+        uint32_t* d_wexit = (uint32_t*)h->wexit.p;
+        uint32_t* d_gexit = d_wexit + 2 * (size_t)nw;
+        uint32_t* d_gentry = d_gexit + ng;
+        uint32_t* d_dirty = d_gentry + ng;
         HIP_OK(h, hipMemcpyAsync(h->wchunks.p, wch.data(), sizeof(fl_chunk) * nw, hipMemcpyHostToDevice, st));
-        HIP_OK(h, hipMemcpyAsync(h->swins.p, sws.data(), sizeof(fl_swin) * nc, hipMemcpyHostToDevice, st));
+        HIP_OK(h, hipMemcpyAsync(h->swins.p, sws.data(), sizeof(fl_swin) * ng, hipMemcpyHostToDevice, st));
         HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
         {
             ProfScope ps(h, K_LZ_CHAIN);
@@ -414,9 +449,25 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         }
         {
             ProfScope ps(h, K_LZ_PARSE);
-            hipLaunchKernelGGL(k_lz_parse<true>, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
+            hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
                                (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
-                               (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p);
+                               (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, 0u);
+        }
+        // the groups that were parsed from a guess: again from where the group before them leaves, until nothing moves any more
+        // (one launch in practice: a parse falls in step within a few bytes; the loop is what makes it exact)
+        for (uint32_t it = 0; grouped; it++) {
+            HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
+            {
+                ProfScope ps(h, K_LZ_PARSE);
+                hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
+                                   (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
+                                   (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, 1u);
+            }
+            uint32_t flag = 0;
+            HIP_OK(h, hipMemcpyAsync(&flag, d_dirty, sizeof flag, hipMemcpyDeviceToHost, st));
+            HIP_OK(h, hipStreamSynchronize(st));
+            if (!flag) break;
+            if (it > ng) return FLATE_HIP_E_LAUNCH;  // (cannot happen: every launch settles at least one more group)
         }
         {
             ProfScope ps(h, K_ST_PARSE);
@@ -744,7 +795,8 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 ProfScope ps(h, K_LZ_PARSE);
                 hipLaunchKernelGGL(k_lz_parse<false>, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
-                                   (const fl_swin*)nullptr, (const fl_chunk*)nullptr, (const uint32_t*)nullptr);
+                                   (const fl_swin*)nullptr, (const fl_chunk*)nullptr, (const uint32_t*)nullptr,
+                                   (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
             }
             }
         }
@@ -1200,7 +1252,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->wchunks, &h->swins, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->wchunks, &h->swins, &h->wexit, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})

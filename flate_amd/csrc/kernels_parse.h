@@ -326,11 +326,20 @@ __device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off)
 // order (`swins`), the anchor the path leaves a window at is where it enters the next.  Chains: k_lz_chain on the windows as
 // chunks (`chunks` holds one fl_chunk per WINDOW then, `schunks` the streams).  Descriptors and anchor bits go to the stream's
 // arrays at absolute positions, a literal's descriptor is 0 there (k_st_emit, kernels_stream.h).
+// A workgroup's share is a GROUP of consecutive windows of one stream: the whole stream when the streams are many, a part of it
+// when they are few.  A group that is not its stream's first does not know where the path enters its first window: it is parsed
+// from a guess (the window's first target -- the speculation of the segments, one level up), every sub-pass leaves its exit in
+// `wexit`, the group its own in `gexit`; a second launch (fix = 1) parses from the TRUE entry -- the exit of the group before --
+// until a sub-pass leaves where it left before: from there on the anchors of the first launch stand (a parse from any entry
+// falls in step with the true one within a few bytes, so this is the first sub-pass of the group's first window).  A group that
+// had to be parsed to its end with a new exit sets `dirty`: the host launches the fix again (never seen).
 struct fl_swin {
     uint32_t chunk;   // the stream (index into schunks)
-    uint32_t win0;    // its first window (index into chunks / the chain links)
-    uint32_t nwin;    // windows: slides + 1
-    uint32_t pad_;
+    uint32_t win0;    // the group's first window (index into chunks / the chain links)
+    uint32_t nwin;    // windows in the group
+    uint32_t wfirst;  // number of the group's first window in its stream
+    uint32_t prev;    // the group before it in the stream (index into swins), ~0u: the stream's first
+    uint32_t pad_[3];
 };
 template <bool STREAM>
 __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const uint8_t* __restrict__ in,
@@ -341,7 +350,9 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                                            uint32_t* __restrict__ true_all,
                                                            const fl_swin* __restrict__ swins,
                                                            const fl_chunk* __restrict__ schunks,
-                                                           const uint32_t* __restrict__ zones) {
+                                                           const uint32_t* __restrict__ zones,
+                                                           uint32_t* gexit, uint32_t* gentry, uint32_t* wexit,
+                                                           uint32_t* dirty, uint32_t fix) {
     __shared__ uint32_t win32[PZ_WIN_DW];
     __shared__ uint16_t prv[PZ_PRV_N];
     __shared__ uint16_t tX[PZ_THREADS];       // exit of a lane's own parse, as soon as it is known
@@ -359,14 +370,32 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     sw.chunk = 0;
     sw.win0 = blockIdx.x;
     sw.nwin = 1;
+    sw.wfirst = 0;
+    sw.prev = ~0u;
     fl_chunk sck = chunks[0];
+    uint32_t carry = 0;  // STREAM: the anchor at which the path enters the window (window-relative)
+    bool guessed = false;
     if (STREAM) {
         sw = swins[blockIdx.x];
         sck = schunks[sw.chunk];
         if (sck.skip) return;
+        if (sw.prev != ~0u) {
+            if (fix) {
+                // the true entry: where the group before leaves (absolute stream position)
+                const uint32_t e = __hip_atomic_load(&gexit[sw.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e == gentry[blockIdx.x]) return;  // parsed from there already
+                __syncthreads();                      // (every thread has read the old entry)
+                if (tid == 0) gentry[blockIdx.x] = e;
+                carry = e - FL_MAX_DIST * sw.wfirst;
+            } else {
+                guessed = true;  // (the first window's first target: set below)
+            }
+        } else if (fix) {
+            return;  // a stream's first group starts at the stream's start
+        }
     }
-    uint32_t carry = 0;  // STREAM: the anchor at which the path enters the window (window-relative)
     for (uint32_t wi = 0; wi < sw.nwin; wi++) {
+    const uint32_t ws = sw.wfirst + wi;  // STREAM: the window's number in its stream
     const uint32_t c = sw.win0 + wi;
     const fl_chunk ck = chunks[c];
     if (!STREAM && ck.skip) return;
@@ -374,17 +403,24 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
     const uint8_t* src = in + ck.in_off;
     const uint16_t* pvg = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
-    const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * wi : ck.pos_off;
+    const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * ws : ck.pos_off;
     uint32_t* descg = desc_all + pos_off;
     uint32_t* trueg = true_all + (pos_off >> 5);
     // the window's targets [t_first, t_last)
     uint32_t t_first = 0, t_last = N;
     if (STREAM) {
         const uint32_t* zone = zones + sck.zone_off;
-        if (wi) t_first = zone[wi - 1] - FL_MAX_DIST * wi;
-        if (wi + 1 < sw.nwin) t_last = zone[wi] - FL_MAX_DIST * wi;
+        if (ws) t_first = zone[ws - 1] - FL_MAX_DIST * ws;
+        if (ws < sck.n_slides) t_last = zone[ws] - FL_MAX_DIST * ws;
         if (wi) __syncthreads();  // the window before is done with the LDS tables
-        if (t_first >= t_last) continue;
+        if (guessed && wi == 0) {
+            carry = t_first;
+            if (tid == 0) gentry[blockIdx.x] = t_first + FL_MAX_DIST * ws;
+        }
+        if (t_first >= t_last) {
+            if (tid == 0) wexit[2 * c] = wexit[2 * c + 1] = ~0u;
+            continue;
+        }
     }
     if (cflag[c] == 1u) {
         // The chunk is one repeated byte (k_lz_chain saw it and built no chains).  Positions 0 and 1 are
@@ -428,7 +464,22 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     for (uint32_t sub = 0; sub < 2; sub++) {
         const uint32_t t0 = sub ? max(PZ_TA, t_first) : t_first;
         const uint32_t end = min(t_last, sub ? 65536u : PZ_TA);  // targets [t0, end)
-        if (t0 >= end) break;  // (a window's first target lies below PZ_TA: sub-pass B never runs without A's staging)
+        if (t0 >= end) {  // (a window's first target lies below PZ_TA: sub-pass B never runs without A's staging)
+            if (STREAM && tid == 0) wexit[2 * c + sub] = ~0u;
+            break;
+        }
+        if (STREAM && fix) {
+            // the anchors the first launch left in this sub-pass's targets go: bit by bit at the ends (the words there are
+            // shared with the sub-passes next to it, which other workgroups may be writing), whole words in between
+            const uint64_t b0 = pos_off + t0, b1 = pos_off + end;  // absolute bits [b0, b1)
+            for (uint64_t w = (b0 >> 5) + tid; w <= ((b1 - 1) >> 5); w += PZ_THREADS) {
+                uint32_t keep = 0;
+                if (w == (b0 >> 5) && (b0 & 31)) keep |= (1u << (b0 & 31)) - 1u;
+                if (w == ((b1 - 1) >> 5) && (b1 & 31)) keep |= ~((1u << (b1 & 31)) - 1u);
+                if (keep) atomicAnd(&true_all[w], keep); else true_all[w] = 0u;
+            }
+            __threadfence();
+        }
         const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
         // (STREAM: small segments when the sub-pass's targets leave a lane for each; a stream's first window starts at 0)
         const bool small = STREAM && !sub && min(t_last, (uint32_t)PZ_TA) - t_first <= PZ_THREADS * PZ_SEG_AS;
@@ -439,6 +490,11 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t nseg = PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
+        // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
+        // last anchor gets there): the reference has dropped every candidate at or below the next window's start by then
+        // (Lookup.zig:43-51) -- relative to this window: at or below 32768
+        const uint32_t zt = (STREAM && ws < sck.n_slides) ? t_last - r0 : ~0u;
+        const uint32_t zlo = FL_MAX_DIST + 1u > r0 ? FL_MAX_DIST + 1u - r0 : 1u;
         if (sub) __syncthreads();  // the previous sub-pass is done with the LDS tables
         // ---- stage window bytes and chain links (loads in batches: one round of memory latency per batch)
 #ifdef PZ_PROF
@@ -576,6 +632,13 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                 sh_exit = y0 + r0;
                 sh_next_entry = sub ? y0 : y0 - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);  // (y0 >= 49152 - 16320 here)
             }
+            if (STREAM) {
+                __syncthreads();
+                const uint32_t was = wexit[2 * c + sub];
+                __syncthreads();
+                if (tid == 0) wexit[2 * c + sub] = sh_exit;
+                if (fix && was == sh_exit) return;  // from here on the first launch's anchors stand
+            }
             continue;
         }
         const uint32_t me = PZ_SEG_OF(y0 - t0r);
@@ -692,6 +755,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         maxlen = min(Nr - p, (uint32_t)FL_MAX_MATCH);                          \
         q = prv[p];                                                            \
         lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
+        if (STREAM && p >= zt) lo = max(lo, zlo);                              \
         cnt = (maxlen > best && q >= lo) ? (BUDGET) : 0u;                      \
         PZ_SET_FILTER(best ? best - 3u : 0u);                                  \
     } while (0)
@@ -1117,10 +1181,23 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             sh_exit = sh_next_entry + r0;
             if (sub == 0) sh_next_entry = sh_next_entry - (PZ_TA - FL_MAX_DIST - PZ_MARGIN);
         }
+        if (STREAM) {
+            __syncthreads();
+            const uint32_t was = wexit[2 * c + sub];
+            __syncthreads();
+            if (tid == 0) wexit[2 * c + sub] = sh_exit;
+            if (fix && was == sh_exit) return;  // from here on the first launch's anchors stand
+        }
     }
     if (STREAM) {
         __syncthreads();
         carry = sh_exit - FL_MAX_DIST;  // (a window that is not the stream's last is left at or beyond 65274)
+        if (wi + 1 == sw.nwin && tid == 0) {
+            // the group's exit; in a fix launch: a NEW one (no sub-pass left where it left before): the group behind has to be
+            // parsed again from it
+            __hip_atomic_store(&gexit[blockIdx.x], sh_exit + FL_MAX_DIST * ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fix) atomicOr(dirty, 1u);
+        }
     }
 #ifdef PZ_PROF
     if ((tid & 63) == 0) {

@@ -21,5 +21,9 @@ run(); torch.cuda.synchronize(); eng.profile_reset(); eng.profile_enable(True)
 for _ in range(3): run()
 torch.cuda.synchronize(); prof = eng.profile_read(); eng.profile_enable(False)
 tot = sum(v[0] for v in prof.values()) / 3
-print("%d streams of %d KiB, level %d: ratio %.3f  %.1f MB/s  %.2f ms" % (k, kib, level, float(ol.sum()) / n, n / tot / 1e3, tot))
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): run()
+torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 3 * 1e3
+print("%d streams of %d KiB, level %d: ratio %.3f  %.1f MB/s  %.2f ms of kernels, %.2f ms wall (%.1f MB/s)" % (k, kib, level, float(ol.sum()) / n, n / tot / 1e3, tot, wall, n / wall / 1e3))
 print("  ".join("%s %.2f" % (kk, v[0] / 3) for kk, v in sorted(prof.items(), key=lambda x: -x[1][0])))
