@@ -327,11 +327,11 @@ __global__ __launch_bounds__(FL_SORT_THREADS) void k_lz_sort(const uint8_t* __re
 
 __device__ __forceinline__ uint32_t fl_lds_load4(const uint32_t* win32, uint32_t off) {
     const uint32_t i = off >> 2;
-    return __builtin_amdgcn_alignbyte(win32[i + 1], win32[i], off & 3);
+    return __builtin_amdgcn_alignbyte(win32[i + 1], win32[i], off);  // (v_alignbyte_b32 shifts by the low two bits of its third operand)
 }
 // window bytes off..off+3 and off+4..off+7
 __device__ __forceinline__ void fl_lds_load8(const uint32_t* win32, uint32_t off, uint32_t& w0, uint32_t& w1) {
-    const uint32_t i = off >> 2, sh = off & 3;
+    const uint32_t i = off >> 2, sh = off;  // (v_alignbyte_b32 shifts by the low two bits)
     const uint32_t d0 = win32[i], d1 = win32[i + 1], d2 = win32[i + 2];
     w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
     w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);

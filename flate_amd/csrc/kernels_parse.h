@@ -253,6 +253,9 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #ifndef PZ_UNROLL
 #define PZ_UNROLL 20              // chain steps between two looks at the other lanes
 #endif
+#ifndef PZ_ROT
+#define PZ_ROT 3                 // the burst is PZ_ROT x 6 steps, registers rotating (0: the two-role burst of round 4, PZ_UNROLL steps)
+#endif
 #ifndef PZ_TRANS_ITERS
 #define PZ_TRANS_ITERS 1         // automaton moves per lane and slow block (runs of literals)
 #endif
@@ -309,8 +312,18 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 // tuning counters (compiled in with -DPZ_PROF; read with tools/parse_probe.py): per wave, summed over the grid
 #ifdef PZ_PROF
 #define PZ_CNT(var, v) (var) += (v)
+// an event of the slow block: c_ev[K] counts the waves that pass here (its first active lane counts), c_ev[K + 1] the lanes
+#define PZ_EV(K)                                                                                   \
+    do {                                                                                           \
+        c_ev[(K) + 1]++;                                                                           \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1))) c_ev[(K)]++;            \
+    } while (0)
+#elif defined(PZ_SEC)  // markers in the assembly listing: instructions per part of the slow block (tools/parse_sections.py)
+#define PZ_CNT(var, v)
+#define PZ_EV(K) asm volatile(";;PZSEC " #K)
 #else
 #define PZ_CNT(var, v)
+#define PZ_EV(K)
 #endif
 
 __device__ __forceinline__ uint32_t pz_lds4(const uint32_t* win32, uint32_t off) {
@@ -353,15 +366,29 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                                            const uint32_t* __restrict__ zones,
                                                            uint32_t* gexit, uint32_t* gentry, uint32_t* wexit,
                                                            uint32_t* dirty, uint32_t fix) {
-    __shared__ uint32_t win32[PZ_WIN_DW];
-    __shared__ uint16_t prv[PZ_PRV_N];
-    __shared__ uint16_t tX[PZ_THREADS];       // exit of a lane's own parse, as soon as it is known
-    __shared__ uint16_t tExg[PZ_THREADS];     // exit the path is assumed to take out of a segment
-    __shared__ uint16_t tNxt[2][PZ_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
-    __shared__ uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
-    __shared__ uint16_t tMark[PZ_THREADS];    // segment is on the path
-    __shared__ uint32_t sh_next_entry;
-    __shared__ uint32_t sh_exit;              // STREAM: where the path leaves the window (window-relative)
+    // One block of LDS in this order: the window at address 0 (a window byte's LDS address is its position: no base to add),
+    // the links behind it (their base, 49680, fits the offset field of the LDS instructions).
+    struct pz_lds {
+        uint32_t win32[PZ_WIN_DW];
+        uint16_t prv[PZ_PRV_N];
+        uint16_t tX[PZ_THREADS];       // exit of a lane's own parse, as soon as it is known
+        uint16_t tExg[PZ_THREADS];     // exit the path is assumed to take out of a segment
+        uint16_t tNxt[2][PZ_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
+        uint16_t tEnt[PZ_THREADS];     // position at which the path enters a segment
+        uint16_t tMark[PZ_THREADS];    // segment is on the path
+        uint32_t sh_next_entry;
+        uint32_t sh_exit;              // STREAM: where the path leaves the window (window-relative)
+    };
+    __shared__ pz_lds lds;
+    uint32_t (&win32)[PZ_WIN_DW] = lds.win32;
+    uint16_t (&prv)[PZ_PRV_N] = lds.prv;
+    uint16_t (&tX)[PZ_THREADS] = lds.tX;
+    uint16_t (&tExg)[PZ_THREADS] = lds.tExg;
+    uint16_t (&tNxt)[2][PZ_THREADS] = lds.tNxt;
+    uint16_t (&tEnt)[PZ_THREADS] = lds.tEnt;
+    uint16_t (&tMark)[PZ_THREADS] = lds.tMark;
+    uint32_t& sh_next_entry = lds.sh_next_entry;
+    uint32_t& sh_exit = lds.sh_exit;
     constexpr uint32_t LITD = STREAM ? 0u : PZ_DESC_LIT;  // descriptor of an anchor that emits one literal
     const uint32_t tid = threadIdx.x;
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
@@ -457,6 +484,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     }
 #ifdef PZ_PROF
     uint64_t c_tb_le2 = 0, c_tb_le8 = 0, c_tb_le24 = 0, c_tb_more = 0, c_nb_le2 = 0;
+    uint32_t c_ev[32] = {0};
     uint32_t c_fast = 0, c_walk = 0, c_slow = 0, c_meas = 0, c_measl = 0, c_trans = 0, c_transl = 0, c_rounds = 0, c_loops = 0;
     uint64_t c_t0 = __builtin_readcyclecounter(), c_tspec = 0, c_tstitch = 0, c_tfast = 0, c_tmeas = 0, c_ttrans = 0, c_tstage = 0, c_tjump = 0;
 #endif
@@ -938,6 +966,83 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             : "vcc", "scc", "memory", "v120", "v121", "v122", "v123");
                         (void)w0B;
                         (void)w1B;
+#elif PZ_ROT
+                        // Registers change roles instead of being copied: the candidate, its link and the link's link rotate
+                        // through q0, q1, q2 (period 3), the window dwords and byte addresses through the pairs a / b (period 2):
+                        // six steps written out.  A lane that leaves (exec bit cleared) keeps its registers as they were in
+                        // the step it left in: h0 / h1 / h2 remember in which role a hit found them; the budget counts down to
+                        // a borrow (cb = cnt - 1), one instruction for decrement and test.  7 VALU instructions a step
+                        // instead of 12.
+#ifdef PZ_PIPE  // experiment: the next link is asked for as soon as this one is there, the window dwords may still be on their way
+#define PZ_W1 "s_waitcnt lgkmcnt(2)\n\t"
+#define PZ_W2 "s_waitcnt lgkmcnt(3)\n\t"
+#define PZ_W3
+#else
+#define PZ_W1
+#define PZ_W2
+#define PZ_W3 "s_waitcnt lgkmcnt(0)\n\t"
+#endif
+#define PZ_RSTEP(QC, QN, QNN, WC0, WC1, WN0, WN1, XC, XN, H)                  \
+    PZ_W1                                                                      \
+    "v_lshl_add_u32 %[a1], %[" QN "], 1, %[prvb]\n\t"                          \
+    "ds_read_u16 %[" QNN "], %[a1]\n\t"                                        \
+    "v_add_u32 %[" XN "], %[" QN "], %[offb]\n\t"                              \
+    "v_and_b32 %[a2], -4, %[" XN "]\n\t"                                       \
+    "ds_read_b32 %[" WN0 "], %[a2]\n\t"                                        \
+    "ds_read_b32 %[" WN1 "], %[a2] offset:4\n\t"                               \
+    PZ_W2                                                                      \
+    "v_alignbyte_b32 %[t], %[" WC1 "], %[" WC0 "], %[" XC "]\n\t"              \
+    "v_cmp_eq_u32 vcc, %[t], %[pref]\n\t"                                      \
+    "s_and_b64 %[st], exec, vcc\n\t"                                           \
+    "s_or_b64 %[" H "], %[" H "], %[st]\n\t"                                   \
+    "s_andn2_b64 exec, exec, vcc\n\t"                                          \
+    "v_cmp_ge_u32 vcc, %[" QN "], %[lo]\n\t"                                   \
+    "v_sub_co_u32_e64 %[cb], %[st], %[cb], 1\n\t"                              \
+    "s_andn2_b64 vcc, vcc, %[st]\n\t"                                          \
+    "s_and_b64 exec, exec, vcc\n\t"                                            \
+    PZ_W3                                                                      \
+    "s_cbranch_execz .Lpz_done_%=\n\t"
+                        uint32_t q2r, xb, cb;
+                        uint64_t s_h0, s_h1, s_h2;
+                        asm volatile(
+                            "s_mov_b64 %[ssave], exec\n\t"
+                            "s_mov_b64 %[h0], 0\n\t"
+                            "s_mov_b64 %[h1], 0\n\t"
+                            "s_mov_b64 %[h2], 0\n\t"
+                            "v_add_u32 %[cb], -1, %[cnt]\n\t"
+                            ".rept " PZ_STR(PZ_ROT) "\n\t"
+                            PZ_RSTEP("q0", "q1", "q2", "wa0", "wa1", "wb0", "wb1", "xa", "xb", "h0")
+                            PZ_RSTEP("q1", "q2", "q0", "wb0", "wb1", "wa0", "wa1", "xb", "xa", "h1")
+                            PZ_RSTEP("q2", "q0", "q1", "wa0", "wa1", "wb0", "wb1", "xa", "xb", "h2")
+                            PZ_RSTEP("q0", "q1", "q2", "wb0", "wb1", "wa0", "wa1", "xb", "xa", "h0")
+                            PZ_RSTEP("q1", "q2", "q0", "wa0", "wa1", "wb0", "wb1", "xa", "xb", "h1")
+                            PZ_RSTEP("q2", "q0", "q1", "wb0", "wb1", "wa0", "wa1", "xb", "xa", "h2")
+                            ".endr\n\t"
+                            ".Lpz_done_%=:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_mov_b64 %[st], exec\n\t"
+                            "s_mov_b64 exec, %[ssave]\n\t"
+                            "v_add_u32 %[cnt], 1, %[cb]\n\t"
+                            "v_cndmask_b32_e64 %[qh], %[qh], %[q0], %[h0]\n\t"
+                            "v_cndmask_b32_e64 %[nqh], %[nqh], %[q1], %[h0]\n\t"
+                            "v_cndmask_b32_e64 %[qh], %[qh], %[q1], %[h1]\n\t"
+                            "v_cndmask_b32_e64 %[nqh], %[nqh], %[q2], %[h1]\n\t"
+                            "v_cndmask_b32_e64 %[qh], %[qh], %[q2], %[h2]\n\t"
+                            "v_cndmask_b32_e64 %[nqh], %[nqh], %[q0], %[h2]\n\t"
+                            "s_or_b64 %[shit], %[h0], %[h1]\n\t"
+                            "s_or_b64 %[shit], %[shit], %[h2]\n\t"
+                            : [q0] "+v"(q), [cnt] "+v"(cnt), [q1] "+v"(nqA), [wa0] "+v"(w0A), [wa1] "+v"(w1A), [xa] "+v"(xq),
+                              [qh] "+v"(qh), [nqh] "+v"(nqh), [q2] "=&v"(q2r), [wb0] "=&v"(w0B), [wb1] "=&v"(w1B), [xb] "=&v"(xb),
+                              [cb] "=&v"(cb), [a1] "=&v"(a1), [a2] "=&v"(a2), [t] "=&v"(t), [ssave] "=&s"(s_save),
+                              [st] "=&s"(s_t), [shit] "=&s"(s_hit), [h0] "=&s"(s_h0), [h1] "=&s"(s_h1), [h2] "=&s"(s_h2)
+                            : [lo] "v"(lo), [offb] "v"(offb), [pref] "v"(pref), [prvb] "s"(prv_lds)
+                            : "vcc", "scc", "memory");
+                        (void)nqB;
+                        (void)xn;
+#undef PZ_RSTEP
+#undef PZ_W1
+#undef PZ_W2
+#undef PZ_W3
 #else
                         asm volatile(
                             "s_mov_b64 %[ssave], exec\n\t"
@@ -1024,28 +1129,34 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #endif
                 PZ_CNT(c_slow, 1);
                 PZ_CNT(c_measl, __popcll(__ballot(st != ST_DONE && qh != PZ_NOHIT)));
+#ifdef PZ_TNEED
+                const uint32_t n_walk_before = (uint32_t)__popcll(__ballot(cnt != 0));
+#endif
                 if (st != ST_DONE && cnt == 0) {
+                    PZ_EV(0);
                     if (qh != PZ_NOHIT) {
+                        PZ_EV(2);
                         // the candidate agrees where it must: its exact common prefix with p
                         uint32_t l = 0;
+                        uint64_t x;
                         for (;;) {
+                            PZ_EV(4);
                             PZ_CNT(c_meas, 1);
                             uint32_t a0, a1, b0, b1;
                             fl_lds_load8(win32, p + l, a0, a1);
                             fl_lds_load8(win32, qh + l, b0, b1);
                             // (one 64-bit test: all six dwords are loaded together, one LDS round trip per 8 bytes -- with
                             // two tests the compiler loads the second half only after the first has compared equal)
-                            const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
-                            if (x) {
-                                l += (uint32_t)__builtin_ctzll(x) >> 3;
-                                break;
-                            }
+                            x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                            if (x || l + 8 >= maxlen) break;
                             l += 8;
-                            if (l >= maxlen) break;
                         }
-                        l = min(l, maxlen);
+                        // (the byte count of the last eight once, behind the loop, for all lanes together; eight equal bytes: ctz of 0
+                        // would be undefined, bit 63 of ~0 stands for "8")
+                        l = min(l + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u), maxlen);
                         cnt = q >= lo ? crem : 0u;            // the walk goes on behind the candidate ...
                         if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
+                            PZ_EV(6);
                             best = l;
                             bdist = p - qh;
                             if (l >= nice || l >= maxlen) {
@@ -1059,15 +1170,24 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #ifdef PZ_PROF
                     c_tmeas += __builtin_readcyclecounter() - c_tb;
 #endif
-                    if (cnt == 0) {
+#ifdef PZ_TNEED
+                    // experiment: the automaton's moves wait until PZ_TNEED lanes ask for one (or fewer than PZ_WMIN lanes walk)
+                    const bool doT = __popcll(__ballot(cnt == 0)) >= PZ_TNEED || n_walk_before + __popcll(__ballot(cnt != 0)) < PZ_WMIN;
+#else
+                    const bool doT = true;
+#endif
+                    if (cnt == 0 && doT) {
                         PZ_CNT(c_trans, 1);
+                        PZ_EV(8);
                         // one move per lane and visit; every path through it ends in at most one new call
                         bool start = false;
                         uint32_t sp = 0, sl = 0, sb = chain;
                         if (st == ST_WAIT) {
+                            PZ_EV(10);
                             // the lane before has finished its own parse: where does that leave this segment?
                             const uint32_t v = __hip_atomic_load(&tX[m - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (v != PZ_NONE) {
+                                PZ_EV(12);
                                 st = ST_DONE;
                                 if (v >= seg0 && v < seg_end) {
                                     y_in = v;
@@ -1089,15 +1209,19 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                         } else {
                             // the call has ended: the automaton's next move
                             bool emit = true;  // the pending match goes out (deflate.zig:182-184), or a literal
+                            PZ_EV(14);
                             if (bdist) {       // a match, longer than the pending one if there is one
+                                PZ_EV(16);
                                 if (p != a) j++;  // the pending match's position becomes a literal (deflate.zig:166-168)
                                 plen = best;
                                 pdist = bdist;
                                 emit = plen >= lazy;  // deflate.zig:171-173
                             }
                             if (emit) {
+                                PZ_EV(18);
                                 uint32_t desc = LITD, next = a + 1;
                                 if (plen) {
+                                    PZ_EV(20);
                                     desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
                                     next = a + j + plen;
                                 }
@@ -1108,6 +1232,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                 plen = 0;
                                 const bool meet = a < seg_end && ((stopmask >> ((a - seg0) & 63u)) & 1ull);
                                 if (a >= seg_end || meet) {
+                                    PZ_EV(22);
                                     // the parse leaves the segment or steps on an anchor of the lane's own parse
                                     if (st == ST_SPEC) {
                                         A = amask;
@@ -1134,6 +1259,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                     sp = a;
                                 }
                             } else {
+                                PZ_EV(24);
                                 // keep the match, look one position further (deflate.zig:174-178), in a quarter
                                 // of the chain if the match is good enough (deflate.zig:241-245)
                                 start = true;
@@ -1142,9 +1268,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                 sb = plen >= good ? (chain >> 2) : chain;
                             }
                         }
-                        if (start) PZ_START_CALL(sp, sl, sb);
+                        if (start) {
+                            PZ_EV(26);
+                            PZ_START_CALL(sp, sl, sb);
+                        }
                     }
-                    if (cnt != 0) PZ_LOAD_CAND();  // (every lane that comes out of this block walking has a new q)
+                    if (cnt != 0) {
+                        PZ_EV(28);
+                        PZ_LOAD_CAND();
+                    }  // (every lane that comes out of this block walking has a new q)
                 }
 #ifdef PZ_PROF
                 c_ttrans += __builtin_readcyclecounter() - c_tb;
@@ -1200,6 +1332,11 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         }
     }
 #ifdef PZ_PROF
+#pragma unroll
+    for (int k = 0; k < 30; k++) {
+        const uint32_t v = fl_wave_sum(c_ev[k]);
+        if ((tid & 63) == 0) atomicAdd((unsigned long long*)&g_fl_prof[k], (unsigned long long)v);
+    }
     if ((tid & 63) == 0) {
         // (c_meas / c_trans are per-lane counters of lane 0's view: only the wave-uniform ones are exact)
         atomicAdd((unsigned long long*)&g_fl_prof[40], (unsigned long long)c_fast);

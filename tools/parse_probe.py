@@ -35,3 +35,8 @@ print("lane 0 of each wave: measure iterations %.1f, transitions %.1f per wave" 
 print("per wave cycles: staging (incl. barrier) %.0f, path following incl. the wait for the slowest wave %.0f" % (t[55] / nw, t[56] / nw))
 print("per wave cycles (k_lz_parse6 only): phase A %.0f" % (t[57] / nw))
 print("per wave cycles in bursts by lanes walking when the burst starts: <= 2 lanes %.0f (%.0f bursts), 3-8 %.0f, 9-24 %.0f, more %.0f" % (t[58] / nw, t[62] / nw, t[59] / nw, t[60] / nw, t[61] / nw))
+names = ["block entered", "hit: measure", "measure iterations", "match improved", "transition part", "WAIT polls", "WAIT: published", "call ended",
+         "call ended with a match", "emit", "emit a match", "segment end / meet", "lazy: look further", "START_CALL", "LOAD_CAND"]
+print("events of the slow block, per chunk: waves that pass (lanes per passing wave)")
+for i, nm in enumerate(names):
+    print("  %-26s %8.1f  (%.1f)" % (nm, t[2 * i] / nc, t[2 * i + 1] / max(t[2 * i], 1)))

@@ -61,10 +61,19 @@ static void build_links(void) {
 }
 static int lcp(int q, int p, int maxlen) { int i = 0; while (i < maxlen && buf[q + i] == buf[p + i]) i++; return i; }
 
-static int cur_seg;
+static double ad_mean[3], ad_max[3]; static unsigned long long ad_n[3]; static int ad_chunks;
+#ifndef EST_BASE
+#define EST_BASE 1.0
+#endif
+#ifndef SEG_MIN
+#define SEG_MIN 16
+#endif
+static int cur_seg, cur_a;
+static uint32_t pos_cost[65536 + 16];
+#define COST_ADD(V) (seg_cost[cur_seg] += (V), pos_cost[cur_a] += (V))
 static int find_match_impl(int p, int len0, int* dist) {
     n_calls++;
-    seg_cost[cur_seg] += 3;  // (a call costs a visit of the slow block: counted as three steps)
+    COST_ADD(3);  // (a call costs a visit of the slow block: counted as three steps)
     if (len0) n_lazy++; else n_fresh++;
     if (p >= Mpos) return 0;
     const int maxlen = N - p < 258 ? N - p : 258;
@@ -79,12 +88,12 @@ static int find_match_impl(int p, int len0, int* dist) {
         n_l4phase++;
         int q = L4[p];
         while (q >= lo) {
-            n_l4steps++; seg_cost[cur_seg]++;
+            n_l4steps++; COST_ADD(1);
             n_l4_by_len[len == 0 ? 0 : len == 4 ? 1 : 2]++;
             last = q;
             const int fo = len ? len - 3 : 0;
             if (ld32(buf + q + fo) == ld32(buf + p + fo)) {
-                n_meas++; seg_cost[cur_seg] += 2;
+                n_meas++; COST_ADD(2);
                 const int l = lcp(q, p, maxlen);
                 if (l >= 4 && l > len) {
                     found = l; *dist = p - q; len = l;
@@ -100,11 +109,11 @@ static int find_match_impl(int p, int len0, int* dist) {
     const uint16_t* C = K == 4 ? L4 : LK;
     int q = C[p];
     while (q >= lo) {
-        if (q >= last) { n_skip++; seg_cost[cur_seg]++; q = C[q]; continue; }
-        n_lksteps++; seg_cost[cur_seg]++;
+        if (q >= last) { n_skip++; COST_ADD(1); q = C[q]; continue; }
+        n_lksteps++; COST_ADD(1);
         const int fo = len ? len - 3 : 0;
         if (ld32(buf + q + fo) == ld32(buf + p + fo)) {
-            n_meas++; seg_cost[cur_seg] += 2;
+            n_meas++; COST_ADD(2);
             const int l = lcp(q, p, maxlen);
             if (l >= 4 && l > len) {
                 found = l; *dist = p - q; len = l;
@@ -125,7 +134,7 @@ static unsigned long long n_rkcheck, n_rkcut, n_waste;
 static unsigned long long n_fb_calls, n_fb_steps, n_fb_long, n_fb_max, n_fb_found, n_fb_hist[8];
 static int find_match_lkfirst(int p, int len0, int* dist) {
     n_calls++;
-    seg_cost[cur_seg] += 3;
+    COST_ADD(3);
     if (len0) n_lazy++; else n_fresh++;
     if (p >= Mpos) return 0;
     const int maxlen = N - p < 258 ? N - p : 258;
@@ -140,10 +149,10 @@ static int find_match_lkfirst(int p, int len0, int* dist) {
     if (maxlen > len) {
         int q = LK[p];
         while (q >= lo) {
-            n_lksteps++; seg_cost[cur_seg]++;
+            n_lksteps++; COST_ADD(1);
             const int fo = len - 3;
             if (ld32(buf + q + fo) == ld32(buf + p + fo)) {
-                n_meas++; seg_cost[cur_seg] += 2;
+                n_meas++; COST_ADD(2);
                 const int l = lcp(q, p, maxlen);
                 if (l > len) {
                     if (lkfirst == 2 && RK[p] > ch) { n_rkcheck++; if ((int)RK[p] - (int)RK[q] > ch) { n_rkcut++; break; } }
@@ -160,11 +169,11 @@ static int find_match_lkfirst(int p, int len0, int* dist) {
     // fallback: the nearest candidate with lcp in (len0, K - 1], the longest first -- i.e. the reference's walk restricted
     // to what L_K cannot see.  Nothing of at least K bytes exists within the bounds.
     n_fb_calls++;
-    seg_cost[cur_seg] += 3;
+    COST_ADD(3);
     int q = L4[p], steps = 0;
     len = len0;
     while (q >= lo) {
-        steps++; n_fb_steps++; seg_cost[cur_seg] += 3;
+        steps++; n_fb_steps++; COST_ADD(3);
         const int fo = len ? len - 3 : 0;
         if (ld32(buf + q + fo) == ld32(buf + p + fo)) {
             const int l = lcp(q, p, maxlen);
@@ -233,6 +242,7 @@ int main(int argc, char** argv) {
         fo_tokenize(buf, N, level, toks, 65536 + 16, &nt);
         build_links();
         memset(seg_cost, 0, sizeof seg_cost);
+        memset(pos_cost, 0, sizeof pos_cost);
         for (int p = 0; p < Mpos; p++) {  // phase A: E4 / E5 of every position
             int q = L4[p], cn = chainmax, e4 = 0; const int lo = p > 32768 ? p - 32768 : 1; const int maxlen = N - p < 258 ? N - p : 258;
             unsigned st = 0;
@@ -253,7 +263,7 @@ int main(int argc, char** argv) {
         { unsigned long long mx = 0, sm = 0; const int nseg = (N + SEG - 1) / SEG, G = nseg < 1024 ? nseg : 1024; for (int i = 0; i < G; i++) { sm += pa_seg[i]; if (pa_seg[i] > mx) mx = pa_seg[i]; } pa_mean += (double)sm / G; pa_max += (double)mx; memset(pa_seg, 0, sizeof pa_seg); }
         int a = 0;
         while (a < N) {  // deflate.zig:154-205
-            cur_seg = a / SEG;
+            cur_seg = a / SEG; cur_a = a;
             int dist = 0, len = find_match(a, 0, &dist);
             if (!len) { mine[k++] = FO_TOK_LIT(buf[a]); a++; continue; }
             int j = 0;
@@ -273,6 +283,55 @@ int main(int argc, char** argv) {
         unsigned long long mx = 0, sm = 0; double wm = 0;
         for (int w = 0; w < G; w += 64) { unsigned long long m2 = 0; for (int i = w; i < w + 64 && i < G; i++) { sm += seg_cost[i]; if (seg_cost[i] > m2) m2 = seg_cost[i]; } if (m2 > mx) mx = m2; wm += (double)m2; }
         sum_mean += (double)sm / G; sum_max += (double)mx; sum_wavemax += wm / ((G + 63) / 64);
+        if (N >= 49152) {
+            // Segments of sub-pass A ([0, 49152), 1024 lanes) cut by an ESTIMATE of the load instead of every 48 bytes: a position whose
+            // chain link is d bytes away sits in a bucket with about 32768 / d members in the window; a call there walks min(that, chain)
+            // candidates.  Segments of 8 .. 64 bytes (the anchors of a segment are one 64-bit mask), at most 1024 of them.
+            static double est[49152];
+            for (int p = 0; p < 49152; p++) {
+                const int d = L4[p] ? p - L4[p] : 0;
+                double e = d ? 32768.0 / d : 0.0;
+                if (e > chainmax) e = chainmax;
+                est[p] = EST_BASE + e;
+            }
+            for (int mode = 0; mode < 2; mode++) {  // 0: by the estimate, 1: by the true load (the bound of the method)
+                double lo_t = 0, hi_t = 1e9;
+                int bounds[1100], nb = 0;
+                for (int it = 0; it < 60; it++) {
+                    const double T = 0.5 * (lo_t + hi_t);
+                    nb = 0; int s0 = 0; double acc = 0;
+                    for (int p = 0; p < 49152 && nb <= 1024; p++) {
+                        acc += mode ? (double)pos_cost[p] + 0.01 : est[p];
+                        const int len = p + 1 - s0;
+                        if (len >= 64 || (acc >= T && len >= SEG_MIN) || p == 49151) { if (nb < 1100) bounds[nb] = p + 1; nb++; s0 = p + 1; acc = 0; }
+                    }
+                    if (nb > 1024) lo_t = T; else hi_t = T;
+                }
+                {   // (with the last feasible T)
+                    const double T = hi_t; nb = 0; int s0 = 0; double acc = 0;
+                    for (int p = 0; p < 49152; p++) {
+                        acc += mode ? (double)pos_cost[p] + 0.01 : est[p];
+                        const int len = p + 1 - s0;
+                        if (len >= 64 || (acc >= T && len >= SEG_MIN) || p == 49151) { bounds[nb++] = p + 1; s0 = p + 1; acc = 0; }
+                    }
+                }
+                unsigned long long mxa = 0, sma = 0; int s0 = 0; double wmax = 0;
+                for (int i = 0; i < nb; i++) {
+                    unsigned long long cs = 0;
+                    for (int p = s0; p < bounds[i]; p++) cs += pos_cost[p];
+                    s0 = bounds[i];
+                    sma += cs; if (cs > mxa) mxa = cs;
+                }
+                (void)wmax;
+                ad_mean[mode] += (double)sma / 1024; ad_max[mode] += (double)mxa; ad_n[mode] += nb;
+            }
+            {   // fixed 48-byte segments over the same range
+                unsigned long long mxa = 0, sma = 0;
+                for (int i = 0; i < 1024; i++) { unsigned long long cs = 0; for (int p = 48 * i; p < 48 * i + 48; p++) cs += pos_cost[p]; sma += cs; if (cs > mxa) mxa = cs; }
+                ad_mean[2] += (double)sma / 1024; ad_max[2] += (double)mxa; ad_n[2] += 1024;
+            }
+            ad_chunks++;
+        }
     }
     printf("level %d K %d hash bits %d: %d chunks, %llu bytes, mismatching chunks %llu, mismatching calls %llu\n", level, K, hbits, c, total, bad, n_bad_calls);
     printf("per byte: calls %.3f (fresh %.3f lazy %.3f)  L4-phase calls %.3f  L4-phase steps %.3f (len 0: %.3f, 4: %.3f, 5+: %.3f)  L%d steps %.3f  skipped %.3f  measures %.3f  all steps %.3f\n",
@@ -289,5 +348,9 @@ int main(int argc, char** argv) {
            (double)hist_best[4] / total, (double)hist_best[5] / total, (double)hist_best[6] / total, (double)hist_best[7] / total);
     printf("load per %d-byte segment (steps + 3 per call + 2 per measure): mean %.0f, slowest of a wave %.0f (%.2f x), slowest of 1024 %.0f (%.2f x)\n",
            SEG, sum_mean / c, sum_wavemax / c, sum_wavemax / sum_mean, sum_max / c, sum_max / sum_mean);
+    if (ad_chunks) {
+        const char* nm[3] = {"cut by the estimate", "cut by the true load", "every 48 bytes"};
+        for (int m = 0; m < 3; m++) printf("sub-pass A, segments %s: %.0f segments, load per lane: mean %.0f, slowest %.0f (%.2f x)\n", nm[m], (double)ad_n[m] / ad_chunks, ad_mean[m] / ad_chunks, ad_max[m] / ad_chunks, ad_max[m] / ad_mean[m]);
+    }
     return bad != 0;
 }
