@@ -95,6 +95,7 @@ struct fl_knobs {
     uint64_t span_min_bytes = 0;          // FLATE_HIP_INFLATE_SPANS (0 = never); set to the default below
     bool span_debug = false;              // FLATE_HIP_SPAN_DEBUG
     int span_twin = -1;                   // FLATE_HIP_SPAN_TWIN: -1 unset, 0 never, 2..950 where to cut
+    bool span_two_runs = false;           // FLATE_HIP_SPAN_TWO_RUNS: round 4's two decodes per span instead of one in symbols (tests, tuning)
     bool no_pin_mirror = false;           // FLATE_HIP_NO_PIN_MIRROR
     bool no_ramp = false;                 // FLATE_HIP_NO_RAMP
     uint32_t stream_group = 0;            // FLATE_HIP_STREAM_GROUP: windows per group of the whole-stream path (0: by the number of streams; tuning / tests)
@@ -277,6 +278,7 @@ void read_knobs(fl_knobs& k, uint64_t span_default) {
     k.no_ramp = getenv("FLATE_HIP_NO_RAMP") != nullptr;
     if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
     k.simple_ck_inline = getenv("FLATE_HIP_SIMPLE_CK_INLINE") != nullptr;
+    if ((e = getenv("FLATE_HIP_SPAN_TWO_RUNS"))) k.span_two_runs = atoi(e) != 0;
     if ((e = getenv("FLATE_HIP_STREAM_WINDOWS"))) k.stream_windows = atoi(e) != 0;
     if ((e = getenv("FLATE_HIP_STREAM_GROUP")) && atoi(e) > 0) k.stream_group = (uint32_t)atoi(e);
     if ((e = getenv("FLATE_HIP_INFLATE_PAR"))) k.inflate_par = atoll(e);
@@ -855,6 +857,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // cut at 56 / 62 / 66.6 / 72 / 78 % of the compressed bytes: 11.7 / 7.9 / 6.3 / 6.9 / 7.1 ms -- second spans that
     // are too long cost more than first spans that are: 1.5 % are added to f.
     const int etw = h->knobs.span_twin;  // FLATE_HIP_SPAN_TWIN -- -1: unset; 0: never; 2..950: where to cut, in thousandths of the stream (tuning)
+    const bool sym = !h->knobs.span_two_runs;  // one decode per span, in symbols (kernels_inflate_par.h)
     const bool twin = n_long > FL_SPAN_STREAMS && etw != 0 && (size_t)n_long * 20 <= (size_t)h->n_cu * 11;  // (40 / 64 / 96 / 160 / 200 one-MiB members: 7.9 / 7.9 / 13.0 / 13.0 / 13.0 ms a workgroup each, 6.1 / 6.1 / 9.1 / 13.3 / 13.4 this way)
     if (n_long > FL_SPAN_STREAMS && !twin) return 0;
     const uint64_t elig_bytes = twin ? std::min<uint64_t>(min_bytes, 32768u) : min_bytes;
@@ -883,7 +886,11 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         const uint32_t P = twin ? 2u : (uint32_t)std::max<uint64_t>(2, std::min<uint64_t>(want * weight(c) / elig_w, c.in_len / (FL_SPAN_BYTES / 4)));
         for (uint32_t j = 1; j < P; j++) {
             fl_scan_point pt;
-            pt.from_bit = twin ? bits / 1000 * (etw > 1 ? (uint64_t)std::min(950, etw) : std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()) + 15))) : bits / P * j;
+            // (two runs: f = 2 S / (CUs + S) of the stream before the cut, + 1.5 %; one decode in symbols, 1.25 x the cost of a decode in
+            // bytes: f = 1.25 S / (CUs + S / 4))
+            const uint64_t auto_f = sym ? std::min<uint64_t>(900, std::max<uint64_t>(500, 1250ull * elig.size() / (h->n_cu + elig.size() / 4) + 10))
+                                        : std::min<uint64_t>(900, std::max<uint64_t>(500, 2000ull * elig.size() / (h->n_cu + elig.size()) + 15));
+            pt.from_bit = twin ? bits / 1000 * (etw > 1 ? (uint64_t)std::min(950, etw) : auto_f) : bits / P * j;
             pt.limit_bit = j + 1 < P ? bits / P * (j + 1) : bits;
             pt.stream = elig[k];
             pt.pad = 0;
@@ -956,7 +963,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     {
         uint64_t bytes = 0;
         for (uint32_t ci : elig) bytes += std::min<uint64_t>(chunks[ci].out_cap, 32ull * chunks[ci].in_len);
-        const uint64_t pieces = ((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1) * (twin ? 2 : 1);
+        const uint64_t pieces = ((bytes >> FP_PIECE_LOG) + 2ull * nsp + 1) * ((twin || sym) ? 2 : 1);
         // (a pool the device cannot give -- callers who reserve the worst case for gigabytes of input: the old way.  The
         // pool is a second copy of the decoded output: it may take a quarter of what is free next to what it holds
         // already, never more than 16 GiB, so that an allocator that shares the device -- PyTorch's -- is not starved.)
@@ -985,15 +992,17 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     // ---- run A
     {
         ProfScope ps(h, K_INFLATE_SPAN);
-        hipLaunchKernelGGL(k_inflate_span, dim3(twin ? 2 * nsp : nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
+        hipLaunchKernelGGL(k_inflate_span, dim3(twin && !sym ? 2 * nsp : nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                            (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u, pool, twin ? nsp : 0u,
-                           (uint8_t*)h->sp_tails_b.p);
+                           (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails.p, 0u, pool, twin && !sym ? nsp : 0u,
+                           (uint8_t*)h->sp_tails_b.p, sym ? nsp : 0u);
     }
+    const bool both = twin || sym;  // what run B makes is there after this launch
     std::vector<fl_span_res> r1(nsp), r2(nsp);
     if (hipMemcpyAsync(r1.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-    if (twin && hipMemcpyAsync(r2.data(), (const fl_span_res*)h->sp_res.p + nsp, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (twin && !sym && hipMemcpyAsync(r2.data(), (const fl_span_res*)h->sp_res.p + nsp, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (sym) r2 = r1;  // (one decode: what it says holds for both planes)
     if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 2 done\n", since());
     // ---- the chain of every stream
     struct StreamPlan {
@@ -1015,7 +1024,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
             if (r.status != 0) { ok = false; break; }
             // (run B of a twin launch does not know where its span starts: a distance that reaches before the start of
             // the OUTPUT -- possible in the first 32 KiB only -- is the old path's to find)
-            if (twin && !spans[cur].first && r.uses_hist && acc < FP_TAIL) { ok = false; break; }
+            if (both && !spans[cur].first && r.uses_hist && acc < FP_TAIL) { ok = false; break; }
             spans[cur].live = 1;
             spans[cur].wp = acc;
             spans[cur].prev = pl.chain.empty() ? FP_NO_SPAN : pl.chain.back();
@@ -1063,9 +1072,9 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
                     it.span = si;
                     it.local = (uint32_t)o;
                     it.len = (uint32_t)std::min<uint64_t>(FP_PIECE, n - o);
-                    it.kind = spans[si].first ? 0u : uses_hist ? (twin ? 3u : 2u) : 1u;
+                    it.kind = spans[si].first ? 0u : uses_hist ? (both ? 3u : 2u) : 1u;
                     it.prev = spans[si].prev;
-                    it.pad = twin ? nsp : 0u;
+                    it.pad = both ? nsp : 0u;
                     items.push_back(it);
                 }
             }
@@ -1084,10 +1093,10 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     {
         ProfScope ps(h, K_INFLATE_SPAN);
         if (uses_hist) {
-            if (!twin)
+            if (!both)
                 hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                                    (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
-                                   (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool, 0u, (uint8_t*)nullptr);
+                                   (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool, 0u, (uint8_t*)nullptr, 0u);
             hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
                                (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
         }
@@ -1114,7 +1123,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         if (hipMemcpyAsync(foot.data(), h->sp_foot.p, 8 * (size_t)nel, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     }
     std::vector<uint32_t> part(2 * (size_t)n_items);
-    if (uses_hist && !twin && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (uses_hist && !both && hipMemcpyAsync(r2.data(), h->sp_res.p, sizeof(fl_span_res) * nsp, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (n_items && hipMemcpyAsync(part.data(), h->sp_part.p, sizeof(uint32_t) * 2 * n_items, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 3 done\n", since());

@@ -110,6 +110,7 @@ struct fp_shared {
     uint32_t r_nvalid, r_kind, r_next, r_cutwave, r_cutbudget, r_nout;
     uint32_t redo, blk_done, blk_final, blk_type, unresolved[3];  // one flag per resolve round, three in rotation
     uint32_t n_pieces, piece_id[2];  // spans, run A: pieces of the pool this span has taken; the last two of them
+    uint32_t piece_idb[2];           // symbols: the last two pieces of plane B
     uint32_t nblk, stop, uses_hist;  // spans: blocks decoded so far; the span ends here; a copy reached before its start
     uint32_t err_far;  // a copy of this round reaches before the start of the output (set in step 6, read after its barrier)
     uint32_t st_len;  // stored block: bytes
@@ -233,12 +234,23 @@ __device__ __forceinline__ void fp_fetch64(const FL_LDS uint32_t* stage, uint32_
     hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 }
 
-__device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  // rel in [-32768, FP_OUT_CAP)
-    uint32_t x = wbase + (uint32_t)((int32_t)FP_RING + rel);  // wbase < FP_RING
-    if (x >= FP_RING) x -= FP_RING;
-    if (x >= FP_RING) x -= FP_RING;
+template <uint32_t RING = FP_RING>
+__device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  // rel in [-32768, the round's output cap)
+    uint32_t x = wbase + (uint32_t)((int32_t)RING + rel);  // wbase < RING
+    if (x >= RING) x -= RING;
+    if (x >= RING) x -= RING;
     return x;
 }
+// SYMBOLS (spans that do not know their history, round 5): the ring holds 16 bits per output byte -- below 256 a byte's value,
+// 256 + h "whatever byte h of the 32 KiB before the span is", 0xC000 + o "not resolved yet: what the window's byte o is" -- so one
+// decode gives what runs A and B gave (a = e & 255, b = a ^ (e >> 8): the two fillings of the history, byte for byte).  The 16-bit
+// ring lies where the byte ring and the pointers of the other mode lie; a round makes 8 KiB at most instead of 16.
+#define FP_SYM_OUT_CAP 8192u
+#define FP_SYM_RING (32768u + FP_SYM_OUT_CAP)
+#define FP_SYM_PTR 0xC000u
+#ifndef FP_SYM_WBITS
+#define FP_SYM_WBITS 1536u  // compressed bits per wave and round: what 8 KiB of output hold (text: 2.6 bytes out per byte in)
+#endif
 
 __device__ __forceinline__ uint32_t fp_tok_len(uint32_t t) { return (t >> 31) ? ((t >> 16) & 0x1ffu) : 1u; }
 
@@ -295,17 +307,20 @@ struct fl_span_pool {
 };
 
 // MODE 0: the whole stream (k_inflate_par); 1: a span, run A (fill 0) or B (fill 1) (k_inflate_span)
-template <int MODE>
+template <int MODE, bool SYM = false>
 __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl_chunk* __restrict__ chunks, int container,
                                         int flags, uint32_t min_bytes, fl_crc_consts cc, uint8_t* __restrict__ out,
                                         uint64_t* __restrict__ out_len, int32_t* __restrict__ status,
                                         uint64_t* __restrict__ consumed, const fl_span* __restrict__ spans,
                                         fl_span_res* __restrict__ sres, const uint64_t* __restrict__ cand,
                                         const uint32_t* __restrict__ cand_off, uint8_t* __restrict__ tails, uint32_t fill,
-                                        fl_span_pool pool, uint32_t unit, bool b_pool) {
+                                        fl_span_pool pool, uint32_t unit, bool b_pool, FL_LDS fp_shared* sh,
+                                        uint32_t b_base = 0u, uint8_t* __restrict__ tails_b = nullptr) {
     // unit: the stream (MODE 0) / the span (MODE 1); b_pool: run B at the same time as run A, its bytes to the pool as well
-    __shared__ fp_shared sh_mem;
-    FL_LDS fp_shared* sh = (FL_LDS fp_shared*)&sh_mem;
+    // SYM: one decode in symbols, both planes to the pool (plane B's pieces: table rows b_base + unit) and both tails
+    constexpr uint32_t OUT_CAP = SYM ? FP_SYM_OUT_CAP : FP_OUT_CAP, RING = 32768u + OUT_CAP;
+    static_assert(offsetof(fp_shared, ptr) == offsetof(fp_shared, ring) + FP_RING && 2u * FP_SYM_RING <= FP_RING + 2u * FP_OUT_CAP, "the 16-bit ring lies over ring + ptr");
+    FL_LDS uint16_t* ring16 = (FL_LDS uint16_t*)sh->ring;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
     fl_span sp;
     sp.start_bit = 0;
@@ -357,6 +372,9 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             return pool.base + (uint64_t)sh->piece_id[(uint32_t)(o >> FP_PIECE_LOG) & 1u] * FP_PIECE + ((uint32_t)o & (FP_PIECE - 1u));
         return dst + o;
     };
+    auto out_b_at = [&](uint64_t o) -> uint8_t* {  // (SYM) plane B
+        return pool.base + (uint64_t)sh->piece_idb[(uint32_t)(o >> FP_PIECE_LOG) & 1u] * FP_PIECE + ((uint32_t)o & (FP_PIECE - 1u));
+    };
     // (thread 0) pieces for the span's bytes below `end`; the bytes about to be written lie in the last two
     auto pieces_to = [&](uint64_t end) -> bool {
         const uint64_t need = (end + FP_PIECE - 1u) >> FP_PIECE_LOG;
@@ -367,6 +385,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             if (id >= pool.pieces) return false;
             pool.tab[(uint64_t)unit * FP_MAX_PIECES + n] = id;
             sh->piece_id[n & 1u] = id;
+            if (SYM) {
+                const uint32_t idb = atomicAdd(pool.next, 1u);
+                if (idb >= pool.pieces) return false;
+                pool.tab[(uint64_t)(b_base + unit) * FP_MAX_PIECES + n] = idb;
+                sh->piece_idb[n & 1u] = idb;
+            }
             n++;
         }
         sh->n_pieces = n;
@@ -376,7 +400,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     if (tid == 0) {
         sh->redo = 0;
         sh->wp = 0;
-        sh->wbits = FP_WBITS;
+        sh->wbits = SYM ? FP_SYM_WBITS : FP_WBITS;
     }
     if (wave == 0) {
         if (sp.first) {
@@ -390,7 +414,14 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             sh->bitpos = sp.start_bit;
         }
     }
-    if (MODE != 0) {
+    if (SYM) {
+        for (uint32_t hh = tid; hh < FP_TAIL; hh += FP_THREADS) ring16[RING - FP_TAIL + hh] = (uint16_t)(256u + hh);
+        if (tid == 0) {
+            sh->nblk = 0;
+            sh->uses_hist = 0;
+            sh->n_pieces = 0;
+        }
+    } else if (MODE != 0) {
         // the 32 KiB before the span: filling A or B (see above)
         for (uint32_t i = tid; i < FP_TAIL / 4; i += FP_THREADS) {
             // bytes 4 i .. 4 i + 3: A = low byte of the index, B = A ^ (high byte of the index + 1)
@@ -506,11 +537,17 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 bail = sh->redo != 0;
             }
             if (!bail) {
-                for (uint32_t i = tid; i < len; i += FP_THREADS) *out_at(wp + i) = src[from + i];
-                const uint32_t tail = min(len, FP_RING);
+                for (uint32_t i = tid; i < len; i += FP_THREADS) {
+                    *out_at(wp + i) = src[from + i];
+                    if (SYM) *out_b_at(wp + i) = src[from + i];
+                }
+                const uint32_t tail = min(len, RING);
                 for (uint32_t i = tid; i < tail; i += FP_THREADS) {
                     const uint64_t o = wp + len - tail + i;
-                    sh->ring[(uint32_t)(o % FP_RING)] = src[from + len - tail + i];
+                    if (SYM)
+                        ring16[(uint32_t)(o % RING)] = src[from + len - tail + i];
+                    else
+                        sh->ring[(uint32_t)(o % RING)] = src[from + len - tail + i];
                 }
             }
             __syncthreads();
@@ -526,7 +563,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 const uint64_t bitpos = sh->bitpos;
                 const uint64_t wp = sh->wp;
                 const uint32_t byte0 = (uint32_t)(bitpos >> 3), bit0 = (uint32_t)bitpos & 7;
-                const uint32_t wbase = (uint32_t)(wp % FP_RING);
+                const uint32_t wbase = (uint32_t)(wp % RING);
                 // bits per wave: halved (for the rest of the stream) when a wave ran out of token slots
                 const uint32_t wbits = sh->wbits, jbits = min(wbits, (uint32_t)FP_JOIN_BITS);
                 // (1) stage the window
@@ -716,12 +753,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                     const uint32_t incl = fl_wave_incl_scan(mine, lane);
                     const uint32_t base = incl - mine;
                     uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), cutwave = 0xffffffffu, cutbudget = 0;
-                    const uint64_t over = __ballot(lane < nvalid && base + total > FP_OUT_CAP);
+                    const uint64_t over = __ballot(lane < nvalid && base + total > OUT_CAP);
                     if (over) {  // the window is cut at a token of this wave (which adds what fits)
                         const int cw = __builtin_ctzll(over);
                         run = (uint32_t)__builtin_amdgcn_readlane((int)base, cw);
                         cutwave = (uint32_t)cw;
-                        cutbudget = FP_OUT_CAP - run;
+                        cutbudget = OUT_CAP - run;
                         nvalid = (uint32_t)cw + 1u;
                     }
                     if (lane < nvalid) sh->w_base[lane] = base;
@@ -734,7 +771,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         sh->r_cutbudget = cutbudget;
                         if (kind == FP_X_BAIL) sh->redo = FP_WHY(4);
                         sh->err_far = 0;
-                        if (MODE == 1 && to_pool && !pieces_to(wp + FP_OUT_CAP)) sh->redo = FP_WHY(9);
+                        if (MODE == 1 && to_pool && !pieces_to(wp + OUT_CAP)) sh->redo = FP_WHY(9);
                         sh->r_nvalid = nvalid;
                         sh->r_nout = run;
                         sh->unresolved[0] = 0;
@@ -774,8 +811,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         const uint32_t my_off = off + used + incl - len;
                         const bool ok = (okm >> lane) & 1;
                         if (ok && !(t >> 31)) {
-                            sh->ring[fp_ring_idx(wbase, (int32_t)my_off)] = (uint8_t)t;
-                            sh->ptr[my_off] = (uint16_t)FP_RES;
+                            if (SYM) {
+                                ring16[fp_ring_idx<RING>(wbase, (int32_t)my_off)] = (uint16_t)(t & 0xffu);
+                            } else {
+                                sh->ring[fp_ring_idx(wbase, (int32_t)my_off)] = (uint8_t)t;
+                                sh->ptr[my_off] = (uint16_t)FP_RES;
+                            }
                         }
                         // a copied byte points at its source: window position + 32768 (below: the 32 KiB before
                         // the window); short copies are written by their own lanes, long ones by the wave
@@ -785,8 +826,17 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         if (MODE == 1 && is_m && (uint64_t)mdist_l > wp + my_off) sh->uses_hist = 1;  // reaches before the start of the output
                         const uint32_t src0 = my_off + 32768u - mdist_l;
                         const uint32_t shortmax = fl_wave_max(is_m && mlen_l <= 32 ? mlen_l : 0u);
+                        // (SYM: a source before the window is a symbol that stands: taken at once; one inside it: where it is)
+                        auto sym_of = [&](uint32_t s_) -> uint16_t {
+                            return s_ < 32768u ? ring16[fp_ring_idx<RING>(wbase, (int32_t)s_ - 32768)] : (uint16_t)(FP_SYM_PTR + (s_ - 32768u));
+                        };
                         for (uint32_t i = 0; i < shortmax; i++)
-                            if (is_m && mlen_l <= 32 && i < mlen_l) sh->ptr[my_off + i] = (uint16_t)(src0 + i);
+                            if (is_m && mlen_l <= 32 && i < mlen_l) {
+                                if (SYM)
+                                    ring16[fp_ring_idx<RING>(wbase, (int32_t)(my_off + i))] = sym_of(src0 + i);
+                                else
+                                    sh->ptr[my_off + i] = (uint16_t)(src0 + i);
+                            }
                         uint64_t mm = __ballot(is_m && mlen_l > 32);
                         while (mm) {
                             const uint32_t l0 = (uint32_t)__builtin_ctzll(mm);
@@ -794,7 +844,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                             const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)mlen_l, (int)l0);
                             const uint32_t mo = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)l0);
                             const uint32_t ms = (uint32_t)__builtin_amdgcn_readlane((int)src0, (int)l0);
-                            for (uint32_t i = lane; i < mlen; i += 64) sh->ptr[mo + i] = (uint16_t)(ms + i);
+                            for (uint32_t i = lane; i < mlen; i += 64) {
+                                if (SYM)
+                                    ring16[fp_ring_idx<RING>(wbase, (int32_t)(mo + i))] = sym_of(ms + i);
+                                else
+                                    sh->ptr[mo + i] = (uint16_t)(ms + i);
+                            }
                         }
                         if (stop < 64) {
                             // the token at k0 + stop does not fit: the next round starts at its bit
@@ -841,6 +896,17 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                         const uint32_t kb = (uint32_t)__builtin_ctz(todo);
                         todo &= todo - 1;
                         const uint32_t j = tid + kb * FP_THREADS;
+                        if (SYM) {
+                            // the source's symbol, or -- if that is not resolved either -- the source's source: one 16-bit word
+                            const uint32_t xi = fp_ring_idx<RING>(wbase, (int32_t)j);
+                            const uint32_t v = ring16[xi];
+                            if (v >= FP_SYM_PTR) {
+                                const uint32_t pv = ring16[fp_ring_idx<RING>(wbase, (int32_t)(v - FP_SYM_PTR))];
+                                ring16[xi] = (uint16_t)pv;
+                                if (pv >= FP_SYM_PTR) pend |= 1u << kb;
+                            }
+                            continue;
+                        }
                         const uint32_t v = sh->ptr[j];
                         if (v != FP_RES) {
                             if (v < 32768u) {  // the source lies before the window: final
@@ -873,7 +939,15 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 }
                 FP_T(39);
                 // (8) the window's bytes leave
-                for (uint32_t j = tid; j < nout; j += FP_THREADS) *out_at(wp + j) = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
+                if (SYM) {
+                    for (uint32_t j = tid; j < nout; j += FP_THREADS) {
+                        const uint32_t e = ring16[fp_ring_idx<RING>(wbase, (int32_t)j)];
+                        *out_at(wp + j) = (uint8_t)e;
+                        *out_b_at(wp + j) = (uint8_t)(e ^ (e >> 8));
+                    }
+                } else {
+                    for (uint32_t j = tid; j < nout; j += FP_THREADS) *out_at(wp + j) = sh->ring[fp_ring_idx(wbase, (int32_t)j)];
+                }
                 __syncthreads();
                 if (tid == 0) {
                     const uint64_t nb = bitpos + sh->r_next;  // r_next counts from the window's first bit
@@ -910,9 +984,18 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     const uint64_t n_out = sh->wp;
     if (MODE != 0) {
         // the span's tail: the last 32 KiB of the output up to its end (what was there before it included)
-        const uint32_t wb = (uint32_t)(n_out % FP_RING);
+        const uint32_t wb = (uint32_t)(n_out % RING);
         uint8_t* tl = tails + (uint64_t)unit * FP_TAIL;
-        for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) tl[i] = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
+        if (SYM) {
+            uint8_t* tlb = tails_b + (uint64_t)unit * FP_TAIL;
+            for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) {
+                const uint32_t e = ring16[fp_ring_idx<RING>(wb, (int32_t)i - (int32_t)FP_TAIL)];
+                tl[i] = (uint8_t)e;
+                tlb[i] = (uint8_t)(e ^ (e >> 8));
+            }
+        } else {
+            for (uint32_t i = tid; i < FP_TAIL; i += FP_THREADS) tl[i] = sh->ring[fp_ring_idx(wb, (int32_t)i - (int32_t)FP_TAIL)];
+        }
         if (tid == 0) {
             fl_span_res* rr = &sres[unit];
             rr->end_bit = sh->bitpos;
@@ -948,7 +1031,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             v = hi > lo ? ~v : 0u;
             v = fl_crc_mulmod(v, fl_crc_xpow8n(cc.xpow8, n_out - hi));
             v = fl_wave_xor(v);
-            if (lane == 0) atomicXor(&sh_mem.crc, v);
+            if (lane == 0) atomicXor((uint32_t*)&sh->crc, v);
         } else {
             uint32_t A = 0, B = 0;
             uint64_t i = lo;
@@ -965,8 +1048,8 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
             uint32_t Bm = (uint32_t)((B + (uint64_t)A * after) % 65521u);
             const uint32_t As = fl_wave_sum(A), Bs = fl_wave_sum(Bm);  // 64 values < 65521
             if (lane == 0) {
-                atomicAdd(&sh_mem.adA, As);  // 16 partial sums < 2^22: no overflow
-                atomicAdd(&sh_mem.adB, Bs);
+                atomicAdd((uint32_t*)&sh->adA, As);  // 16 partial sums < 2^22: no overflow
+                atomicAdd((uint32_t*)&sh->adB, Bs);
             }
         }
         __syncthreads();
@@ -1350,8 +1433,9 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_par(const uint8_t* __
                                                                uint8_t* __restrict__ out, uint64_t* __restrict__ out_len,
                                                                int32_t* __restrict__ status,
                                                                uint64_t* __restrict__ consumed) {
+    __shared__ fp_shared sh_mem;
     fp_body<0>(in, chunks, container, flags, min_bytes, cc, out, out_len, status, consumed, nullptr, nullptr, nullptr,
-               nullptr, nullptr, 0u, fl_span_pool{nullptr, nullptr, nullptr, 0u, 0u}, blockIdx.x, false);
+               nullptr, nullptr, 0u, fl_span_pool{nullptr, nullptr, nullptr, 0u, 0u}, blockIdx.x, false, (FL_LDS fp_shared*)&sh_mem);
 }
 
 // One workgroup per span (see above); fill 0: run A, 1: run B.
@@ -1364,7 +1448,7 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
                                                                 const uint32_t* __restrict__ cand_off,
                                                                 uint8_t* __restrict__ tails, uint32_t fill,
                                                                 fl_span_pool pool, uint32_t twin_nsp,
-                                                                uint8_t* __restrict__ tails_b) {
+                                                                uint8_t* __restrict__ tails_b, uint32_t sym_nsp) {
     // twin_nsp != 0: both runs in one launch -- workgroups [0, twin_nsp) are run A of the spans, [twin_nsp, 2 twin_nsp)
     // run B of the same spans, with its results, tails and pieces behind run A's
     uint32_t unit = blockIdx.x;
@@ -1377,8 +1461,20 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
         tails = tails_b;
         pool.tab += (uint64_t)twin_nsp * FP_MAX_PIECES;
     }
+    __shared__ fp_shared sh_mem;
+    if (sym_nsp) {
+        // ONE decode per span (round 5): a stream's first span writes its bytes in place, every other one symbols -- both planes
+        // (what runs A and B made) to the pool, plane B's pieces and results where a twin launch's run B had them
+        if (spans[unit].first)
+            fp_body<1, false>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails, 0u,
+                              pool, unit, false, (FL_LDS fp_shared*)&sh_mem);
+        else
+            fp_body<1, true>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails, 0u,
+                             pool, unit, false, (FL_LDS fp_shared*)&sh_mem, sym_nsp, tails_b);
+        return;
+    }
     fp_body<1>(in, chunks, container, flags, 0u, cc, out, nullptr, nullptr, nullptr, spans, sres, cand, cand_off, tails, fill,
-               pool, unit, b_pool);
+               pool, unit, b_pool, (FL_LDS fp_shared*)&sh_mem);
 }
 
 // The bytes of the live spans, 64 KiB (an ITEM) per wave, a lane per 1024 of them: moved from the pool to their place

@@ -1413,7 +1413,6 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     uint32_t tw_next = 0;  // the wave's 16 words of anchor bits of the next part
     if (lane < FL_TOK_SPAN / 32u && wave * FL_TOK_SPAN + 32 * lane < min((uint32_t)FL_TOK_PART, N)) tw_next = trueg[((wave * FL_TOK_SPAN) >> 5) + lane];
     for (uint32_t h0 = 0; h0 < N; h0 += FL_TOK_PART) {
-        const uint32_t h1 = min(h0 + FL_TOK_PART, N);
         const uint32_t span0 = h0 + wave * FL_TOK_SPAN;
         // the wave's 512 anchor bits (16 words); the positions of its anchors go to a list (a third of the positions
         // of text are anchors: the rounds below are over anchors, 64 at a time, not over positions)

@@ -16,6 +16,18 @@ from test_gpu_inflate import _long_streams, _mutants
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["symbols", "two_runs"])
+def _span_decode_mode(request, monkeypatch):
+    """Every test of this module twice: a span decoded ONCE, in 16-bit symbols (a byte's value, or which byte of the 32 KiB
+    before the span it equals) -- the default since round 5 --, and round 4's two decodes with two fillings of that history
+    (FLATE_HIP_SPAN_TWO_RUNS=1: kept as the cross-check of the first)."""
+    if request.param == "two_runs":
+        monkeypatch.setenv("FLATE_HIP_SPAN_TWO_RUNS", "1")
+    else:
+        monkeypatch.delenv("FLATE_HIP_SPAN_TWO_RUNS", raising=False)
+    yield
+
+
 def _kernels(eng, fn):
     eng.profile_reset()
     eng.profile_enable(True)
