@@ -131,7 +131,7 @@ struct flate_hip_ctx {
     std::function<void(uint32_t, uint32_t)> mirror_in, mirror_out;
     uint32_t n_cu = 0;  // of the device (spans)
     DevBuf sp_points, sp_found, sp_spans, sp_res, sp_cand, sp_candoff, sp_tails, sp_tails_b, sp_chain, sp_chainoff,
-        sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part, sp_footoff, sp_foot, sp_fin;  // inflate of long streams by spans
+        sp_pool, sp_pooltab, sp_poolctl, sp_items, sp_part, sp_footoff, sp_foot, sp_fin, sp_chainpos, sp_rs;  // inflate of long streams by spans
     DevBuf tiles, segs, pieces, fpts, zones, nsorted, jmp, exitmap, entry, segtok, tokbase, bound;  // whole-stream passes
     DevBuf sgroups, sgroup0, gmap, gentry, sblocks;
     DevBuf st_in, st_out, st_inoff, st_outlen, st_status, st_consumed, st_pack, st_packoff, st_slot;
@@ -1066,15 +1066,22 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         if (plans[k].ok) {
             for (uint32_t si : plans[k].chain) {
                 const uint64_t n = r1[si].out_len;
-                for (uint64_t o = 0; o < n; o += FP_PIECE) {
+                for (uint64_t o = 0; o < n; o += FP_FIX_ITEM) {
                     fl_fix_item it;
                     it.dst = chunks[elig[k]].out_off + spans[si].wp + o;
                     it.span = si;
                     it.local = (uint32_t)o;
-                    it.len = (uint32_t)std::min<uint64_t>(FP_PIECE, n - o);
+                    it.len = (uint32_t)std::min<uint64_t>(FP_FIX_ITEM, n - o);
                     it.kind = spans[si].first ? 0u : uses_hist ? (both ? 3u : 2u) : 1u;
                     it.prev = spans[si].prev;
                     it.pad = both ? nsp : 0u;
+                    items.push_back(it);
+                }
+                // (a workgroup of k_span_fix takes FP_FIX_WAVES items of ONE span: empty ones fill the last)
+                while (items.size() % FP_FIX_WAVES) {
+                    fl_fix_item it = items.back();
+                    it.local = 0;
+                    it.len = 0;
                     items.push_back(it);
                 }
             }
@@ -1089,6 +1096,21 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (hipMemcpyAsync(h->sp_spans.p, spans.data(), sizeof(fl_span) * nsp, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chain.p, chain_all.data(), sizeof(uint32_t) * chain_all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(h->sp_chainoff.p, chain_off.data(), sizeof(uint32_t) * chain_off.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    // (symbols) every span's place in its chain, the longest chain, room for two sets of tails in symbols; no room: span after span
+    std::vector<uint32_t> chain_pos;
+    uint32_t longest = 0;
+    bool rs_ok = false;
+    if (sym && uses_hist) {
+        for (size_t k = 0; k < elig.size(); k++)
+            if (plans[k].ok) {
+                for (uint32_t j = 0; j < plans[k].chain.size(); j++) chain_pos.push_back(j);
+                longest = std::max<uint32_t>(longest, (uint32_t)plans[k].chain.size());
+            }
+        rs_ok = !chain_pos.empty() && ensure(h, h->sp_chainpos, sizeof(uint32_t) * chain_pos.size()) == 0 &&
+                ensure(h, h->sp_rs, 2 * chain_pos.size() * (size_t)FP_TAIL * sizeof(uint16_t)) == 0;
+        if (!rs_ok) (void)hipGetLastError();
+        if (rs_ok && hipMemcpyAsync(h->sp_chainpos.p, chain_pos.data(), sizeof(uint32_t) * chain_pos.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    }
     if (n_items && hipMemcpyAsync(h->sp_items.p, items.data(), sizeof(fl_fix_item) * n_items, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     {
         ProfScope ps(h, K_INFLATE_SPAN);
@@ -1097,11 +1119,26 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
                 hipLaunchKernelGGL(k_inflate_span, dim3(nsp), dim3(FP_THREADS), 0, st, d_in, dch, container, flags, h->crc, d_out,
                                    (const fl_span*)h->sp_spans.p, (fl_span_res*)h->sp_res.p, (const uint64_t*)h->sp_cand.p,
                                    (const uint32_t*)h->sp_candoff.p, (uint8_t*)h->sp_tails_b.p, 1u, pool, 0u, (uint8_t*)nullptr, 0u);
-            hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
-                               (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
+            if (sym && rs_ok) {
+                // the true tails of all spans at once: log2(longest chain) steps (kernels_inflate_par.h, k_span_rs_*)
+                const uint32_t ng = (uint32_t)chain_all.size();
+                uint16_t* S0 = (uint16_t*)h->sp_rs.p;
+                uint16_t* S1 = S0 + (size_t)ng * FP_TAIL;
+                const dim3 grid(ng, FP_TAIL / (256 * 8));
+                hipLaunchKernelGGL(k_span_rs_init, grid, dim3(256), 0, st, (const uint32_t*)h->sp_chain.p, (const uint32_t*)h->sp_chainpos.p,
+                                   (const uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p, S0);
+                for (uint32_t D = 1; D < longest; D *= 2) {
+                    hipLaunchKernelGGL(k_span_rs_step, grid, dim3(256), 0, st, (const uint32_t*)h->sp_chainpos.p, (const uint16_t*)S0, S1, D);
+                    std::swap(S0, S1);
+                }
+                hipLaunchKernelGGL(k_span_rs_out, grid, dim3(256), 0, st, (const uint32_t*)h->sp_chain.p, (const uint16_t*)S0, (uint8_t*)h->sp_tails.p);
+            } else {
+                hipLaunchKernelGGL(k_span_resolve, dim3((uint32_t)elig.size()), dim3(FP_THREADS), 0, st, (const uint32_t*)h->sp_chain.p,
+                                   (const uint32_t*)h->sp_chainoff.p, (uint8_t*)h->sp_tails.p, (const uint8_t*)h->sp_tails_b.p);
+            }
         }
         if (n_items)
-            hipLaunchKernelGGL(k_span_fix, dim3(n_items), dim3(64), 0, st, (const fl_fix_item*)h->sp_items.p, pool,
+            hipLaunchKernelGGL(k_span_fix, dim3(n_items / FP_FIX_WAVES), dim3(64 * FP_FIX_WAVES), 0, st, (const fl_fix_item*)h->sp_items.p, pool,
                                (const uint8_t*)h->sp_tails.p, d_out, container, h->crc, (uint32_t*)h->sp_part.p);
     }
     // the footers of the streams whose chain is whole (one small gather instead of a copy per stream)
@@ -1128,7 +1165,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     if (dbg) fprintf(stderr, "[spans] %.3f ms: sync 3 done\n", since());
     // ---- run B as run A, the checksum, the footer
-    const uint32_t pow_piece = fl_crc_xpow8n(h->crc.xpow8, FP_PIECE);
+    const uint32_t pow_piece = fl_crc_xpow8n(h->crc.xpow8, FP_FIX_ITEM);
     int done = 0;
     std::vector<fl_span_fin> fin;
     for (size_t k = 0; k < elig.size(); k++) {
@@ -1148,7 +1185,7 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         for (uint32_t q = item_first[k]; q < item_first[k + 1] && ok; q++) {
             const uint32_t pc = part[2 * (size_t)q], plen = part[2 * (size_t)q + 1];
             if (container == 1) {
-                crc = fl_crc_mulmod(crc, plen == FP_PIECE ? pow_piece : fl_crc_xpow8n(h->crc.xpow8, plen)) ^ pc;
+                crc = fl_crc_mulmod(crc, plen == FP_FIX_ITEM ? pow_piece : fl_crc_xpow8n(h->crc.xpow8, plen)) ^ pc;
             } else if (container == 2) {
                 adB = (adB + adA * plen + (pc >> 16)) % 65521u;
                 adA = (adA + (pc & 0xffff)) % 65521u;
@@ -1258,7 +1295,7 @@ int flate_hip_destroy(flate_hip_handle h) {
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     for (DevBuf* b : {&h->sp_points, &h->sp_found, &h->sp_spans, &h->sp_res, &h->sp_cand, &h->sp_candoff, &h->sp_tails,
                       &h->sp_tails_b, &h->sp_chain, &h->sp_chainoff, &h->sp_pool, &h->sp_pooltab, &h->sp_poolctl, &h->sp_items,
-                      &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin})
+                      &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin, &h->sp_chainpos, &h->sp_rs})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
                       &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->wchunks, &h->swins, &h->wexit, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,

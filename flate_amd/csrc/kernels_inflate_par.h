@@ -1487,42 +1487,57 @@ __global__ __launch_bounds__(FP_THREADS, 1) void k_inflate_span(const uint8_t* _
 struct __attribute__((aligned(4))) fl_u4a {  // four words at a word-aligned address
     uint32_t x[4];
 };
+#define FP_FIX_LANE 1024u                 // bytes per lane
+#define FP_FIX_ITEM (64u * FP_FIX_LANE)   // ... and item (a wave): a piece of the pool (16 KiB items, 256 bytes a lane: 0.84 -> 1.21 ms)
+#define FP_FIX_WAVES 4u                   // items per workgroup: of ONE span, whose history (the true tail before it) they share in LDS
 struct fl_fix_item {
     uint64_t dst;    // of the item's first byte in the output buffer
     uint32_t span;   // whose pieces
-    uint32_t local;  // offset of the item in the span's output (a multiple of FP_PIECE)
-    uint32_t len;    // <= FP_PIECE
+    uint32_t local;  // offset of the item in the span's output (a multiple of FP_FIX_ITEM)
+    uint32_t len;    // <= FP_FIX_ITEM
     uint32_t kind;
     uint32_t prev;   // kind 2: the span before it in the chain
     uint32_t pad;
 };
-__global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__ items, fl_span_pool pool,
+__global__ __launch_bounds__(64 * FP_FIX_WAVES) void k_span_fix(const fl_fix_item* __restrict__ items, fl_span_pool pool,
                                                  const uint8_t* __restrict__ tails, uint8_t* out, int container,
                                                  fl_crc_consts cc, uint32_t* __restrict__ part /* [n_items][2] */) {
     __shared__ uint32_t tab[4][256];
-    const fl_fix_item it = items[blockIdx.x];
-    const uint32_t lane = threadIdx.x;
+    // the history of the workgroup's items (all of one span): a byte that depends on it is a lookup here, not a gather from L2 --
+    // in text half of all bytes are such, a cache line each from L2 (the tails of the spans a CU works on do not fit its L1)
+    __shared__ uint32_t T32[FP_TAIL / 4];
+    const uint32_t item_no = blockIdx.x * FP_FIX_WAVES + (threadIdx.x >> 6);
+    const fl_fix_item it = items[item_no];
+    const uint32_t lane = threadIdx.x & 63u;
     if (container == 1) {
-        for (uint32_t t = lane; t < 256; t += 64) {
+        const uint32_t t = threadIdx.x;
+        {
             uint32_t c = t;
             for (int k = 0; k < 8; k++) c = (c & 1) ? (FL_CRC_POLY ^ (c >> 1)) : (c >> 1);
             tab[0][t] = c;
         }
-        fl_wave_lds_sync();
+        __syncthreads();
         for (int k = 1; k < 4; k++) {
-            for (uint32_t t = lane; t < 256; t += 64) {
-                const uint32_t c = tab[k - 1][t];
-                tab[k][t] = tab[0][c & 0xff] ^ (c >> 8);
-            }
-            fl_wave_lds_sync();
+            const uint32_t c = tab[k - 1][t];
+            tab[k][t] = tab[0][c & 0xff] ^ (c >> 8);
+            __syncthreads();
         }
     }
-    const uint32_t lo = min(it.len, lane * 1024u), hi = min(it.len, lane * 1024u + 1024u);
+    {
+        const fl_fix_item it0 = items[blockIdx.x * FP_FIX_WAVES];  // (the host pads a span's items to whole workgroups)
+        if (it0.kind >= 2) {
+            const uint4* tg = (const uint4*)(tails + (uint64_t)it0.prev * FP_TAIL);
+            for (uint32_t i = threadIdx.x; i < FP_TAIL / 16; i += 64 * FP_FIX_WAVES) ((uint4*)T32)[i] = tg[i];
+        }
+        __syncthreads();
+    }
+    const uint8_t* T = (const uint8_t*)T32;
+    const uint32_t lo = min(it.len, lane * FP_FIX_LANE), hi = min(it.len, lane * FP_FIX_LANE + FP_FIX_LANE);
     uint8_t* D = out + it.dst;
-    const uint8_t* A = it.kind ? pool.base + (uint64_t)pool.tab[(uint64_t)it.span * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE : D;
-    const uint8_t* T = it.kind >= 2 ? tails + (uint64_t)it.prev * FP_TAIL : tails;
+    const uint32_t in_piece = it.local & (FP_PIECE - 1u);  // (an item is a part of a piece)
+    const uint8_t* A = it.kind ? pool.base + (uint64_t)pool.tab[(uint64_t)it.span * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE + in_piece : D;
     // run B's bytes: in place, or in its pieces (which lie as run A's do: the same shift brings both to the output's words)
-    const uint8_t* Bp = it.kind == 3 ? pool.base + (uint64_t)pool.tab[(uint64_t)(it.pad + it.span) * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE : D;
+    const uint8_t* Bp = it.kind == 3 ? pool.base + (uint64_t)pool.tab[(uint64_t)(it.pad + it.span) * FP_MAX_PIECES + (it.local >> FP_PIECE_LOG)] * FP_PIECE + in_piece : D;
     uint32_t c = 0xffffffffu, adA = 0, adB = 0;
     auto one = [&](uint32_t i) {  // byte i of the item
         uint32_t v = A[i];
@@ -1622,21 +1637,21 @@ __global__ __launch_bounds__(64) void k_span_fix(const fl_fix_item* __restrict__
     const uint32_t after = it.len - hi;
     if (container == 1) {
         c = (hi > lo) ? ~c : 0u;  // crc of an empty slice is 0
-        const uint32_t full = after >> 10, tail = after & 1023u;
+        // x^(8 after): `after` is a multiple of the lane's share but for the item's last lanes -- a few factors
         uint32_t tpow = 0x80000000u;
-        for (int j = 0; j < 10; j++)
-            if (tail & (1u << j)) tpow = fl_crc_mulmod(cc.xpow8[j], tpow);
-        c = fl_crc_mulmod(fl_crc_mulmod(c, cc.pow1024[full]), tpow);
+        for (int j = 0; j < 16; j++)
+            if (after & (1u << j)) tpow = fl_crc_mulmod(cc.xpow8[j], tpow);
+        c = fl_crc_mulmod(c, tpow);
         c = fl_wave_xor(c);
-        if (lane == 0) part[2 * (uint64_t)blockIdx.x] = c;
+        if (lane == 0) part[2 * (uint64_t)item_no] = c;
     } else if (container == 2) {
         // (<= 1024 bytes per lane: adB < 2^28) pieces with a = b = 0 start, lanes combined in order
         const uint32_t Bm = (uint32_t)(((uint64_t)adB + (uint64_t)adA * after) % 65521u);
         const uint32_t Am = fl_wave_sum(adA) % 65521u;  // <= 65536 * 255
         const uint32_t Bs = fl_wave_sum(Bm) % 65521u;
-        if (lane == 0) part[2 * (uint64_t)blockIdx.x] = Am | (Bs << 16);
+        if (lane == 0) part[2 * (uint64_t)item_no] = Am | (Bs << 16);
     }
-    if (lane == 0) part[2 * (uint64_t)blockIdx.x + 1] = it.len;
+    if (lane == 0) part[2 * (uint64_t)item_no + 1] = it.len;
 }
 
 // The footers of the streams that came out of the spans (one thread each; off = ~0: none), and what the host found:
@@ -1725,4 +1740,59 @@ __global__ __launch_bounds__(FP_THREADS) void k_span_resolve(const uint32_t* __r
         __syncthreads();
         cur ^= 1;
     }
+}
+
+// ------------------------------------------------------------------ the true tails, all spans at once (round 5)
+// k_span_resolve walks a stream's chain span after span (one workgroup, 3.5 us a span: 0.87 ms for 248 spans).  A tail in SYMBOLS
+// (below 256: a byte; 256 + h: byte h of the tail BEFORE) is a map from the tail before it to itself, and maps compose: after a
+// step with stride D the symbols of the span at chain position j refer to the tail at position j - 2 D (Hillis-Steele: log2 of
+// the chain's length steps, every span in every step, 64 KiB of symbols a span and step).  Positions below the stride hold bytes
+// only: a stream's first span has no history.
+//   S0 from the two planes (a, b): a == b: the byte; else 256 + (((a ^ b) - 1) << 8 | a)
+__global__ __launch_bounds__(256) void k_span_rs_init(const uint32_t* __restrict__ chain, const uint32_t* __restrict__ pos,
+                                                      const uint8_t* __restrict__ tails_a, const uint8_t* __restrict__ tails_b,
+                                                      uint16_t* __restrict__ S0) {
+    const uint32_t g = blockIdx.x, i0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
+    const uint32_t sp = chain[g];
+    const uint2 a = *(const uint2*)(tails_a + (uint64_t)sp * FP_TAIL + i0);
+    const uint2 b = pos[g] ? *(const uint2*)(tails_b + (uint64_t)sp * FP_TAIL + i0) : a;
+    const uint32_t aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t av = (aw[k >> 2] >> (8 * (k & 3))) & 0xffu, bv = (bw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        const uint32_t x = av ^ bv;
+        const uint32_t sy = x ? 256u + ((((x - 1u) << 8) | av) & (FP_TAIL - 1u)) : av;
+        if (k & 1) o[k >> 1] |= sy << 16; else o[k >> 1] = sy;
+    }
+    *(uint4*)(S0 + (uint64_t)g * FP_TAIL + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(256) void k_span_rs_step(const uint32_t* __restrict__ pos, const uint16_t* __restrict__ Sin,
+                                                      uint16_t* __restrict__ Sout, uint32_t D) {
+    const uint32_t g = blockIdx.x, i0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
+    const uint4 v = *(const uint4*)(Sin + (uint64_t)g * FP_TAIL + i0);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (pos[g] >= D) {
+        const uint16_t* P = Sin + (uint64_t)(g - D) * FP_TAIL;  // (the same stream: its chain is contiguous)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t sy = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            if (sy >= 256u) {
+                const uint32_t t = P[sy - 256u];
+                w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | (t << (16 * (k & 1)));
+            }
+        }
+    }
+    *(uint4*)(Sout + (uint64_t)g * FP_TAIL + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// ... and the bytes they have become, where k_span_fix looks for the true tails (plane A's)
+__global__ __launch_bounds__(256) void k_span_rs_out(const uint32_t* __restrict__ chain, const uint16_t* __restrict__ S,
+                                                     uint8_t* __restrict__ tails_a) {
+    const uint32_t g = blockIdx.x, i0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
+    const uint4 v = *(const uint4*)(S + (uint64_t)g * FP_TAIL + i0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) o[k >> 2] |= ((w[k >> 1] >> (16 * (k & 1))) & 0xffu) << (8 * (k & 3));
+    *(uint2*)(tails_a + (uint64_t)chain[g] * FP_TAIL + i0) = make_uint2(o[0], o[1]);
 }
