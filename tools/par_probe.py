@@ -21,7 +21,7 @@ add("zeros4M-gz", bytes(4 << 20), 6, 31); add("zeros100K", bytes(100000))
 add("rand1M", rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes())
 add("huff-only", text[:1 << 20], 6, -15, zlib.Z_HUFFMAN_ONLY); add("rle", text[:1 << 20], 6, -15, zlib.Z_RLE)
 add("fixed", text[:200000], 6, -15, zlib.Z_FIXED)
-add("small", text[:20000]); add("abab", (b"ab" * 300000)); add("period7", (b"abcdefg" * 100000), 9)
+add("rec1M", synth._records(4242, 1 << 20).tobytes()); add("small", text[:20000]); add("abab", (b"ab" * 300000)); add("period7", (b"abcdefg" * 100000), 9)
 bad = 0
 for cont in (0, 1, 2):
     grp = [c for c in cases if c[3] == cont]
@@ -45,7 +45,7 @@ if os.environ.get("FL_PAR_EACH"):
         prof = eng.profile_read()
         print("%-14s" % c[0], {k: round(v[0], 3) for k, v in prof.items()}, "redo reason", int(eng.phase_cycles()[60]))
 if os.environ.get("FL_PAR_PROF"):
-    only = [c for c in cases if c[0] == "text1M-l6"]
+    only = [c for c in cases if c[0] == os.environ.get("FL_PAR_CASE", "text1M-l6")]
     tz = eng.phase_cycles().astype(np.int64)
     eng.decompress_many([only[0][2]], 0, 0, caps=[len(only[0][1]) + 64])
     t = eng.phase_cycles().astype(np.int64) - tz
