@@ -982,6 +982,11 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #define PZ_W2
 #define PZ_W3 "s_waitcnt lgkmcnt(0)\n\t"
 #endif
+#ifdef PZ_EARLY  // experiment: a burst ends after six or twelve steps when fewer than PZ_EARLY lanes still walk
+#define PZ_EARLY_EXIT "s_bcnt1_i32_b64 vcc_lo, exec\n\ts_cmp_lt_u32 vcc_lo, " PZ_STR(PZ_EARLY) "\n\ts_cbranch_scc1 .Lpz_done_%=\n\t"
+#else
+#define PZ_EARLY_EXIT
+#endif
 #define PZ_RSTEP(QC, QN, QNN, WC0, WC1, WN0, WN1, XC, XN, H)                  \
     PZ_W1                                                                      \
     "v_lshl_add_u32 %[a1], %[" QN "], 1, %[prvb]\n\t"                          \
@@ -1017,6 +1022,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                             PZ_RSTEP("q0", "q1", "q2", "wb0", "wb1", "wa0", "wa1", "xb", "xa", "h0")
                             PZ_RSTEP("q1", "q2", "q0", "wa0", "wa1", "wb0", "wb1", "xa", "xb", "h1")
                             PZ_RSTEP("q2", "q0", "q1", "wb0", "wb1", "wa0", "wa1", "xb", "xa", "h2")
+                            PZ_EARLY_EXIT  // (behind the six steps: a burst always makes some)
                             ".endr\n\t"
                             ".Lpz_done_%=:\n\t"
                             "s_waitcnt lgkmcnt(0)\n\t"

@@ -1,2 +1,2 @@
 cd /root/repo
-bash tools/run_variants.sh 2>&1 | tee gpurun_out/r05_variants_a.txt
+timeout 600 bash tools/run_variants.sh 2>&1 | tee gpurun_out/r05_variants_a.txt
