@@ -256,6 +256,9 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #ifndef PZ_ROT
 #define PZ_ROT 3                 // the burst is PZ_ROT x 6 steps, registers rotating (0: the two-role burst of round 4, PZ_UNROLL steps)
 #endif
+#ifndef PZ_RUNSKIP
+#define PZ_RUNSKIP 0                // 1: a call inside a run of one byte takes the run's members below p - 1 together (bit-exact; sparse zeros 3 % faster, text 1 % slower: off)
+#endif
 #ifndef PZ_TRANS_ITERS
 #define PZ_TRANS_ITERS 1         // automaton moves per lane and slow block (runs of literals)
 #endif
@@ -1161,16 +1164,50 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                         // would be undefined, bit 63 of ~0 stands for "8")
                         l = min(l + (x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u), maxlen);
                         cnt = q >= lo ? crem : 0u;            // the walk goes on behind the candidate ...
+                        bool runhit = false;  // the candidate is the position before p and it is the best so far
                         if (l >= FL_MIN_MATCH && l > best) {  // deflate.zig:254-261
                             PZ_EV(6);
                             best = l;
                             bdist = p - qh;
+                            runhit = bdist == 1u;
                             if (l >= nice || l >= maxlen) {
                                 cnt = 0;  // ... unless the match is good enough / nothing longer is possible
                             } else {
                                 PZ_SET_FILTER(l - 3u);
                             }
                         }
+#if PZ_RUNSKIP
+                        // The candidate right before p matched l bytes and the walk goes on (l < nice, l < maxlen): p starts a
+                        // run of l bytes b that ends inside the lookahead, and so does every position below p - 1 as far down
+                        // as the bytes are b -- each of them is the chain's next member (same four bytes, consecutive positions),
+                        // matches exactly l bytes (its byte number l is still b, p's is not) and so changes nothing but the
+                        // budget (deflate.zig:248-263).  They are taken together: k of them, as far as the run, the budget and
+                        // the distance go; the walk goes on behind the lowest.  (Zero padding, sparse data, records: at level 6
+                        // such a call walked its 128 candidates one LDS round trip at a time.)
+                        if (cnt != 0 && runhit) {
+                            const uint32_t c0 = p - 1u;  // (= the candidate just measured)
+                            const uint32_t bp = (pz_lds4(win32, p) & 0xffu) * 0x01010101u;
+                            const uint32_t fl_ = max(lo, c0 > cnt ? c0 - cnt : 0u);
+                            uint32_t t = c0;
+                            while (t > fl_) {
+                                const uint32_t stp = min(8u, t - fl_);
+                                uint32_t w0, w1;
+                                fl_lds_load8(win32, t - stp, w0, w1);  // bytes t - stp .. t - stp + 7: the first stp of them count
+                                uint64_t xx = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                                if (stp < 8u) xx &= (1ull << (8u * stp)) - 1ull;
+                                if (xx) {
+                                    t -= (uint32_t)(__builtin_clzll(xx) - (64 - 8 * (int)stp)) >> 3;  // the equal bytes right below t
+                                    break;
+                                }
+                                t -= stp;
+                            }
+                            const uint32_t k = c0 - t;
+                            if (k) {
+                                q = prv[t];
+                                cnt = q >= lo ? cnt - k : 0u;
+                            }
+                        }
+#endif
                         qh = PZ_NOHIT;
                     }
 #ifdef PZ_PROF
