@@ -66,12 +66,19 @@
 #define FP_WBITS (64 * FP_SUBW)                  // bits per wave and round
 #define FP_WIN_BYTES (FP_WAVES * FP_WBITS / 8)   // compressed bytes per round
 #define FP_STAGE_DW (FP_WIN_BYTES / 4 + 8)       // + the bytes the last tokens reach into
+#ifndef FP_TOK_CAP
 #define FP_TOK_CAP 512                           // tokens per wave and round
+#endif
+#ifndef FP_JOIN_BITS
 #define FP_JOIN_BITS 1024                        // bits of a wave's range within which an entering path must join
+#endif
 #define FP_MAX_FIX 96                            // tokens an entering path may take before it joins
 #define FP_ENTRIES 48                            // a token has at most 48 bits: entry bit < 48
 #define FP_OUT_CAP 16384u                        // output bytes per round
 #define FP_RING (32768u + FP_OUT_CAP)            // history + window
+#ifndef FP_PTR_EXTRA
+#define FP_PTR_EXTRA 0u
+#endif
 #define FP_RES 0xffffu                           // ptr value: byte is final
 #define FP_DST_BITS 10                           // bits of the distance table
 #define FP_NOJOIN 0xffffu
@@ -98,7 +105,7 @@ struct fp_shared {
     uint32_t fixtok[FP_WAVES][FP_MAX_FIX];
     uint16_t fixpos[FP_WAVES][FP_MAX_FIX];
     uint8_t ring[FP_RING];
-    uint16_t ptr[FP_OUT_CAP];
+    uint16_t ptr[FP_OUT_CAP + FP_PTR_EXTRA];  // (+ what the 16-bit ring of the other mode needs beyond ring + ptr)
     uint32_t dst_big[1u << FP_DST_BITS];  // this kernel's distance table (k_inflate's has 8 bits: one pass in six met a longer code)
     // per wave
     uint32_t w_ntok[FP_WAVES], w_xkind[FP_WAVES], w_xpos[FP_WAVES];
@@ -245,7 +252,9 @@ __device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  
 // 256 + h "whatever byte h of the 32 KiB before the span is", 0xC000 + o "not resolved yet: what the window's byte o is" -- so one
 // decode gives what runs A and B gave (a = e & 255, b = a ^ (e >> 8): the two fillings of the history, byte for byte).  The 16-bit
 // ring lies where the byte ring and the pointers of the other mode lie; a round makes 8 KiB at most instead of 16.
+#ifndef FP_SYM_OUT_CAP
 #define FP_SYM_OUT_CAP 8192u
+#endif
 #define FP_SYM_RING (32768u + FP_SYM_OUT_CAP)
 #define FP_SYM_PTR 0xC000u
 #ifndef FP_SYM_WBITS
@@ -319,7 +328,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
     // unit: the stream (MODE 0) / the span (MODE 1); b_pool: run B at the same time as run A, its bytes to the pool as well
     // SYM: one decode in symbols, both planes to the pool (plane B's pieces: table rows b_base + unit) and both tails
     constexpr uint32_t OUT_CAP = SYM ? FP_SYM_OUT_CAP : FP_OUT_CAP, RING = 32768u + OUT_CAP;
-    static_assert(offsetof(fp_shared, ptr) == offsetof(fp_shared, ring) + FP_RING && 2u * FP_SYM_RING <= FP_RING + 2u * FP_OUT_CAP, "the 16-bit ring lies over ring + ptr");
+    static_assert(offsetof(fp_shared, ptr) == offsetof(fp_shared, ring) + FP_RING && 2u * FP_SYM_RING <= FP_RING + 2u * (FP_OUT_CAP + FP_PTR_EXTRA), "the 16-bit ring lies over ring + ptr");
     FL_LDS uint16_t* ring16 = (FL_LDS uint16_t*)sh->ring;
     FL_LDS fl_inflate_ws* ws = &sh->ws;
     fl_span sp;
