@@ -252,6 +252,9 @@ __device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  
 // 256 + h "whatever byte h of the 32 KiB before the span is", 0xC000 + o "not resolved yet: what the window's byte o is" -- so one
 // decode gives what runs A and B gave (a = e & 255, b = a ^ (e >> 8): the two fillings of the history, byte for byte).  The 16-bit
 // ring lies where the byte ring and the pointers of the other mode lie; a round makes 8 KiB at most instead of 16.
+#ifndef FP_ADAPT_WBITS
+#define FP_ADAPT_WBITS 0
+#endif
 #ifndef FP_SYM_OUT_CAP
 #define FP_SYM_OUT_CAP 8192u
 #endif
@@ -965,6 +968,17 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                     sh->wp = wp + nout;
                     sh->blk_done = sh->r_kind == FP_X_EOB;
                     if (sh->r_kind == FP_X_FULL && wbits > 512) sh->wbits = wbits >> 1;  // 512 bits hold at most 512 tokens
+#if FP_ADAPT_WBITS
+                    // A round that was CUT (its output was full) decoded bits it had no room for: the next rounds take what this
+                    // one used and an eighth (data that compresses well: records, markup, runs); a round that used all its bits
+                    // grows by a quarter again.
+                    else if (sh->r_kind == FP_X_CUT) {
+                        const uint32_t want = (((sh->r_next + (sh->r_next >> 3)) / FP_WAVES) + 63u) & ~63u;
+                        sh->wbits = min(wbits, max(512u, want));
+                    } else if (sh->r_kind == FP_X_NORMAL && wbits < (SYM ? FP_SYM_WBITS : (uint32_t)FP_WBITS)) {
+                        sh->wbits = min((SYM ? FP_SYM_WBITS : (uint32_t)FP_WBITS), ((wbits + (wbits >> 2)) + 63u) & ~63u);
+                    }
+#endif
                 }
                 __syncthreads();
                 FP_T(40);
