@@ -252,6 +252,9 @@ __device__ __forceinline__ uint32_t fp_ring_idx(uint32_t wbase, int32_t rel) {  
 // 256 + h "whatever byte h of the 32 KiB before the span is", 0xC000 + o "not resolved yet: what the window's byte o is" -- so one
 // decode gives what runs A and B gave (a = e & 255, b = a ^ (e >> 8): the two fillings of the history, byte for byte).  The 16-bit
 // ring lies where the byte ring and the pointers of the other mode lie; a round makes 8 KiB at most instead of 16.
+#ifndef FP_RESOLVE_SWEEPS
+#define FP_RESOLVE_SWEEPS 1
+#endif
 #ifndef FP_ADAPT_WBITS
 #define FP_ADAPT_WBITS 0
 #endif
@@ -902,6 +905,9 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                 // at those only)
                 uint32_t pend = nout > tid ? (1u << ((nout - tid + FP_THREADS - 1) / FP_THREADS)) - 1u : 0u;
                 for (uint32_t rr = 0;;) {
+                    // (several sweeps between two barriers: a position follows its chain on what the other threads have written
+                    // so far -- any order is right, a byte is written before its flag and read after it)
+                    for (int sweep = 0; sweep < FP_RESOLVE_SWEEPS && (sweep == 0 || pend != 0); sweep++) {
                     uint32_t todo = pend;
                     pend = 0;
                     while (todo) {
@@ -938,6 +944,7 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
                                 }
                             }
                         }
+                    }
                     }
                     const bool mine = pend != 0;
                     FP_CNT(51, 1);

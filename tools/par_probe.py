@@ -21,7 +21,9 @@ add("zeros4M-gz", bytes(4 << 20), 6, 31); add("zeros100K", bytes(100000))
 add("rand1M", rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes())
 add("huff-only", text[:1 << 20], 6, -15, zlib.Z_HUFFMAN_ONLY); add("rle", text[:1 << 20], 6, -15, zlib.Z_RLE)
 add("fixed", text[:200000], 6, -15, zlib.Z_FIXED)
-add("rec1M", synth._records(4242, 1 << 20).tobytes()); add("small", text[:20000]); add("abab", (b"ab" * 300000)); add("period7", (b"abcdefg" * 100000), 9)
+add("rec1M", synth._records(4242, 1 << 20).tobytes()); _rec = synth._records(4242, 1 << 20).tobytes()
+cases.append(("rec1M-ours", _rec, eng.compress_many([_rec], 0, 6)[0][0], 0))
+add("small", text[:20000]); add("abab", (b"ab" * 300000)); add("period7", (b"abcdefg" * 100000), 9)
 bad = 0
 for cont in (0, 1, 2):
     grp = [c for c in cases if c[3] == cont]
