@@ -194,6 +194,34 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
             }
         }
     }
+#ifdef WK_RANK_CHECK  // (built and measured in round 5: k_lz_links 4.8 -> 5.5 ms per GiB even on one chunk in eight; off)
+    if (WHICH == 1 && NARR == 4 && (c & 7u) == 0u) {
+        // A count says nothing about the order it was served in (o > p above never fires for it).  The links of the launch
+        // before this one do: a position's rank is its predecessor's + 1, and a position without a predecessor has rank 0 --
+        // or 1 when position 0, the chain's null, shares its bucket.  Two lanes of one exchange served out of lane order
+        // swap their ranks and are seen here.  Every position costs two dependent gathers (all positions of all
+        // chunks: 4.8 -> 8.3 ms per GiB for the four arrays; one in eight: 5.5): one chunk in eight is looked at, one position in
+        // eight of it -- an LDS that serves out of order does not do so once.
+        __syncthreads();  // (this workgroup's ranks are in memory)
+        const uint16_t* l4 = out_all + (uint64_t)c * (4u * FL_CHUNK_STRIDE);
+        constexpr uint32_t NCK = 65536u / (8u * 64u * FL_CHAIN_WAVES);  // positions per thread: their loads together, then the predecessors'
+        uint32_t qq[NCK], rr[NCK], rq[NCK];
+#pragma unroll
+        for (uint32_t u = 0; u < NCK; u++) {
+            const uint32_t p = 8u * (u * 64u * FL_CHAIN_WAVES + threadIdx.x) + ((c >> 3) & 7u);
+            qq[u] = p < Mpos ? l4[p] : 0u;
+            rr[u] = p < Mpos ? pv[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < NCK; u++) rq[u] = qq[u] ? pv[qq[u]] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < NCK; u++) overtaken = overtaken || (qq[u] ? rr[u] != rq[u] + 1u : rr[u] > 1u);
+#ifdef WK_RANKCHECK_DEBUG
+        if (overtaken) atomicAdd((unsigned long long*)&g_fl_prof[63], 1ull);
+        overtaken = false;
+#endif
+    }
+#endif
     // (k_lz_walk<true> takes the chunks with long runs of one byte, k_lz_walk<false> the others: cflag 2 / 0)
     if (WHICH == 0 && __syncthreads_or(runny != 0 ? 1 : 0) && threadIdx.x == 0) cflag[c] = 2u;
 #ifdef FL_CHAIN_FORCE_SLOW
