@@ -1052,6 +1052,10 @@ int try_span_inflate(flate_hip_ctx* h, hipStream_t st, const uint8_t* d_in, std:
         }
         if (ok && (pl.chain.empty() || !r1[pl.chain.back()].final_seen)) ok = false;
         if (dbg) fprintf(stderr, "[spans] stream %u: chain of %zu spans, %llu bytes, ok=%d\n", elig[k], pl.chain.size(), (unsigned long long)acc, (int)ok);
+        if (dbg)
+            for (uint32_t j = sp_first[k]; j < sp_first[k + 1]; j++)
+                fprintf(stderr, "[spans]    span %u: start %llu status %u (0: decoded; else why it gave up) end %llu out %llu final %u blocks / pieces %u\n", j,
+                        (unsigned long long)spans[j].start_bit, r1[j].status, (unsigned long long)r1[j].end_bit, (unsigned long long)r1[j].out_len, r1[j].final_seen, r1[j].n_pieces);
         if (!ok)
             for (uint32_t j = sp_first[k]; j < sp_first[k + 1]; j++) spans[j].live = 0;
         pl.ok = ok;

@@ -43,7 +43,7 @@
 
 // phase cycles of workgroup 0 (tuning aid, -DFL_PAR_PROF; read by tools/par_probe.py)
 #ifdef FL_PAR_PROF
-#define FP_WHY(n) (g_fl_prof[60] = (n), 1u)
+#define FP_WHY(n) (g_fl_prof[60] = (n), (uint32_t)(n))
 #define FP_T(slot)                                                        \
     do {                                                                  \
         const uint64_t t_now_ = __builtin_readcyclecounter();             \
@@ -55,7 +55,7 @@
         if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] += (v);  \
     } while (0)
 #else
-#define FP_WHY(n) 1u
+#define FP_WHY(n) ((uint32_t)(n))  // (the reason a workgroup gives a stream up for: a span reports it as its status; 1: something else)
 #define FP_T(slot)
 #define FP_CNT(slot, v)
 #endif
@@ -1004,8 +1004,12 @@ __device__ __forceinline__ void fp_body(const uint8_t* __restrict__ in, const fl
         if (tid == 0) {
             if (MODE == 0)
                 status[c] = FL_PAR_REDO;
-            else
-                sres[unit].status = 1;
+            else {
+                sres[unit].status = sh->redo ? sh->redo : 1u;
+                sres[unit].end_bit = sh->bitpos;  // (where it gave up: FLATE_HIP_SPAN_DEBUG prints it)
+                sres[unit].out_len = sh->wp;
+                sres[unit].n_pieces = sh->nblk;
+            }
         }
         return;
     }
