@@ -65,3 +65,21 @@ def test_synth_text_properties():
     assert s.size == 1 << 21
     off = synth.split_offsets(200000, 65535)
     assert list(off) == [0, 65535, 131070, 196605, 200000]
+
+
+def test_every_tuning_variable_the_library_reads_is_documented_and_reloadable():
+    """The library reads its FLATE_HIP_* variables once per handle (flate_hip.hip, read_knobs): every one of them is described in
+    INTEGRATION.md section 7 and is in the list the Python engine watches (Engine._KNOBS: a change between two calls makes the
+    handle read them again -- tests and probes rely on it)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "flate_amd", "csrc", "flate_hip.hip")).read()
+    names = sorted(set(re.findall(r'getenv\("(FLATE_HIP_[A-Z_0-9]+)"\)', src)))
+    assert len(names) >= 12, names
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    from flate_amd.engine import Engine
+    missing_doc = [n for n in names if n not in doc]
+    missing_knob = [n for n in names if n not in Engine._KNOBS]
+    assert not missing_doc, missing_doc
+    assert not missing_knob, missing_knob
