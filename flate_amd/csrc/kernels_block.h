@@ -51,51 +51,68 @@ __device__ __forceinline__ void fl_plan_marker(fl_block_plan* plan) {
 
 // ------------------------------------------------------------------ histograms
 // huffman-only mode: 256-bin byte histogram of each 65535-byte block
-// (block_writer.zig:575-585).  One workgroup (256 threads) per block, 16-byte loads; every wave keeps FL_HIST_COPIES
-// sub-histograms in LDS, a lane adds to copy (lane mod FL_HIST_COPIES): lanes that meet in one counter are served one after the
-// other, and on runs of one byte (zero padding, sparse zeros) all 64 lanes of an instruction used to meet.
-#define FL_HIST_COPIES 8
+// (block_writer.zig:575-585).  One workgroup (256 threads) per block, 16-byte loads.  Every LANE has a histogram of its own
+// (64 copies, shared by the four waves' lanes of one number): 16-bit counters, two to a word (a copy sees 4 x 256 bytes at most),
+// the words of a copy swizzled by the copy's number -- lanes that count the same byte (text: a space, an e; padding: all of
+// them) hit 32 different banks, not one counter.  (Round 4: 8 copies per wave of 32-bit counters: an LDS atomic took 47 cycles
+// on text, the kernel 0.16 ms of config #4's 0.78.)
+#define FL_HIST_WORD(cp, bin) ((cp) * 128u + ((((bin) >> 1) ^ (cp)) & 127u))
 __global__ __launch_bounds__(256) void k_byte_hist(const uint8_t* __restrict__ in,
                                                    const fl_chunk* __restrict__ chunks,
                                                    const uint32_t* __restrict__ blk_chunk,
                                                    const fl_sblock* __restrict__ sblocks,
                                                    uint32_t* __restrict__ hist /* [n_blocks][320] */) {
-    __shared__ uint32_t sh[4 * FL_HIST_COPIES][256];
+    __shared__ uint32_t sh[64 * 128];
     const uint32_t b = blockIdx.x;
     const fl_chunk ck = chunks[blk_chunk[b]];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t cp = wave * FL_HIST_COPIES + (tid & (FL_HIST_COPIES - 1));  // (indexed, not through a pointer: the atomics stay LDS instructions)
-    for (uint32_t i = tid; i < 4 * FL_HIST_COPIES * 256; i += 256) (&sh[0][0])[i] = 0;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cp = tid & 63u;
+    for (uint32_t i = tid; i < 64 * 128; i += 256) sh[i] = 0;
     __syncthreads();
+    bool wide = false;  // a block of more than 65535 bytes (never made: the counters would not hold it)
     if (!ck.skip) {
         const fl_sb sb = fl_simple_block(ck, sblocks, b);
         const uint32_t len = sb.len;
         const uint8_t* src = in + ck.in_off + sb.start;
+        wide = len > 65535u;
+        auto count = [&](uint32_t byte) { atomicAdd(&sh[FL_HIST_WORD(cp, byte)], 1u << (16u * (byte & 1u))); };
         // head bytes up to 16-byte alignment, then 16-byte loads
         const uint32_t mis = (uint32_t)((16 - ((uintptr_t)src & 15)) & 15);
         const uint32_t head = mis < len ? mis : len;
-        if (tid < head) atomicAdd(&sh[cp][src[tid]], 1u);
-        const uint32_t body = (len - head) >> 4;
-        const uint4* src16 = (const uint4*)(src + head);
-        for (uint32_t i = tid; i < body; i += 256) {
-            const uint4 v = src16[i];
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        if (!wide) {
+            if (tid < head) count(src[tid]);
+            const uint32_t body = (len - head) >> 4;
+            const uint4* src16 = (const uint4*)(src + head);
+            for (uint32_t i = tid; i < body; i += 256) {
+                const uint4 v = src16[i];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t w = w4[k];
-                atomicAdd(&sh[cp][w & 0xff], 1u);
-                atomicAdd(&sh[cp][(w >> 8) & 0xff], 1u);
-                atomicAdd(&sh[cp][(w >> 16) & 0xff], 1u);
-                atomicAdd(&sh[cp][w >> 24], 1u);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w = w4[k];
+                    count(w & 0xff);
+                    count((w >> 8) & 0xff);
+                    count((w >> 16) & 0xff);
+                    count(w >> 24);
+                }
             }
+            const uint32_t tail0 = head + (body << 4);
+            if (tail0 + tid < len) count(src[tail0 + tid]);
         }
-        const uint32_t tail0 = head + (body << 4);
-        if (tail0 + tid < len) atomicAdd(&sh[cp][src[tail0 + tid]], 1u);
     }
     __syncthreads();
     uint32_t v = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4 * FL_HIST_COPIES; k++) v += sh[k][tid];
+#pragma unroll 8
+    for (uint32_t k = 0; k < 64; k++) v += (sh[FL_HIST_WORD(k, tid)] >> (16u * (tid & 1u))) & 0xffffu;
+    if (wide) {  // (one byte at a time, 32-bit counters: what the kernel was before it had any copies)
+        __syncthreads();
+        sh[tid] = 0;
+        __syncthreads();
+        const fl_sb sb = fl_simple_block(ck, sblocks, b);
+        const uint8_t* src = in + ck.in_off + sb.start;
+        for (uint32_t i = tid; i < sb.len; i += 256) atomicAdd(&sh[src[i]], 1u);
+        __syncthreads();
+        v = sh[tid];
+    }
     hist[(uint64_t)b * 320 + tid] = v;
 }
 
@@ -586,7 +603,9 @@ __global__ __launch_bounds__(64 * FL_OFFS_MAX_WAVES) void k_offsets(const fl_chu
 // dword of a wave's range can be shared with a neighbour; those are atomic ORs
 // into the pre-zeroed output.
 #define FL_ENC_WAVES 4
-#define FL_STG_DW 112
+#define FL_STG_DW 128  // (64 items of 60 bits at most + what is carried over)
+// items that hold the block's symbols: a token each, or four bytes each (huffman-only)
+#define FL_ENC_UNITS(TOKENS, n_sym) ((TOKENS) ? (n_sym) : (((n_sym) + 3u) >> 2))
 
 struct fl_item {
     uint64_t v;
@@ -606,12 +625,23 @@ __device__ __forceinline__ fl_item fl_block_item(uint32_t i, uint32_t n_hdr, uin
         const uint32_t rem = hdr_nbits - 8 * i;
         it.n = rem < 8 ? rem : 8;
         it.v = hdr[i] & ((1u << it.n) - 1);
-    } else if (i < n_hdr + n_sym) {
+    } else if (i < n_hdr + FL_ENC_UNITS(TOKENS, n_sym)) {
         const uint32_t k = i - n_hdr;
         if (!TOKENS) {
-            const uint32_t e = lit_lds[bytes[k]];
-            it.v = e & 0xffff;
-            it.n = e >> 16;
+            // FOUR bytes an item (huffman-only: 4 x 15 bits at most): the scan, the placing and the LDS traffic of the packing
+            // are paid per item, not per byte (round 5: config #4's k_encode 0.35 ms)
+            uint64_t v = 0;
+            uint32_t n = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (4 * k + j < n_sym) {
+                    const uint32_t e = lit_lds[bytes[4 * k + j]];
+                    v |= (uint64_t)(e & 0xffff) << n;
+                    n += e >> 16;
+                }
+            }
+            it.v = v;
+            it.n = n;
         } else {
             const uint32_t t = toks[k];
             if (!FL_TOK_IS_MATCH(t)) {
@@ -639,7 +669,7 @@ __device__ __forceinline__ fl_item fl_block_item(uint32_t i, uint32_t n_hdr, uin
                 it.n = n;
             }
         }
-    } else if (i == n_hdr + n_sym) {
+    } else if (i == n_hdr + FL_ENC_UNITS(TOKENS, n_sym)) {
         const uint32_t e = lit_lds[FL_EOB];
         it.v = e & 0xffff;
         it.n = e >> 16;
@@ -690,7 +720,7 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode(const uint8_t* __r
     const uint32_t hdr_nbits = plan->hdr_nbits;
     const uint32_t n_hdr = (hdr_nbits + 7) >> 3;
     const uint32_t n_sym = plan->tok_count;
-    const uint32_t n_items = n_hdr + n_sym + 1;
+    const uint32_t n_items = n_hdr + FL_ENC_UNITS(TOKENS, n_sym) + 1;
     const uint8_t* bytes = src + plan->tok_start;
     const uint32_t* toks = TOKENS ? tokens + ck.pos_off + plan->tok_start : nullptr;
     const uint8_t* hdr = plan->hdr;
@@ -813,7 +843,7 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode_wave(const uint8_t
     const uint32_t hdr_nbits = plan->hdr_nbits;
     const uint32_t n_hdr = (hdr_nbits + 7) >> 3;
     const uint32_t n_sym = plan->tok_count;
-    const uint32_t n_items = n_hdr + n_sym + 1;
+    const uint32_t n_items = n_hdr + FL_ENC_UNITS(TOKENS, n_sym) + 1;
     const uint8_t* bytes = src + plan->tok_start;
     const uint32_t* toks = TOKENS ? tokens + ck.pos_off + plan->tok_start : nullptr;
     const uint8_t* hdr = plan->hdr;
