@@ -524,6 +524,136 @@ FL_HD uint32_t fl_huff_bit_length(const fl_hcode* codes, const uint16_t* freq, u
     return total;
 }
 
+// One run of `count` equal code lengths `size` as generateCodegen writes it (block_writer.zig:118-165): the bytes go to `out`
+// (nullptr: only counted), the code-length codes used are counted in freq3 = {how often `size` itself, code 16, code 17 | 18 << 8}.
+FL_HD uint32_t fl_codegen_run(uint32_t size, int32_t count, uint8_t* out, uint32_t* n_size, uint32_t* n_16, uint32_t* n_17, uint32_t* n_18) {
+    uint32_t o = 0, k_size = 0, k16 = 0, k17 = 0, k18 = 0;
+    if (size != 0) {
+        if (out) out[o] = (uint8_t)size;
+        o++;
+        k_size++;
+        count--;
+        while (count >= 3) {
+            const int32_t n = count < 6 ? count : 6;
+            if (out) {
+                out[o] = 16;
+                out[o + 1] = (uint8_t)(n - 3);
+            }
+            o += 2;
+            k16++;
+            count -= n;
+        }
+    } else {
+        while (count >= 11) {
+            const int32_t n = count < 138 ? count : 138;
+            if (out) {
+                out[o] = 18;
+                out[o + 1] = (uint8_t)(n - 11);
+            }
+            o += 2;
+            k18++;
+            count -= n;
+        }
+        if (count >= 3) {
+            if (out) {
+                out[o] = 17;
+                out[o + 1] = (uint8_t)(count - 3);
+            }
+            o += 2;
+            k17++;
+            count = 0;
+        }
+    }
+    for (; count > 0; count--) {
+        if (out) out[o] = (uint8_t)size;
+        o++;
+        k_size++;
+    }
+    *n_size = k_size;
+    *n_16 = k16;
+    *n_17 = k17;
+    *n_18 = k18;
+    return o;
+}
+
+#if FL_PLAN_PARALLEL
+// The same on the GPU, by the wave's lanes (round 5: the serial form below was 40 % of the planner's time on a block without
+// matches -- 316 lengths, a dependent LDS load and a store each).  A RUN of equal lengths becomes its bytes independently of the
+// others; where they go is a prefix sum over the runs.  Slot i = 64 k + lane holds length i: a run is written by the lane of
+// its LAST length (run start by a running maximum over the run starts, offsets by a running sum of the runs' byte counts, both
+// scans per group of 64 with a carry).  The lengths are read before anything is written: the output overwrites them.
+static __device__ __forceinline__ uint32_t fl_plan_scan_max(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= (uint32_t)d) v = v > o ? v : o;
+    }
+    return v;
+}
+static __device__ __forceinline__ uint32_t fl_plan_scan_sum(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+FL_HD void fl_generate_codegen(fl_plan_ws* ws, uint32_t num_literals, uint32_t num_distances,
+                               const fl_hcode* lit_codes, const fl_hcode* dist_codes) {
+    const uint32_t lane = FL_PLAN_LANE();
+    const uint32_t n = num_literals + num_distances;
+    uint8_t* codegen = ws->codegen;
+    uint32_t* cnt32 = ws->pm_p;  // (scratch of the Huffman construction: free here) 19 counters
+    FL_PLAN_FOR(i, 0, num_literals) codegen[i] = (uint8_t)lit_codes[i].len;
+    FL_PLAN_FOR(i, 0, num_distances) codegen[num_literals + i] = (uint8_t)dist_codes[i].len;
+    FL_PLAN_FOR(i, 0, FL_NUM_CG) cnt32[i] = 0;
+    FL_PLAN_SYNC();
+    constexpr uint32_t G = (FL_NUM_LIT + FL_NUM_DIST + 63) / 64;  // groups of 64 slots
+    uint32_t cur[G], start_at[G], nbytes[G], off[G];
+    bool is_end[G];
+    uint32_t carry_max = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < G; k++) {
+        const uint32_t i = 64 * k + lane;
+        const bool in = i < n;
+        cur[k] = in ? codegen[i] : 0xffffu;
+        const uint32_t prev = (in && i) ? codegen[i - 1] : 0xfffeu, next = (in && i + 1 < n) ? codegen[i + 1] : 0xfffdu;
+        is_end[k] = in && next != cur[k];
+        const uint32_t st = (in && prev != cur[k]) ? i + 1 : 0u;  // (+ 1: 0 = not a start)
+        const uint32_t m = fl_plan_scan_max(st, lane);
+        start_at[k] = (m > carry_max ? m : carry_max) - 1u;  // the start of the run slot i lies in
+        const uint32_t gmax = (uint32_t)__shfl((int)m, 63, 64);
+        carry_max = gmax > carry_max ? gmax : carry_max;
+    }
+    uint32_t carry_sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < G; k++) {
+        const uint32_t i = 64 * k + lane;
+        uint32_t a, b, c, d;
+        nbytes[k] = is_end[k] ? fl_codegen_run(cur[k], (int32_t)(i - start_at[k] + 1u), nullptr, &a, &b, &c, &d) : 0u;
+        const uint32_t incl = fl_plan_scan_sum(nbytes[k], lane);
+        off[k] = carry_sum + incl - nbytes[k];
+        carry_sum += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    FL_PLAN_SYNC();  // (every lane has read its lengths)
+#pragma unroll
+    for (uint32_t k = 0; k < G; k++) {
+        if (is_end[k]) {
+            const uint32_t i = 64 * k + lane;
+            uint32_t k_size, k16, k17, k18;
+            (void)fl_codegen_run(cur[k], (int32_t)(i - start_at[k] + 1u), codegen + off[k], &k_size, &k16, &k17, &k18);
+            if (k_size) atomicAdd(&cnt32[cur[k]], k_size);
+            if (k16) atomicAdd(&cnt32[16], k16);
+            if (k17) atomicAdd(&cnt32[17], k17);
+            if (k18) atomicAdd(&cnt32[18], k18);
+        }
+    }
+    if (lane == 0) codegen[carry_sum] = FL_END_MARK;
+    FL_PLAN_SYNC();
+    FL_PLAN_FOR(i, 0, FL_NUM_CG) ws->cg_freq[i] = (uint16_t)cnt32[i];
+    FL_PLAN_SYNC();
+}
+#else
 // block_writer.zig:78-171.  lit_lens / dist_lens are read through the code tables.
 FL_HD void fl_generate_codegen(fl_plan_ws* ws, uint32_t num_literals, uint32_t num_distances,
                                const fl_hcode* lit_codes, const fl_hcode* dist_codes) {
@@ -580,6 +710,7 @@ FL_HD void fl_generate_codegen(fl_plan_ws* ws, uint32_t num_literals, uint32_t n
     }
     codegen[out_index] = FL_END_MARK;
 }
+#endif
 
 // tiny LSB-first bit sink for the block header (bit_writer.zig:63-79 semantics)
 struct fl_hdr_writer {
