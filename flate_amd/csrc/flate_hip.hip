@@ -680,6 +680,9 @@ int launch_checksum_side(flate_hip_ctx* h, uint32_t nb, const uint8_t* d_in, con
     return FLATE_HIP_OK;
 }
 
+#ifndef FL_ENC_WAVE_MIN_SLOTS_STREAM
+#define FL_ENC_WAVE_MIN_SLOTS_STREAM 32768u
+#endif
 int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t nb, uint32_t c0, const fl_chunk* dch,
                      const uint32_t* dbc, const fl_sblock* dsb, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_outlen,
                      int32_t* d_status) {
@@ -714,7 +717,9 @@ int enqueue_back_end(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32
         ProfScope ps(h, K_ENCODE);
         // many blocks (the chunk path: two plan slots per chunk): a wave per block, one pass over its tokens; few blocks
         // (long streams): a workgroup per block, its waves share the block
-        if (mode >= 4 && nb >= 8192u)
+        // (whole-stream passes: a block holds 32768 tokens and most slots are empty -- 256 streams of 1 MiB have 3072 blocks in 8448
+        // slots: four waves a block are faster than one until the blocks are many)
+        if (mode >= 4 && nb >= (prm.stream ? FL_ENC_WAVE_MIN_SLOTS_STREAM : 8192u))
             hipLaunchKernelGGL(k_encode_wave<true>, dim3((nb + FL_ENC_WAVES - 1) / FL_ENC_WAVES), dim3(64 * FL_ENC_WAVES), 0, st,
                                d_in, dch, dbc, (const fl_block_plan*)dpl, (const uint32_t*)h->tokens.p, (uint32_t*)d_out, nb,
                                (prm.stream || (nb & 1u)) ? 0u : 1u);
