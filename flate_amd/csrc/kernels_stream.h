@@ -258,6 +258,9 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_parse2(const fl_chun
 // ------------------------------------------------------------------ k_st_count
 // Round 5: when the anchors come from k_lz_parse<true> (kernels_parse.h: the demand-driven tokenizer walking the stream's windows),
 // all that is left of k_st_parse2 is its count: the tokens of the segment's marked anchors.
+#ifndef FL_CNT_U
+#define FL_CNT_U 8u
+#endif
 __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_count(const fl_chunk* __restrict__ chunks,
                                                                    const fl_piece* __restrict__ pieces,
                                                                    const fl_seg* __restrict__ segs,
@@ -274,14 +277,26 @@ __global__ __launch_bounds__(FL_PARSE_THREADS, 8) void k_st_count(const fl_chunk
     const uint32_t* desc = desc_all + ck.pos_off + h0;
     const uint32_t* gmarks = marks_all + ((ck.pos_off + h0) >> 5);
     uint32_t cnt = 0;
-    // a lane per position, 64 consecutive positions per wave and step: the marked lanes' descriptors lie in two or three lines
-    for (uint32_t r0 = tid & ~63u; r0 < len; r0 += FL_PARSE_THREADS) {
-        const uint32_t r = r0 + lane;
-        const uint64_t mk = (uint64_t)gmarks[r0 >> 5] | ((uint64_t)gmarks[(r0 >> 5) + 1] << 32);  // (wave-uniform)
-        if (((mk >> lane) & 1ull) && r >= rlo && r < len) {
-            const uint32_t d = desc[r];
-            cnt += d ? ((d >> 23) & 0xff) + 1 : 1;
+    // a lane per position, 64 consecutive positions per wave and step: the marked lanes' descriptors lie in two or three lines.
+    // FL_CNT_U steps' loads are in flight together (the marks of all of them, then the descriptors: a step used to be two
+    // dependent round trips to memory, 128 steps a wave)
+    for (uint32_t rb = tid & ~63u; rb < len; rb += FL_CNT_U * FL_PARSE_THREADS) {
+        uint64_t mk[FL_CNT_U];
+        uint32_t d[FL_CNT_U];
+#pragma unroll
+        for (uint32_t u = 0; u < FL_CNT_U; u++) {
+            const uint32_t r0 = rb + u * FL_PARSE_THREADS;
+            mk[u] = r0 < len ? ((uint64_t)gmarks[r0 >> 5] | ((uint64_t)gmarks[(r0 >> 5) + 1] << 32)) : 0ull;  // (wave-uniform)
         }
+#pragma unroll
+        for (uint32_t u = 0; u < FL_CNT_U; u++) {
+            const uint32_t r = rb + u * FL_PARSE_THREADS + lane;
+            const bool on = ((mk[u] >> lane) & 1ull) && r >= rlo && r < len;
+            d[u] = on ? desc[r] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < FL_CNT_U; u++)
+            if (d[u] != 0xffffffffu) cnt += d[u] ? ((d[u] >> 23) & 0xff) + 1 : 1;
     }
     cnt = fl_wave_sum(cnt);
     if (lane == 0) wsum[wave] = cnt;
