@@ -25,8 +25,6 @@
 #include "kernels_lz.h"
 #include "kernels_parse.h"
 #include "kernels_walk.h"
-#include "kernels_rank.h"
-#include "kernels_parse6.h"
 #include "kernels_stream.h"
 #include "stream_tables.h"
 
@@ -40,9 +38,6 @@ enum KernelId {
     K_LZ_MATCH,
     K_LZ_CHAIN,
     K_LZ_PARSE,
-    K_LZ_RANK,
-    K_LZ_LINK6,
-    K_LZ_PARSE6,
     K_LZ_LINKS,
     K_LZ_WALK,
     K_LZ_EMIT,
@@ -59,7 +54,7 @@ enum KernelId {
     K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {"memset_out", "k_byte_hist", "k_checksum", "k_lz_sort", "k_lz_match",
-                                           "k_lz_chain", "k_lz_parse", "k_lz_rank", "k_lz_link6", "k_lz_parse6", "k_lz_links", "k_lz_walk", "k_lz_emit",
+                                           "k_lz_chain", "k_lz_parse", "k_lz_links", "k_lz_walk", "k_lz_emit",
                                            "k_st_parse", "k_st_emit", "k_plan",
                                            "k_offsets",  "k_encode",    "k_inflate",  "k_inflate_par", "k_span_scan", "k_inflate_span",
                                            "k_gather"};
@@ -119,7 +114,6 @@ struct flate_hip_ctx {
     DevBuf chunks, blk_chunk, plans, hist, cks, S, NC, rec, desc, marks, tokens, ntok, cflag, links, shard_sz;
     DevBuf wexit;  // per window and sub-pass: where the path left it; per group: its exit, its entry; a flag (kernels_parse.h, fix launch)
     DevBuf wchunks, swins;  // whole-stream passes on k_lz_parse<true>: the streams' windows as chunks, a table entry per stream
-    DevBuf l6, bnd, ent;  // k_lz_parse6: the chain on six bytes, the budget bounds, phase A's entries (kernels_parse6.h)
     void* pin_in = nullptr;   // pinned mirrors of pageable host buffers (compress_impl)
     void* pin_out = nullptr;
     void* pin_len = nullptr;  // out_len of a sub-batch on its way home (mirror_out reads it before the call ends)
@@ -634,11 +628,6 @@ int ensure_lz_workspace(flate_hip_ctx* h, uint32_t nc, uint32_t chain) {
         if ((rc = ensure(h, h->links, per * 4 * sizeof(uint16_t)))) return rc;  // per chunk [L4 | L6 | L8 | RK] (kernels_walk.h)
     } else {
         if ((rc = ensure(h, h->S, per * sizeof(uint16_t)))) return rc;          // chain links (kernels_parse.h)
-        if (chain >= FL_PARSE6_MIN_CHAIN) {
-            if ((rc = ensure(h, h->l6, per * sizeof(uint16_t)))) return rc;     // links on six bytes (kernels_parse6.h)
-            if ((rc = ensure(h, h->bnd, per * sizeof(uint32_t)))) return rc;    // budget bounds (kernels_rank.h)
-            if ((rc = ensure(h, h->ent, per * sizeof(uint32_t)))) return rc;    // (E4, E5) of phase A
-        }
     }
     if ((rc = ensure(h, h->desc, per * sizeof(uint32_t)))) return rc;   // anchor descriptors
     if ((rc = ensure(h, h->marks, per / 8))) return rc;                 // true anchors, one bit per position
@@ -780,26 +769,6 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
             }
         } else {
-            if (prm.chain >= FL_PARSE6_MIN_CHAIN) {
-                // the chain on six bytes in LDS, the reference's own chain for what it cannot see (kernels_parse6.h)
-                {
-                    ProfScope ps(h, K_LZ_RANK);
-                    hipLaunchKernelGGL(k_lz_rank, dim3(nc), dim3(RK_THREADS), 0, st, d_in, dch, prm, (uint16_t*)h->S.p,
-                                       (uint32_t*)h->bnd.p, (uint32_t*)h->cflag.p);
-                }
-                {
-                    ProfScope ps(h, K_LZ_LINK6);
-                    hipLaunchKernelGGL((k_lz_links<2, 1>), dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->l6.p,
-                                       (uint32_t*)h->cflag.p);
-                }
-                if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
-                {
-                    ProfScope ps(h, K_LZ_PARSE6);
-                    hipLaunchKernelGGL(k_lz_parse6, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
-                                       (const uint16_t*)h->l6.p, (const uint32_t*)h->bnd.p, (uint32_t*)h->ent.p,
-                                       (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
-                }
-            } else {
             // levels 4..7: the reference's chain in LDS, the automaton per segment (kernels_parse.h)
             {
                 ProfScope ps(h, K_LZ_CHAIN);
@@ -813,7 +782,6 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
                                    (const fl_swin*)nullptr, (const fl_chunk*)nullptr, (const uint32_t*)nullptr,
                                    (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
-            }
             }
         }
         {
@@ -1316,7 +1284,7 @@ int flate_hip_destroy(flate_hip_handle h) {
                       &h->sp_part, &h->sp_footoff, &h->sp_foot, &h->sp_fin, &h->sp_chainpos, &h->sp_rs})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&h->chunks, &h->blk_chunk, &h->plans, &h->hist, &h->cks, &h->S, &h->NC, &h->rec, &h->desc, &h->marks,
-                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->l6, &h->bnd, &h->ent, &h->wchunks, &h->swins, &h->wexit, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
+                      &h->tokens, &h->ntok, &h->cflag, &h->links, &h->wchunks, &h->swins, &h->wexit, &h->shard_sz, &h->tiles, &h->segs, &h->pieces, &h->fpts, &h->zones, &h->nsorted, &h->jmp,
                       &h->exitmap, &h->entry, &h->segtok, &h->tokbase, &h->bound, &h->sgroups, &h->sgroup0, &h->gmap, &h->gentry,
                       &h->sblocks, &h->st_in, &h->st_out, &h->st_inoff, &h->st_outlen, &h->st_status,
                       &h->st_consumed, &h->st_pack, &h->st_packoff, &h->st_slot})

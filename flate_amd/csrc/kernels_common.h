@@ -10,7 +10,7 @@
 // Phase timestamps (shader clock) of workgroup 0 of the tokenizer kernels: a debugging /
 // tuning aid read back through flate_hip_debug_phase_cycles.  One s_memtime + one store by
 // one thread per phase.
-#define FL_PROF_SLOTS 64
+#define FL_PROF_SLOTS 160
 __device__ uint64_t g_fl_prof[FL_PROF_SLOTS];
 __device__ __forceinline__ void fl_prof_mark(uint32_t slot) {
     if (blockIdx.x == 0 && threadIdx.x == 0) g_fl_prof[slot] = __builtin_readcyclecounter();

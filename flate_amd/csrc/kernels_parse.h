@@ -282,7 +282,66 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #error PZ_UNROLL: 4, 8, 12, 16, 20, 24 or 32
 #endif
 #define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
-#define PZ_SEG_B 32u
+#ifndef PZ_SEG_B
+#define PZ_SEG_B 32u   // bytes per segment in sub-pass B (16384 targets: 32 -> 8 of the 16 waves hold segments, 16 -> all of them)
+#endif
+#if PZ_SEG_B == 32
+#define PZ_SEG_B_OF(D) ((D) >> 5)
+#elif PZ_SEG_B == 24
+#define PZ_SEG_B_OF(D) (((D) * 43691u) >> 20)
+#elif PZ_SEG_B == 16
+#define PZ_SEG_B_OF(D) ((D) >> 4)
+#else
+#error PZ_SEG_B: 16, 24 or 32
+#endif
+// Sub-pass A of a chunk, round 6: segments of UNEQUAL size.  The cost of a segment grows with its position -- the chains of a
+// position hold what lies before it, up to 32 KiB -- and a wave is as slow as its slowest lanes: with 48 bytes everywhere wave 0
+// (positions 0 .. 3071) finished its own parse in half the time of wave 15 (profiles/r06_parse_experiments.txt item 1) and waited.
+// Wave w takes 64 consecutive segments of PZ_VSIZES[w] bytes each (at most 64: a lane's anchors are a 64-bit mask), the waves in
+// order of position; the sizes add up to PZ_TA / 64.
+#ifndef PZ_VARY
+#define PZ_VARY 0
+#endif
+#ifndef PZ_WREV
+#define PZ_WREV 1
+#endif
+#ifndef PZ_VSIZES
+#define PZ_VSIZES 64, 60, 56, 54, 52, 50, 48, 48, 44, 44, 42, 42, 42, 42, 40, 40
+#endif
+struct pz_vgeom {
+    uint32_t size[16], base[17];
+    float rcp[16];
+};
+constexpr pz_vgeom pz_make_vgeom() {
+    pz_vgeom g{};
+    const uint32_t sz[16] = {PZ_VSIZES};
+    uint32_t b = 0;
+    for (int w = 0; w < 16; w++) {
+        g.size[w] = sz[w];
+        g.base[w] = b;
+        g.rcp[w] = 1.0f / (float)sz[w];
+        b += 64u * sz[w];
+    }
+    g.base[16] = b;
+    return g;
+}
+constexpr pz_vgeom PZ_VG = pz_make_vgeom();
+static_assert(PZ_THREADS != 1024 || PZ_VG.base[16] >= PZ_TA, "the segments of sub-pass A cover its targets");
+// segment of the target at offset D (< PZ_VG.base[16]) from the sub-pass's first: the wave by comparison with the 15 bounds, the
+// lane by a division that is exact in single precision (D - base < 4096, sizes <= 64: (d + 0.5) / size is at least 1 / 128
+// away from an integer)
+__device__ __forceinline__ uint32_t pz_vseg(uint32_t D) {
+    uint32_t w = 0, bw = 0;
+    float r = PZ_VG.rcp[0];
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+        const bool ge = D >= PZ_VG.base[k];
+        w = ge ? (uint32_t)k : w;
+        bw = ge ? PZ_VG.base[k] : bw;
+        r = ge ? PZ_VG.rcp[k] : r;
+    }
+    return 64u * w + (uint32_t)(((float)(D - bw) + 0.5f) * r);
+}
 // STREAM: sub-pass A of a window has only the targets [32506, 49152): smaller segments, so that every lane has one
 #ifndef PZ_SEG_AS
 #define PZ_SEG_AS 24u  // (256 x 1 MiB of text, k_lz_parse<true>: 48 / 32 / 24 / 17 bytes 9.91 / 9.29 / 9.04 / 9.57 ms)
@@ -394,6 +453,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     uint32_t& sh_exit = lds.sh_exit;
     constexpr uint32_t LITD = STREAM ? 0u : PZ_DESC_LIT;  // descriptor of an anchor that emits one literal
     const uint32_t tid = threadIdx.x;
+#ifdef PZ_PRIO
+    {
+        // experiment: the issue priority of a wave by its number (the hardware serves the oldest wave of a SIMD first)
+        const uint32_t g = (PZ_PRIO == 1) ? (tid >> 8) : (PZ_PRIO == 2) ? 3u - (tid >> 8) : (PZ_PRIO == 3) ? ((tid >> 6) & 3u) : 0u;
+        if (g == 1) __builtin_amdgcn_s_setprio(1);
+        else if (g == 2) __builtin_amdgcn_s_setprio(2);
+        else if (g == 3) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
     const uint32_t prv_lds = (uint32_t)(size_t)(fl_lds_u32*)prv, win_lds = (uint32_t)(size_t)(fl_lds_u32*)win32;  // LDS byte addresses
     fl_swin sw;
@@ -514,11 +582,12 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t r0 = sub ? (PZ_TA - FL_MAX_DIST - PZ_MARGIN) : 0u;  // everything below is relative to r0
         // (STREAM: small segments when the sub-pass's targets leave a lane for each; a stream's first window starts at 0)
         const bool small = STREAM && !sub && min(t_last, (uint32_t)PZ_TA) - t_first <= PZ_THREADS * PZ_SEG_AS;
+        const bool vary = PZ_VARY && !STREAM && !sub && PZ_THREADS == 1024;  // (a chunk's sub-pass A starts at position 0)
         const uint32_t S = sub ? (STREAM ? PZ_SEG_BS : PZ_SEG_B) : (small ? PZ_SEG_AS : PZ_SEG_A);
         // segment of a relative target position x - t0r (< 65536): a shift, or a multiplication by 1 / 48
         // (43691 / 2^21 = 1 / 47.99997: exact for arguments below 2^16)
-#define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : ((D) >> 5)) : (small ? PZ_SEG_AS_OF(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21))))
-        const uint32_t nseg = PZ_SEG_OF(end - t0 + S - 1);
+#define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : PZ_SEG_B_OF(D)) : (small ? PZ_SEG_AS_OF(D) : (vary ? pz_vseg(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))))
+        const uint32_t nseg = vary ? pz_vseg(end - t0 - 1u) + 1u : PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
         // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
@@ -655,9 +724,14 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         c_tstage += __builtin_readcyclecounter() - c_ts0;
 #endif
         const uint32_t y0 = sub ? sh_next_entry : carry;  // the sub-pass is entered at this anchor (relative)
-        const uint32_t m = tid;                         // this lane's segment
-        const uint32_t seg0 = t0r + m * S;
-        const uint32_t seg_end = min(seg0 + S, endr);
+        // this lane's segment.  Sub-pass A of a chunk: the waves take the blocks of 64 segments in REVERSE order -- a segment costs
+        // the more the later it lies (its chains hold what lies before it) and a SIMD serves its oldest waves first (the same
+        // work takes wave 15 a third longer than wave 0: profiles/r06_parse_experiments.txt item 1): the dearest segments go to
+        // the waves that are served best.
+        const uint32_t m = (PZ_WREV && !STREAM && !sub) ? (((PZ_WAVES - 1u - (tid >> 6)) << 6) | (tid & 63u)) : tid;
+        const uint32_t Sm = vary ? PZ_VG.size[m >> 6] : S;  // this lane's segment: [seg0, seg_end)
+        const uint32_t seg0 = vary ? t0r + PZ_VG.base[m >> 6] + (m & 63u) * Sm : t0r + m * S;
+        const uint32_t seg_end = min(seg0 + Sm, endr);
         if (y0 >= endr) {  // the path jumps over the whole sub-pass: no anchors (the bitmap is zero already)
             if (tid == 0) {
                 sh_exit = y0 + r0;
@@ -690,6 +764,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             PZ_CNT(c_rounds, 1);
 #ifdef PZ_PROF
             const uint64_t c_tr0 = __builtin_readcyclecounter();
+            const uint32_t c_l0 = c_loops;
 #endif
             uint32_t st = ST_DONE;
             uint32_t a = 0;
@@ -1330,6 +1405,8 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #undef PZ_LOAD_CAND
 #ifdef PZ_PROF
             if (round == 0) c_tspec += __builtin_readcyclecounter() - c_tr0; else c_tstitch += __builtin_readcyclecounter() - c_tr0;
+            if (round == 0 && (tid & 63) == 0) atomicAdd((unsigned long long*)&g_fl_prof[64 + 16 * sub + (tid >> 6)], (unsigned long long)(__builtin_readcyclecounter() - c_tr0));
+            if (round == 0 && (tid & 63) == 0) atomicAdd((unsigned long long*)&g_fl_prof[96 + 16 * sub + (tid >> 6)], (unsigned long long)(c_loops - c_l0));
 #endif
             // Every segment parsed again in this round leaves where the round's path assumed: the path stands, and with
             // it the marks and entries found above -- no round to confirm it.

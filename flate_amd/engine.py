@@ -217,8 +217,8 @@ class Engine:
 
     def phase_cycles(self):
         """Shader-clock timestamps of workgroup 0's phases in the last tokenizer launch (tuning aid)."""
-        buf = np.zeros(64, dtype=np.uint64)
-        self._L.flate_hip_debug_phase_cycles(self._h, buf.ctypes.data, 64)
+        buf = np.zeros(160, dtype=np.uint64)
+        self._L.flate_hip_debug_phase_cycles(self._h, buf.ctypes.data, 160)
         return buf
 
     def debug_write_block(self, tokens, input_bytes, eof, dynamic_only=False):

@@ -40,3 +40,9 @@ names = ["block entered", "hit: measure", "measure iterations", "match improved"
 print("events of the slow block, per chunk: waves that pass (lanes per passing wave)")
 for i, nm in enumerate(names):
     print("  %-26s %8.1f  (%.1f)" % (nm, t[2 * i] / nc, t[2 * i + 1] / max(t[2 * i], 1)))
+
+if len(t) >= 128:
+    print("round 0 per wave (cycles / outer loops), sub-pass A then B, averaged over chunks:")
+    for sub in range(2):
+        print("  %s cycles: %s" % ("AB"[sub], " ".join("%6.0f" % (t[64 + 16 * sub + w] / nc) for w in range(16))))
+        print("  %s loops:  %s" % ("AB"[sub], " ".join("%6.1f" % (t[96 + 16 * sub + w] / nc) for w in range(16))))
