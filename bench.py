@@ -164,8 +164,28 @@ class CompressJob:
         import numpy as np
         st = self.status.cpu().numpy()
         lens = self.out_len.cpu().numpy()
-        assert (st == 0).all(), "non-zero chunk status: %s" % np.unique(st)
+        # 102 = FLATE_HIP_ST_REFERENCE_Q1_STREAM: the reference's own bytes, which do not inflate to the input (include/flate_hip.h)
+        assert ((st == 0) | (st == 102)).all(), "non-zero chunk status: %s" % np.unique(st)
+        self.q1_chunks = np.flatnonzero(st == 102)
         return lens
+
+    def roundtrip(self, lens):
+        """GPU inflate of the streams just produced against the input: every stream of status 0 gives its chunk back; the
+        streams of status 102 (the reference's Q1 streams) are the only ones allowed not to.  -> (ok, n_q1)"""
+        import numpy as np
+        torch = self.torch
+        comp, comp_off, _ = self.packed(lens)
+        inf = InflateJob(torch, self.eng, comp, comp_off, self.n_chunks, self.in_off, self.n_in, self.container)
+        inf.step()
+        torch.cuda.synchronize()
+        bad = np.zeros(self.n_chunks, dtype=bool)
+        bad[np.flatnonzero(inf.dec_st.cpu().numpy() != 0)] = True
+        diff = torch.nonzero(inf.dec[:self.n_in] != self.data).flatten()
+        if diff.numel():
+            bad[np.unique(np.searchsorted(self.off_np, diff.cpu().numpy(), side="right") - 1)] = True
+        q1 = np.zeros(self.n_chunks, dtype=bool)
+        q1[self.q1_chunks] = True
+        return bool((bad == q1).all()), int(q1.sum())
 
     def packed(self, lens):
         """The produced streams back to back (device) + their offsets."""
@@ -663,6 +683,23 @@ def other_workloads(args, torch, eng, device):
             ok = True
         res[name] = {"MBps": round(d.numel() * 2 / dt / 1e6, 1), "ratio": round(float(lens.sum()) / d.numel(), 4),
                      "sampled_chunks_equal_oracle": ok}
+        if not args.no_verify:
+            # every stream back through GPU inflate: status 0 <=> the chunk comes back; status 102 = the reference's own Q1
+            # streams (its bytes, replicated: they lose or repeat a match's bytes); with FLATE_HIP_DEFLATE_REPAIR_Q1 every
+            # stream comes back
+            rt, nq1 = job.roundtrip(lens)
+            assert rt, "a stream of status 0 does not inflate to its chunk (or a status-102 stream does)"
+            res[name].update({"roundtrip_equal": rt, "reference_q1_streams": nq1})
+            if nq1:
+                eng.set_flags(1)
+                try:
+                    job.step()
+                    lens2 = job.results()
+                    rt2, nq2 = job.roundtrip(lens2)
+                finally:
+                    eng.set_flags(0)
+                assert rt2 and nq2 == 0, "FLATE_HIP_DEFLATE_REPAIR_Q1: a stream does not inflate to its chunk"
+                res[name]["roundtrip_equal_with_repair_q1"] = True
         del job, d
     res.update(one_stream_inflate(args, torch, eng, device))
     res.update(baseline_configs(args, torch, eng, device))

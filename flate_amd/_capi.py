@@ -15,10 +15,12 @@ MODE_STORE, MODE_HUFFMAN = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MAX_LZ_CHUNK = 65535
 INFLATE_STRICT_Q6 = 1
+DEFLATE_REPAIR_Q1 = 1          # flate_hip_set_flags
+ST_REFERENCE_Q1_STREAM = 102   # compress status: the reference's bytes, which do not inflate to the input (include/flate_hip.h)
 
 # every symbol include/flate_hip.h declares
 SYMBOLS = [
-    "flate_hip_create", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_set_sync",
+    "flate_hip_create", "flate_hip_destroy", "flate_hip_set_stream", "flate_hip_set_sync", "flate_hip_set_flags",
     "flate_hip_compress_bound", "flate_hip_compress_batch", "flate_hip_decompress_batch",
     "flate_hip_status_name", "flate_hip_last_error", "flate_hip_version",
     "flate_hip_profile_enable", "flate_hip_profile_read", "flate_hip_profile_reset",
@@ -75,6 +77,8 @@ def lib():
     L.flate_hip_destroy.argtypes = [vp]
     L.flate_hip_set_stream.argtypes = [vp, vp]
     L.flate_hip_set_sync.argtypes = [vp, C.c_int]
+    L.flate_hip_set_flags.argtypes = [vp, C.c_uint32]
+    L.flate_hip_set_flags.restype = C.c_int
     L.flate_hip_compress_bound.argtypes = [C.c_size_t, C.c_int, C.c_int]
     L.flate_hip_compress_bound.restype = C.c_size_t
     L.flate_hip_compress_batch.argtypes = [vp, vp, u64p, C.c_uint32, C.c_int, C.c_int, vp, u64p, u64p, i32p, C.c_int]

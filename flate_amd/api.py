@@ -45,8 +45,9 @@ class Level(enum.IntEnum):  # deflate.zig:23-32
 
 
 class Options:  # deflate.zig:15-17
-    def __init__(self, level=Level.default):
+    def __init__(self, level=Level.default, repair_q1=False):
         self.level = Level(level)
+        self.repair_q1 = bool(repair_q1)  # not in the reference: FLATE_HIP_DEFLATE_REPAIR_Q1 (ReferenceQ1StreamWarning)
 
 
 class FlateError(Exception):
@@ -73,7 +74,15 @@ WrongStoredBlockNlen = _mk("WrongStoredBlockNlen", 13)
 InvalidDynamicBlockHeader = _mk("InvalidDynamicBlockHeader", 14)
 OutputTooSmall = _mk("OutputTooSmall", 100)
 ChunkTooLarge = _mk("ChunkTooLarge", 101)
-InvalidState = _mk("InvalidState", 102)  # inflate.zig:303
+InvalidState = _mk("InvalidState", 103)  # inflate.zig:303 (a host-side state, no device status)
+
+
+class ReferenceQ1StreamWarning(UserWarning):
+    """The stream just written is byte for byte the reference's -- and does not inflate to its input: the reference flushes
+    a full block of 32768 tokens before its window has advanced over the last token's match (deflate.zig:227-230 before
+    :193), and when exactly one of the two blocks at that seam is stored the match's bytes are lost or written twice
+    (include/flate_hip.h: FLATE_HIP_ST_REFERENCE_Q1_STREAM).  `Options(level, repair_q1=True)` writes a stream that
+    inflates to the input instead."""
 
 _ERRORS = {e.status: e for e in (
     EndOfStream, BadGzipHeader, BadZlibHeader, WrongGzipChecksum, WrongGzipSize, WrongZlibChecksum, InvalidCode,
@@ -84,6 +93,16 @@ _ERRORS = {e.status: e for e in (
 def raise_for_status(code):
     if code:
         raise _ERRORS.get(code, FlateError)(_capi.status_name(code))
+
+
+def _compress_status(code):
+    """Status of a compress call: 102 is the reference's own (broken) stream -- written as the reference writes it, with a
+    warning; anything else non-zero raises."""
+    if code == _capi.ST_REFERENCE_Q1_STREAM:
+        import warnings
+        warnings.warn(ReferenceQ1StreamWarning(ReferenceQ1StreamWarning.__doc__.split("\n")[0]), stacklevel=3)
+        return
+    raise_for_status(code)
 
 
 def _read_all(reader):
@@ -110,9 +129,10 @@ class _Compressor:
     The container header is written once, the footer's checksum is folded from per-piece checksums
     (flate_hip_checksum / _combine)."""
 
-    def __init__(self, container, mode, writer, engine=None):
+    def __init__(self, container, mode, writer, engine=None, repair_q1=False):
         self._container, self._mode, self._wrt = container, int(mode), writer
         self._eng = engine or default_engine()
+        self._repair = bool(repair_q1)
         self._buf = bytearray()  # stream bytes from absolute position self._base on
         self._base = 0
         self._total = 0          # bytes written so far
@@ -121,6 +141,16 @@ class _Compressor:
         self._rel_emitted = None  # bytes the tail [base, last flush) compresses to (cached while base stands)
         self._cks, self._cks_pos = None, 0
         self._done = False
+
+    def _call(self, fn, *args):
+        # (the flag is the handle's: set for this object's calls only)
+        if not self._repair:
+            return fn(*args)
+        self._eng.set_flags(_capi.DEFLATE_REPAIR_Q1)
+        try:
+            return fn(*args)
+        finally:
+            self._eng.set_flags(0)
 
     def _live(self):
         # the reference's compressor has no such check (writing after finish() emits a broken stream);
@@ -159,11 +189,11 @@ class _Compressor:
         if self._rel_emitted is None:
             # how much of the tail's output was handed over already: the tail up to the previous flush
             prev = rel[-2] if not finish else rel[-1]
-            done, st = self._eng.compress_flush(tail[:prev], rel[:-1] if not finish else rel, False, _capi.RAW, self._mode)
-            raise_for_status(st)
+            done, st = self._call(self._eng.compress_flush, tail[:prev], rel[:-1] if not finish else rel, False, _capi.RAW, self._mode)
+            _compress_status(st)
             self._rel_emitted = len(done)
-        out, st = self._eng.compress_flush(tail, rel, finish, _capi.RAW, self._mode)
-        raise_for_status(st)
+        out, st = self._call(self._eng.compress_flush, tail, rel, finish, _capi.RAW, self._mode)
+        _compress_status(st)
         new = out[self._rel_emitted:]
         self._rel_emitted = len(out)
         return new
@@ -203,8 +233,8 @@ class _Compressor:
             elif self._container == _capi.ZLIB:  # container.zig:104
                 self._wrt.write(self._cks.to_bytes(4, "big"))
         else:
-            outs, st = self._eng.compress_many([bytes(self._buf)], self._container, self._mode)
-            raise_for_status(st[0])
+            outs, st = self._call(self._eng.compress_many, [bytes(self._buf)], self._container, self._mode)
+            _compress_status(st[0])
             self._wrt.write(outs[0])
         self._done = True
 
@@ -350,8 +380,8 @@ class ContainerModule:
         c.finish()
 
     def compressor(self, writer, options=None, engine=None):
-        level = (options or Options()).level
-        return _Compressor(self._container, int(level), writer, engine)
+        options = options or Options()
+        return _Compressor(self._container, int(options.level), writer, engine, repair_q1=options.repair_q1)
 
     Compressor = compressor
 

@@ -196,6 +196,11 @@ struct fl_block_plan {
     uint32_t tok_count;
     uint32_t valid;
     uint32_t no_input;   // token blocks: the raw input slice is gone (window slide since the last flush)
+    // Quirk Q1 (deflate.zig:227-230 -> 268-270 -> SlidingWindow.zig:119-123; the window advances only at deflate.zig:193):
+    // when the block's 32768th token is a match, the slice [in_start, in_start + in_len) ends q1_gap bytes before the bytes
+    // its tokens cover, and the next block's slice starts that early.  Harmless while both blocks are Huffman coded or both
+    // stored; with exactly one of them stored the reference's stream loses or repeats those bytes (k_offsets reports it).
+    uint32_t q1_gap;
     uint64_t bit_off;  // absolute bit offset in `out`, filled by the offset scan
     uint8_t hdr[FL_HDR_BYTES];
     fl_hcode lit[FL_NUM_LIT];

@@ -108,6 +108,7 @@ struct flate_hip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool sync = true;
+    uint32_t flags = 0;  // flate_hip_set_flags
     std::string last_error;
     fl_crc_consts crc{};
     // device workspace (grown on demand, reused across calls)
@@ -351,7 +352,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     if ((rc = ensure(h, h->entry, sizeof(uint32_t) * (nseg + 1)))) return rc;
     if ((rc = ensure(h, h->segtok, sizeof(uint32_t) * (nseg + 1)))) return rc;
     if ((rc = ensure(h, h->tokbase, sizeof(uint32_t) * (nseg + 1)))) return rc;
-    if ((rc = ensure(h, h->bound, sizeof(uint32_t) * nb))) return rc;
+    if ((rc = ensure(h, h->bound, sizeof(uint32_t) * 2 * nb))) return rc;  // [nb] window positions + [nb] Q1 gaps (k_st_emit)
     if ((rc = ensure(h, h->ntok, sizeof(uint32_t) * npc))) return rc;
     HIP_OK(h, hipMemcpyAsync(h->tiles.p, t.tiles.data(), sizeof(fl_tile) * t.tiles.size(), hipMemcpyHostToDevice, st));
     if (nseg) HIP_OK(h, hipMemcpyAsync(h->segs.p, t.segs.data(), sizeof(fl_seg) * nseg, hipMemcpyHostToDevice, st));
@@ -548,9 +549,10 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             hipLaunchKernelGGL(k_st_emit, dim3(nseg), dim3(FL_EMIT_THREADS), 0, st, d_in, dch, dpc, dsg, prm,
                                (const uint32_t*)h->desc.p, (const uint32_t*)h->marks.p,
                                (const uint32_t*)h->tokbase.p, (uint32_t*)h->tokens.p, (uint32_t*)h->hist.p,
-                               (uint32_t*)h->bound.p);
+                               (uint32_t*)h->bound.p, (uint32_t*)h->bound.p + nb);
         hipLaunchKernelGGL(k_st_blocks, dim3(npc), dim3(64), 0, st, dch, dpc, (const uint32_t*)h->ntok.p,
-                           (const uint32_t*)h->bound.p, (const uint32_t*)h->zones.p, (fl_block_plan*)h->plans.p);
+                           (const uint32_t*)h->bound.p, (const uint32_t*)h->bound.p + nb, prm.flags & FL_PRM_REPAIR_Q1,
+                           (const uint32_t*)h->zones.p, (fl_block_plan*)h->plans.p);
     }
     (void)nc;
     return FLATE_HIP_OK;
@@ -1239,6 +1241,7 @@ const char* flate_hip_status_name(int s) {
         case 14: return "InvalidDynamicBlockHeader";
         case 100: return "OutputTooSmall";
         case 101: return "ChunkTooLarge";
+        case 102: return "ReferenceQ1Stream";
         default: return "Unknown";
     }
 }
@@ -1379,6 +1382,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     if (hipSetDevice(h->device) != hipSuccess) return FLATE_HIP_E_NO_DEVICE;
     prm.container = container;
     prm.mode = mode;
+    prm.flags = (h->flags & FLATE_HIP_DEFLATE_REPAIR_Q1) ? FL_PRM_REPAIR_Q1 : 0u;
     hipStream_t st = h->stream;
 
     std::vector<uint64_t> hin_, hout_;
@@ -2128,6 +2132,12 @@ int flate_hip_gather_streams(flate_hip_handle h, const uint8_t* out, const uint6
     }
     HIP_OK(h, hipGetLastError());
     if (h->sync) HIP_OK(h, hipStreamSynchronize(st));
+    return FLATE_HIP_OK;
+}
+
+int flate_hip_set_flags(flate_hip_handle h, uint32_t flags) {
+    if (!h || (flags & ~(uint32_t)FLATE_HIP_DEFLATE_REPAIR_Q1)) return FLATE_HIP_E_INVALID_ARG;
+    h->flags = flags;
     return FLATE_HIP_OK;
 }
 

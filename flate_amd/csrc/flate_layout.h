@@ -66,6 +66,8 @@ struct fl_sblock {
 };
 
 // call-wide constants
+// fl_params.flags
+#define FL_PRM_REPAIR_Q1 1u  // flate_hip_set_flags(FLATE_HIP_DEFLATE_REPAIR_Q1): a block is handed the bytes its tokens cover (below: q1_gap)
 struct fl_params {
     uint32_t n_chunks;
     uint32_t n_blocks;
@@ -73,7 +75,7 @@ struct fl_params {
     int32_t mode;       // 0 store, 1 huffman, 4..9
     // level args (deflate.zig:41-52)
     uint32_t good, lazy, nice, chain;
-    uint32_t pad0_;
+    uint32_t flags;   // FL_PRM_*
     uint32_t stream;  // non-zero: whole-stream pass (kernels_stream.h)
     uint32_t plan_dynamic_only;  // debug seam only: plan token blocks as BlockWriter.dynamicBlock does
 };

@@ -47,6 +47,7 @@ __device__ __forceinline__ void fl_plan_marker(fl_block_plan* plan) {
     plan->tok_start = 0;
     plan->tok_count = 0;
     plan->no_input = 0;
+    plan->q1_gap = 0;
 }
 
 // ------------------------------------------------------------------ histograms
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256) void k_plan_store(const fl_chunk* __restrict__
     plan->tok_start = sb.start;
     plan->tok_count = sb.len;
     plan->no_input = 0;
+    plan->q1_gap = 0;
 }
 
 // Fold the checksum parts of n_blocks consecutive blocks (k_checksum: CRC-32 of each block / Adler-32
@@ -422,10 +424,13 @@ __global__ __launch_bounds__(64 * FL_OFFS_MAX_WAVES) void k_offsets(const fl_chu
     __shared__ fl_offmap wtot[FL_OFFS_MAX_WAVES];
     __shared__ uint32_t wx[FL_OFFS_MAX_WAVES], wy[FL_OFFS_MAX_WAVES];
     __shared__ uint64_t wl[FL_OFFS_MAX_WAVES];
+    __shared__ uint32_t q1_sh;  // a block boundary of this chunk loses or repeats bytes (quirk Q1)
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     if (ck.skip) return;  // host already wrote status / out_len
+    if (threadIdx.x == 0) q1_sh = 0;
+    __syncthreads();
     const uint32_t hdr_bytes = prm.container == 1 ? 10u : (prm.container == 2 ? 2u : 0u);
     const uint32_t ftr_bytes = ck.unfinished ? 0u : (prm.container == 1 ? 8u : (prm.container == 2 ? 4u : 0u));
     const uint64_t base = (ck.out_off + hdr_bytes) * 8;
@@ -473,7 +478,16 @@ __global__ __launch_bounds__(64 * FL_OFFS_MAX_WAVES) void k_offsets(const fl_chu
                 exc.c = __shfl_up(inc.c, 1, 64);
                 exc.has = __shfl_up(inc.has, 1, 64);
                 if (lane == 0) exc = ident;
-                if (plan && plan->valid) plan->bit_off = fl_offmap_apply(fl_offmap_compose(run, exc), base);
+                if (plan && plan->valid) {
+                    plan->bit_off = fl_offmap_apply(fl_offmap_compose(run, exc), base);
+                    // Q1: this block's slice ends q1_gap bytes before the bytes its tokens cover and the next block's starts
+                    // there.  One of the two stored, the other Huffman coded: the reference's stream loses those bytes (this
+                    // block stored) or holds them twice (the next one stored) -- reported, not repaired (fl_block_plan.q1_gap)
+                    if (plan->q1_gap && j + 1 < ck.n_blocks) {
+                        const fl_block_plan* nx = &plans[ck.first_block + j + 1];
+                        if (nx->valid && (plan->type == FL_BLOCK_STORED) != (nx->type == FL_BLOCK_STORED)) q1_sh = 1u;
+                    }
+                }
             }
             fl_offmap last;
             last.a = __shfl(inc.a, 63, 64);
@@ -568,9 +582,11 @@ __global__ __launch_bounds__(64 * FL_OFFS_MAX_WAVES) void k_offsets(const fl_chu
             cks = prm.container == 1 ? fx : (((1u + fx) % 65521u) | ((uint32_t)((all % 65521u + fy) % 65521u) << 16));  // a = 1 + A, b = n + B
         }
     }
+    __syncthreads();  // (q1_sh)
     if (threadIdx.x == 0) {
         out_len[c] = fits ? total : 0;
-        status[c] = fits ? 0 : 100;  // FLATE_HIP_ST_OUTPUT_TOO_SMALL
+        // FLATE_HIP_ST_OUTPUT_TOO_SMALL; FLATE_HIP_ST_REFERENCE_Q1_STREAM: the bytes are the reference's, and do not inflate to the input
+        status[c] = fits ? (q1_sh ? 102 : 0) : 100;
         if (fits) {
             uint8_t* o = out + ck.out_off;
             if (prm.container == 1) {  // container.zig:64

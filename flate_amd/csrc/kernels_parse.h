@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #endif
 #define PZ_SEG_A (PZ_TA / PZ_THREADS)  // 48 bytes per lane with 1024 lanes (64 with 768)
 #ifndef PZ_SEG_B
-#define PZ_SEG_B 32u   // bytes per segment in sub-pass B (16384 targets: 32 -> 8 of the 16 waves hold segments, 16 -> all of them)
+#define PZ_SEG_B 24u   // bytes per segment in sub-pass B (16384 targets; 32: 8 of the 16 waves hold segments, 20.47 ms; 24: 11 waves, 20.34; 16: all of them, 21.98 with unequal segments in A)
 #endif
 #if PZ_SEG_B == 32
 #define PZ_SEG_B_OF(D) ((D) >> 5)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #define PZ_WREV 1
 #endif
 #ifndef PZ_VSIZES
-#define PZ_VSIZES 64, 60, 56, 54, 52, 50, 48, 48, 44, 44, 42, 42, 42, 42, 40, 40
+#define PZ_VSIZES 53, 46, 43, 42, 47, 46, 46, 45, 48, 48, 48, 48, 52, 52, 52, 52
 #endif
 struct pz_vgeom {
     uint32_t size[16], base[17];
@@ -327,20 +327,24 @@ constexpr pz_vgeom pz_make_vgeom() {
 }
 constexpr pz_vgeom PZ_VG = pz_make_vgeom();
 static_assert(PZ_THREADS != 1024 || PZ_VG.base[16] >= PZ_TA, "the segments of sub-pass A cover its targets");
-// segment of the target at offset D (< PZ_VG.base[16]) from the sub-pass's first: the wave by comparison with the 15 bounds, the
-// lane by a division that is exact in single precision (D - base < 4096, sizes <= 64: (d + 0.5) / size is at least 1 / 128
-// away from an integer)
-__device__ __forceinline__ uint32_t pz_vseg(uint32_t D) {
-    uint32_t w = 0, bw = 0;
-    float r = PZ_VG.rcp[0];
-#pragma unroll
-    for (int k = 1; k < 16; k++) {
-        const bool ge = D >= PZ_VG.base[k];
-        w = ge ? (uint32_t)k : w;
-        bw = ge ? PZ_VG.base[k] : bw;
-        r = ge ? PZ_VG.rcp[k] : r;
-    }
-    return 64u * w + (uint32_t)(((float)(D - bw) + 0.5f) * r);
+// Segment of the target at offset D from the sub-pass's first.  The blocks are about 3072 bytes: block D / 3072 or one of its
+// neighbours holds D (checked below for the sizes chosen), so the block's number comes from two bounds of a small table in LDS,
+// the lane from a division that is exact in single precision (D - base < 4096, sizes <= 64: (d + 0.5) / size is at least
+// 1 / 128 away from an integer).
+constexpr bool pz_vgeom_ok() {
+    for (int k = 0; k <= 16; k++)
+        if (PZ_VG.base[k] > 3072u * (k + 1) || PZ_VG.base[k] + 3072u < 3072u * k) return false;
+    return true;
+}
+static_assert(pz_vgeom_ok(), "block k of sub-pass A starts within 3072 bytes of 3072 k");
+struct pz_vtab {
+    uint16_t base[20];  // [k + 1] = first target of block k; [0] = 0, [18], [19] = beyond every target
+    float rcp[17];      // [k + 1] = 1 / bytes per segment of block k
+};
+__device__ __forceinline__ uint32_t pz_vseg(const pz_vtab& vt, uint32_t D) {
+    const uint32_t g = (D * 43691u) >> 27;  // D / 3072 (exact below 2^16)
+    const uint32_t w = g - 1u + (D >= vt.base[g + 1] ? 1u : 0u) + (D >= vt.base[g + 2] ? 1u : 0u);  // in [g - 1, g + 1]; g = 0: base[1] = 0 counts
+    return 64u * w + (uint32_t)(((float)(D - vt.base[w + 1]) + 0.5f) * vt.rcp[w + 1]);
 }
 // STREAM: sub-pass A of a window has only the targets [32506, 49152): smaller segments, so that every lane has one
 #ifndef PZ_SEG_AS
@@ -440,8 +444,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         uint16_t tMark[PZ_THREADS];    // segment is on the path
         uint32_t sh_next_entry;
         uint32_t sh_exit;              // STREAM: where the path leaves the window (window-relative)
+        pz_vtab vt;                    // the blocks of sub-pass A (PZ_VARY)
     };
     __shared__ pz_lds lds;
+    if (PZ_VARY && !STREAM && threadIdx.x < 20) {
+        const uint32_t k = threadIdx.x;  // (read behind the barrier that ends the first staging)
+        lds.vt.base[k] = (uint16_t)(k == 0 ? 0u : k <= 17 ? min(PZ_VG.base[k - 1], 65535u) : 65535u);
+        if (k >= 1 && k <= 16) lds.vt.rcp[k] = PZ_VG.rcp[k - 1];
+    }
+    if (PZ_VARY && !STREAM) __syncthreads();
     uint32_t (&win32)[PZ_WIN_DW] = lds.win32;
     uint16_t (&prv)[PZ_PRV_N] = lds.prv;
     uint16_t (&tX)[PZ_THREADS] = lds.tX;
@@ -586,8 +597,8 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t S = sub ? (STREAM ? PZ_SEG_BS : PZ_SEG_B) : (small ? PZ_SEG_AS : PZ_SEG_A);
         // segment of a relative target position x - t0r (< 65536): a shift, or a multiplication by 1 / 48
         // (43691 / 2^21 = 1 / 47.99997: exact for arguments below 2^16)
-#define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : PZ_SEG_B_OF(D)) : (small ? PZ_SEG_AS_OF(D) : (vary ? pz_vseg(D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))))
-        const uint32_t nseg = vary ? pz_vseg(end - t0 - 1u) + 1u : PZ_SEG_OF(end - t0 + S - 1);
+#define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : PZ_SEG_B_OF(D)) : (small ? PZ_SEG_AS_OF(D) : (vary ? pz_vseg(lds.vt, D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))))
+        const uint32_t nseg = vary ? pz_vseg(lds.vt, end - t0 - 1u) + 1u : PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
         const uint32_t endr = end - r0, t0r = t0 - r0;
         // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
@@ -1507,7 +1518,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     __shared__ uint32_t hist[2][320];
     __shared__ uint32_t wtot[16];
     __shared__ uint16_t alist[16][FL_TOK_SPAN];  // per wave: the positions (in its span) of the span's anchors, ascending
-    __shared__ uint32_t v1_sh;
+    __shared__ uint32_t v1_sh, e1_sh;  // where the reference's window stands when token 32768 is added; where that token's bytes end
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1528,7 +1539,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
     uint32_t* tokens = tokens_all + ck.pos_off;
 
     for (uint32_t i = tid; i < 640; i += FL_EMITZ_THREADS) (&hist[0][0])[i] = 0;
-    if (tid == 0) v1_sh = N;
+    if (tid == 0) v1_sh = e1_sh = N;
     uint32_t run0 = 0;  // tokens of the parts before this one (same value in every thread)
     uint32_t tw_next = 0;  // the wave's 16 words of anchor bits of the next part
     if (lane < FL_TOK_SPAN / 32u && wave * FL_TOK_SPAN + 32 * lane < min((uint32_t)FL_TOK_PART, N)) tw_next = trueg[((wave * FL_TOK_SPAN) >> 5) + lane];
@@ -1597,7 +1608,7 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
                 const uint32_t byte = fl_win_byte(winp, q + x);
                 tokens[idx] = FL_TOK_LIT(byte);
                 atomicAdd(&hist[idx >> 15][byte], 1u);
-                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + x + 1;  // emitted at the visit of the next position
+                if (idx == FL_MAX_TOKENS - 1) v1_sh = e1_sh = p + x + 1;  // emitted at the visit of the next position
                 idx++;
             }
             if (mk && dd) {
@@ -1607,7 +1618,10 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
                 atomicAdd(&hist[idx >> 15][286 + fl_dist_code(d0)], 1u);
                 // a match of at least `lazy` goes out at its own visit, a shorter one at the next
                 // (deflate.zig:171-173 vs 182-184); rp at that moment decides the Q1 input slice
-                if (idx == FL_MAX_TOKENS - 1) v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+                if (idx == FL_MAX_TOKENS - 1) {
+                    v1_sh = p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+                    e1_sh = p + nl + ll + 3;  // (Q1: the window has not advanced over the match yet, deflate.zig:193)
+                }
             }
         }
         __syncthreads();  // wtot and winp are reused by the next part
@@ -1620,9 +1634,13 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
         if (i < 320 * nblk) hg[i] = (&hist[0][0])[i];
     if (tid == 0) {
         ntok_all[c] = total;
-        const uint32_t v1 = v1_sh;
+        // the slice the block writer is handed with the first 32768 tokens ends at v1 (the reference: Q1) or where the tokens end
+        const bool repair = (prm.flags & FL_PRM_REPAIR_Q1) != 0;
+        const uint32_t v1 = repair ? e1_sh : v1_sh;
         plan0->no_input = 0;
         plan1->no_input = 0;
+        plan0->q1_gap = (nblk == 2 && !repair) ? e1_sh - v1_sh : 0u;
+        plan1->q1_gap = 0;
         if (nblk == 1) {
             plan0->valid = 1;
             plan0->tok_start = 0;

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_st_emit(const uint8_t* _
                                                               const uint32_t* __restrict__ tokbase,
                                                               uint32_t* __restrict__ tokens_all,
                                                               uint32_t* __restrict__ hist_all,
-                                                              uint32_t* __restrict__ bound) {
+                                                              uint32_t* __restrict__ bound,
+                                                              uint32_t* __restrict__ qgap) {
     __shared__ uint32_t win32[FL_STE_WIN_DW];
     __shared__ uint32_t marks[FL_SEG / 32];
     __shared__ uint32_t hist[2][320];
@@ -410,8 +411,10 @@ __global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_st_emit(const uint8_t* _
                 tokens[idx] = FL_TOK_LIT(byte);
                 atomicAdd(&hist[(idx >> 15) - blk0][byte], 1u);
                 // a literal goes out at the visit of the next position (deflate.zig:214-216)
-                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
+                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1) {
                     bound[pc.first_block + (idx >> 15) + 1] = h0 + p + x + 1;
+                    qgap[pc.first_block + (idx >> 15) + 1] = 0;
+                }
                 idx++;
             }
             if (mk && dd) {
@@ -420,8 +423,11 @@ __global__ __launch_bounds__(FL_EMIT_THREADS, 8) void k_st_emit(const uint8_t* _
                 atomicAdd(&hist[(idx >> 15) - blk0][257 + fl_len_index(ll)], 1u);
                 atomicAdd(&hist[(idx >> 15) - blk0][286 + fl_dist_code(d0)], 1u);
                 // a match of at least `lazy` goes out at its own visit, a shorter one at the next
-                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1)
-                    bound[pc.first_block + (idx >> 15) + 1] = h0 + p + nl + ((ll + 3 >= prm.lazy) ? 0 : 1);
+                if ((idx & (FL_MAX_TOKENS - 1)) == FL_MAX_TOKENS - 1) {
+                    const uint32_t adv = (ll + 3 >= prm.lazy) ? 0u : 1u;
+                    bound[pc.first_block + (idx >> 15) + 1] = h0 + p + nl + adv;
+                    qgap[pc.first_block + (idx >> 15) + 1] = ll + 3 - adv;  // Q1: the match's bytes the window has not advanced over
+                }
             }
         }
     }
@@ -440,6 +446,7 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
                                                   const fl_piece* __restrict__ pieces,
                                                   const uint32_t* __restrict__ piece_ntok,
                                                   const uint32_t* __restrict__ bound,
+                                                  const uint32_t* __restrict__ qgap, uint32_t repair,
                                                   const uint32_t* __restrict__ zones,
                                                   fl_block_plan* __restrict__ plans) {
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
             plan->tok_start = 0;
             plan->tok_count = 0;
             plan->no_input = 0;
+            plan->q1_gap = 0;
             continue;
         }
         if (k >= nblk) {
@@ -468,14 +476,22 @@ __global__ __launch_bounds__(64) void k_st_blocks(const fl_chunk* __restrict__ c
             continue;
         }
         const bool last = k + 1 == nblk;
-        const uint32_t start = k ? bound[pc.first_block + k] : pc.start;
-        const uint32_t end = last ? pc.end : bound[pc.first_block + k + 1];
+        // (Q1: a full block that ends in a match is flushed before the window advances over the match; with `repair` the slices
+        // are the bytes the tokens cover, the slides still those of the visit in which the block is flushed)
+        const uint32_t g0 = k ? qgap[pc.first_block + k] : 0u, g1 = last ? 0u : qgap[pc.first_block + k + 1];
+        uint32_t start = k ? bound[pc.first_block + k] : pc.start;
+        uint32_t end = last ? pc.end : bound[pc.first_block + k + 1];
         // window start when the block goes out: inside the visit of `end` for a full block; for
         // the last one at the flush / finish call, when every slide the written bytes caused is done
         const uint32_t slides = last ? fl_slides_when_written(pc.end) : fl_slides_before(end, zone, ck.n_slides);
         plan->valid = 1;
         plan->tok_start = pc.start + k * FL_MAX_TOKENS;
         plan->tok_count = last ? total - k * FL_MAX_TOKENS : FL_MAX_TOKENS;
+        if (repair) {
+            start += g0;
+            end += g1;
+        }
+        plan->q1_gap = repair ? 0u : g1;
         const bool no_input = start < slides * FL_SEG;  // SlidingWindow.zig:40, 119-123: fp went negative
         plan->in_start = start;
         plan->in_len = no_input ? FL_NO_INPUT : end - start;  // (a block without input is never stored)

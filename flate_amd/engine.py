@@ -19,8 +19,14 @@ class Engine:
         self._h = C.c_void_p()
         rc = self._L.flate_hip_create(int(device), C.byref(self._h))
         if rc != 0:
+            import sys
+            hint = ""
+            if "torch" in sys.modules and os.environ.get("FLATE_HIP_PRELOAD_TORCH_HIP", "0") in ("", "0"):
+                # (two HIP runtimes in one process: the second to come up finds no device -- flate_amd/_capi.py)
+                hint = ("; this process also runs PyTorch, which ships its own libamdhip64: import torch BEFORE flate_amd, "
+                        "or set FLATE_HIP_PRELOAD_TORCH_HIP=1 before importing flate_amd, so that both use one runtime")
             raise FlateHipError("flate_hip_create(device=%d) failed with %d: no usable MI355X / HIP device "
-                                "(there is no CPU fallback)" % (device, rc))
+                                "(there is no CPU fallback)%s" % (device, rc, hint))
         self.device = device
 
     def close(self):
@@ -58,6 +64,11 @@ class Engine:
 
     def set_sync(self, flag):
         self._L.flate_hip_set_sync(self._h, int(bool(flag)))
+
+    def set_flags(self, flags):
+        """_capi.DEFLATE_REPAIR_Q1: levels 4..9 hand every block the bytes its tokens cover (streams that always inflate
+        to their input; they differ from the reference's only where the reference's own stream is broken: status 102)."""
+        self._check(self._L.flate_hip_set_flags(self._h, int(flags)), "flate_hip_set_flags")
 
     def compress_bound(self, n, container=0, mode=6):
         return self._L.flate_hip_compress_bound(int(n), container, mode)

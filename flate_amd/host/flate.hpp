@@ -58,6 +58,16 @@ class Engine {
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
     flate_hip_handle handle() const { return h_; }
+    // FLATE_HIP_DEFLATE_REPAIR_Q1: every block is handed the bytes its tokens cover (streams that always inflate to
+    // their input; they differ from the reference's only where the reference's own stream is broken, below)
+    void set_flags(uint32_t flags) {
+        const int rc = flate_hip_set_flags(h_, flags);
+        if (rc != FLATE_HIP_OK) throw Error(rc, "flate_hip_set_flags");
+    }
+    // streams written so far that are byte for byte the reference's and do not inflate to their input (quirk Q1,
+    // FLATE_HIP_ST_REFERENCE_Q1_STREAM in include/flate_hip.h): the reference writes them without a word, so does the
+    // facade -- and counts them
+    uint64_t reference_q1_streams() const { return q1_streams_; }
     static Engine& instance() {
         static Engine e(0);
         return e;
@@ -74,7 +84,8 @@ class Engine {
         const int rc = flate_hip_compress_batch(h_, in.empty() ? &dummy : in.data(), in_off, 1, container, mode,
                                                 out.data(), out_off, &out_len, &status, FLATE_HIP_MEM_HOST);
         if (rc != FLATE_HIP_OK) throw Error(rc, std::string("flate_hip_compress_batch: ") + flate_hip_last_error(h_));
-        if (status) throw Error(status);
+        if (status == FLATE_HIP_ST_REFERENCE_Q1_STREAM) q1_streams_++;
+        else if (status) throw Error(status);
         out.resize(out_len);
         return out;
     }
@@ -98,7 +109,8 @@ class Engine {
                                                 finish ? 1 : 0, container, mode, out.data(), cap, &out_len, &status,
                                                 FLATE_HIP_MEM_HOST);
         if (rc != FLATE_HIP_OK) throw Error(rc, std::string("flate_hip_compress_flush: ") + flate_hip_last_error(h_));
-        if (status) throw Error(status);
+        if (status == FLATE_HIP_ST_REFERENCE_Q1_STREAM) q1_streams_++;
+        else if (status) throw Error(status);
         out.resize(out_len);
         return out;
     }
@@ -128,6 +140,7 @@ class Engine {
 
    private:
     flate_hip_handle h_ = nullptr;
+    uint64_t q1_streams_ = 0;
 };
 
 namespace detail {

@@ -81,8 +81,25 @@ enum {
     FLATE_HIP_ST_WRONG_STORED_BLOCK_NLEN = 13,
     FLATE_HIP_ST_INVALID_DYNAMIC_BLOCK_HEADER = 14,
     FLATE_HIP_ST_OUTPUT_TOO_SMALL = 100,
-    FLATE_HIP_ST_CHUNK_TOO_LARGE = 101 /* reserved; not produced any more: long inputs take the whole-stream path */
+    FLATE_HIP_ST_CHUNK_TOO_LARGE = 101, /* reserved; not produced any more: long inputs take the whole-stream path */
+    /* Compress, levels 4..9, informational: out / out_len hold exactly the reference's bytes for this input, and those
+     * bytes DO NOT inflate to the input.  The reference hands its block writer a full block of 32768 tokens before its
+     * window has advanced over the last token's match (deflate.zig:227-230 -> 268-270 -> SlidingWindow.zig:119-123; the
+     * advance is at deflate.zig:193), so the raw slice of that block ends up to 258 bytes early and the next block's slice
+     * starts there; when exactly ONE of the two blocks goes out stored (block_writer.zig:369) the stream loses those bytes
+     * (the first block stored) or holds them twice (the second).  Every inflater -- the reference's included -- then
+     * reports a wrong checksum / size for gzip and zlib, and returns other bytes than went in for a raw stream.
+     * See FLATE_HIP_DEFLATE_REPAIR_Q1. */
+    FLATE_HIP_ST_REFERENCE_Q1_STREAM = 102
 };
+
+/* handle flags (flate_hip_set_flags).  bit0: compress at levels 4..9 hands every block the bytes its tokens cover -- the
+ * reference with its window advanced before the tokens are flushed.  Streams differ from the reference's ONLY for inputs on
+ * which a full token block ends in a match (the slices that decide "stored or Huffman" move by the match's length); they
+ * always inflate to the input and status FLATE_HIP_ST_REFERENCE_Q1_STREAM is never produced.  Default 0: the reference's
+ * bytes, whatever they decode to. */
+enum { FLATE_HIP_DEFLATE_REPAIR_Q1 = 1 };
+int flate_hip_set_flags(flate_hip_handle h, uint32_t flags);
 
 /* decompress flags.  bit0: reference-strict dynamic block header (quirk Q6,
  * inflate.zig:161-180: a code-length repeat that crosses the HLIT/HDIST
@@ -120,7 +137,8 @@ size_t flate_hip_compress_bound(size_t n, int container, int mode);
  *   out_len  n_chunks produced lengths (bytes)
  *   status   n_chunks FLATE_HIP_ST_* codes
  * The bytes of chunk i are exactly what the reference writes for the same
- * input with the same container and level/mode.
+ * input with the same container and level/mode (status 0, or 102 where the reference's own stream is
+ * broken: FLATE_HIP_ST_REFERENCE_Q1_STREAM).
  * Host buffers (FLATE_HIP_MEM_HOST): a slot's bytes beyond out_len[i] are unspecified (zeros or
  * what the caller had there; a pinned `out` is written in place by the DMA engine and a kernel).
  */

@@ -879,6 +879,7 @@ struct fo_deflate {
     int has_prev_match, has_prev_literal;
     uint32_t prev_match;
     uint8_t prev_literal;
+    size_t q1_pending; /* bytes of the token being added that the window has not advanced over yet (quirk Q1, below) */
     /* what every flushTokens handed to the block writer, in stream offsets (tests: the window-slide path against the
      * independent model of tests/golden/make_slide_fixtures.py): tokens, final, has input, slice start, slice length */
     uint64_t slid_total;
@@ -921,12 +922,20 @@ const uint32_t* fo_deflate_token_log(const fo_deflate* d, size_t* count) {
     return d->bw.tok_log;
 }
 
+/* NOT the reference's behaviour, off by default (tests of FLATE_HIP_DEFLATE_REPAIR_Q1 only): the reference with its window
+ * advanced (deflate.zig:193) BEFORE a full token block is flushed (deflate.zig:227-230), so that the slice handed to the block
+ * writer is the bytes the tokens cover.  As written the slice ends before the bytes of a match that is the block's 32768th
+ * token (quirk Q1). */
+static int fo_q1_repair = 0;
+void fo_set_q1_repair(int on) { fo_q1_repair = on; }
+
 /* deflate.zig:268-288 */
 static void df_flush_tokens(fo_deflate* d, int flush_opt) {
     /* win.tokensBuffer(): SlidingWindow.zig:119-123 */
+    const size_t rp_eff = d->win.rp + (fo_q1_repair ? d->q1_pending : 0);
     int has_input = d->win.fp >= 0;
     const uint8_t* input = has_input ? d->win.buffer + d->win.fp : NULL;
-    size_t input_len = has_input ? d->win.rp - (size_t)d->win.fp : 0;
+    size_t input_len = has_input ? rp_eff - (size_t)d->win.fp : 0;
     if (d->bw.log_tokens) {
         if (d->blk_log_len + 5 > d->blk_log_cap) {
             d->blk_log_cap = d->blk_log_cap ? d->blk_log_cap * 2 : 320;
@@ -946,7 +955,7 @@ static void df_flush_tokens(fo_deflate* d, int flush_opt) {
     if (flush_opt == FLUSH_FLUSH) blockw_stored_block(&d->bw, NULL, 0, 0);
     if (flush_opt != FLUSH_NONE) bw_flush(&d->bw.bw);
     d->tokens_pos = 0;
-    d->win.fp = (long)d->win.rp; /* SlidingWindow.zig:113-115 */
+    d->win.fp = (long)rp_eff; /* SlidingWindow.zig:113-115 (rp_eff == rp unless the test-only repair is on) */
 }
 /* deflate.zig:227-230 */
 static void df_add_token(fo_deflate* d, uint32_t t) {
@@ -956,8 +965,10 @@ static void df_add_token(fo_deflate* d, uint32_t t) {
 static void df_add_prev_literal(fo_deflate* d) { /* deflate.zig:214-216 */
     if (d->has_prev_literal) df_add_token(d, FO_TOK_LIT(d->prev_literal));
 }
-static uint16_t df_add_match(fo_deflate* d, uint32_t m) { /* deflate.zig:220-225 */
+static uint16_t df_add_match(fo_deflate* d, uint32_t m, size_t not_advanced) { /* deflate.zig:220-225 */
+    d->q1_pending = not_advanced;
     df_add_token(d, m);
+    d->q1_pending = 0;
     d->has_prev_literal = 0;
     d->has_prev_match = 0;
     return (uint16_t)(FO_TOK_LENLIT(m) + 3);
@@ -1016,7 +1027,7 @@ static void df_tokenize(fo_deflate* d, int flush_opt) {
         if (df_find_match(d, pos, lh, lh_len, min_len, &match)) {
             df_add_prev_literal(d);
             if (FO_TOK_LENLIT(match) + 3 >= d->level.lazy) {
-                step = df_add_match(d, match);
+                step = df_add_match(d, match, FO_TOK_LENLIT(match) + 3u);
             } else {
                 d->prev_literal = literal;
                 d->has_prev_literal = 1;
@@ -1025,7 +1036,7 @@ static void df_tokenize(fo_deflate* d, int flush_opt) {
             }
         } else {
             if (d->has_prev_match) {
-                step = (uint16_t)(df_add_match(d, d->prev_match) - 1);
+                step = (uint16_t)(df_add_match(d, d->prev_match, FO_TOK_LENLIT(d->prev_match) + 2u) - 1);
             } else {
                 df_add_prev_literal(d);
                 d->prev_literal = literal;

@@ -112,7 +112,15 @@ def tok_decode(t):
     return ("L", (t >> 15) & 0xFF)
 
 
-def compress(data, container=RAW, mode=6):
+def compress(data, container=RAW, mode=6, repair_q1=False):
+    """repair_q1: NOT the reference -- the reference with its window advanced before a full token block is flushed (the
+    twin of FLATE_HIP_DEFLATE_REPAIR_Q1; oracle/flate_oracle.c, fo_set_q1_repair)."""
+    if repair_q1:
+        lib().fo_set_q1_repair(1)
+        try:
+            return compress(data, container, mode)
+        finally:
+            lib().fo_set_q1_repair(0)
     p, n, keep = _buf(data)
     cap = lib().fo_compress_bound(n)
     out = np.empty(cap, dtype=np.uint8)

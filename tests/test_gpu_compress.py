@@ -150,6 +150,88 @@ def test_q1_token_flush_input_slice():
             assert got == O.compress(d, 0, level)
 
 
+def _q1_inputs(level):
+    """Inputs whose 32768th token is a match next to a stored block (quirk Q1), made with the oracle's
+    tokenizer: `lost` -- 32767 tokens of noise (the block goes out stored), a 40-byte copy, text (Huffman): the reference's
+    stream loses the copy's bytes; `twice` -- 32767 tokens over 64 symbols (Huffman), a 16-byte copy, 600 bytes of noise
+    (stored): the copy's bytes come out twice."""
+    def covered(data, ntok):
+        pos = 0
+        for t in O.tokenize(data, level)[:ntok]:
+            t = int(t)
+            pos += ((t >> 15) & 0xFF) + 3 if (t >> 23) & 1 else 1
+        return pos
+
+    out = {}
+    for seed in (0, 1):
+        a = np.random.default_rng(seed).integers(0, 256, 33000, dtype=np.uint8).tobytes()
+        out["lost%d" % seed] = a[:covered(a, 32767)] + a[100:140] + (b"compressible tail " * 2000)[:30000]
+        h = np.random.default_rng(seed).integers(0, 64, 40000, dtype=np.uint8).tobytes()
+        out["twice%d" % seed] = (h[:covered(h, 32767)] + h[200:216] +
+                                 np.random.default_rng(1000 + seed).integers(0, 256, 600, dtype=np.uint8).tobytes())
+    # ... and the same seam in a stream that slides its window (the whole-stream path: k_st_emit / k_st_blocks)
+    a = np.random.default_rng(7).integers(0, 256, 33000, dtype=np.uint8).tobytes()
+    out["lost_long"] = a[:covered(a, 32767)] + a[100:140] + (b"compressible tail, and a long one " * 6000)[:150000]
+    return out
+
+
+@pytest.mark.parametrize("level", [4, 6, 9])
+def test_q1_streams_are_reported_and_repairable(level):
+    # VERDICT r5 item 2: the reference's Q1 stream is replicated byte for byte (status 102, informational) and
+    # FLATE_HIP_DEFLATE_REPAIR_Q1 writes a stream that inflates to the input -- under the oracle, puff and zlib.
+    # deflate.zig:193, 227-230, 268-288; SlidingWindow.zig:119-123.
+    import zlib
+    from flate_amd import _capi
+    eng = engine()
+    inputs = _q1_inputs(level)
+    names, datas = list(inputs), list(inputs.values())
+    n102 = 0
+    for container in (0, 1):
+        outs, st = eng.compress_many(datas, container, level)
+        for nm, d, got, s in zip(names, datas, outs, st):
+            assert got == O.compress(d, container, level), (nm, "default bytes are the reference's")
+            name, back = O.decompress(got, container, 0, cap=len(d) + 600)[:2]
+            broken = not (name == "Ok" and back == d)
+            assert s == (_capi.ST_REFERENCE_Q1_STREAM if broken else 0), (nm, s, name, len(back), len(d))
+            n102 += broken
+    assert n102 >= 4, "the constructions above no longer reach the seam"
+    assert _capi.status_name(102) == "ReferenceQ1Stream"
+    eng.set_flags(_capi.DEFLATE_REPAIR_Q1)
+    try:
+        for container in (0, 1, 2):
+            outs, st = eng.compress_many(datas, container, level)
+            assert st == [0] * len(datas)
+            for nm, d, got in zip(names, datas, outs):
+                assert got == O.compress(d, container, level, repair_q1=True), (nm, "the oracle's twin of the repair")
+                assert O.decompress(got, container, 0, cap=len(d) + 600)[:2] == ("Ok", d), nm
+                assert zlib.decompress(got, {0: -15, 1: 31, 2: 15}[container]) == d, nm
+                if container == 0:
+                    assert O.puff(got) == (0, d), nm
+        # flush points around the seam (flate_hip_compress_flush): the piece that holds it behaves the same way
+        d = inputs["lost0"]
+        fl, s = eng.compress_flush(d, [100, len(d) - 50], True, 0, level)
+        assert s == 0 and zlib.decompress(fl, -15) == d
+        back, st2, _ = eng.decompress_many(outs, 2, caps=[len(x) + 8 for x in datas])
+        assert st2 == [0] * len(datas) and back == datas
+    finally:
+        eng.set_flags(0)
+    # the flag is off again: the reference's bytes
+    outs, st = eng.compress_many(datas[:1], 0, level)
+    assert outs[0] == O.compress(datas[0], 0, level)
+    # the mirror: the reference's bytes with a warning, or Options(repair_q1=True)
+    import io
+    from flate_amd import api, flate
+    if level == 6:
+        d = inputs["lost0"]
+        w = io.BytesIO()
+        with pytest.warns(api.ReferenceQ1StreamWarning):
+            flate.compress(d, w, engine=eng)
+        assert w.getvalue() == O.compress(d, 0, 6)
+        w = io.BytesIO()
+        flate.compress(d, w, api.Options(6, repair_q1=True), engine=eng)
+        assert zlib.decompress(w.getvalue(), -15) == d
+
+
 def test_long_chunk_takes_the_whole_stream_path():
     # levels 4..9: inputs of more than 65535 bytes are no longer refused (tests/test_gpu_stream.py)
     eng = engine()

@@ -21,7 +21,7 @@ class Plan(C.Structure):
     _fields_ = [("type", C.c_uint32), ("size_bits", C.c_uint32), ("hdr_nbits", C.c_uint32),
                 ("final_block", C.c_uint32), ("in_start", C.c_uint32), ("in_len", C.c_uint32),
                 ("tok_start", C.c_uint32), ("tok_count", C.c_uint32), ("valid", C.c_uint32),
-                ("pad_", C.c_uint32), ("bit_off", C.c_uint64), ("hdr", C.c_uint8 * 640),
+                ("no_input", C.c_uint32), ("q1_gap", C.c_uint32), ("pad_", C.c_uint32), ("bit_off", C.c_uint64), ("hdr", C.c_uint8 * 640),
                 ("lit", C.c_uint16 * (2 * 286)), ("dist", C.c_uint16 * (2 * 30))]
 
 

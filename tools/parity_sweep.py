@@ -33,7 +33,9 @@ for rd in range(rounds):
         container = int(rng.integers(0, 3))
         outs, st = eng.compress_many(datas, container, mode)
         for d, got, s in zip(datas, outs, st):
-            if s != 0 or got != O.compress(d, container, mode):
+            # status 102 (the reference's own Q1 stream): exactly when the ORACLE's inflater does not get the input back
+            back_ok = mode < 4 or O.decompress(got, container, 0, cap=len(d) + 600)[:2] == ("Ok", d)
+            if s != (0 if back_ok else 102) or got != O.compress(d, container, mode):
                 bad += 1
                 print("CHUNK MISMATCH", rd, mode, container, len(d), s)
         back, st2, _ = eng.decompress_many(outs, container, 0, [len(d) + 8 for d in datas])
@@ -57,7 +59,8 @@ for rd in range(rounds):
         container = int(rng.integers(0, 3))
         outs, st = eng.compress_many(datas, container, mode)
         for d, got, s in zip(datas, outs, st):
-            if s != 0 or got != O.compress(d, container, mode):
+            back_ok = O.decompress(got, container, 0, cap=len(d) + 600)[:2] == ("Ok", d)
+            if s != (0 if back_ok else 102) or got != O.compress(d, container, mode):
                 bad += 1
                 print("STREAM MISMATCH", rd, mode, container, len(d), s)
     # sync flushes
@@ -71,7 +74,7 @@ for rd in range(rounds):
         mode = int(rng.choice([0, 1, 4, 6, 9]))
         container = int(rng.integers(0, 3))
         got, s = eng.compress_flush(d, fl, finish, container, mode)
-        if s != 0 or got != _oracle_stream(d, fl, finish, container, mode)[0]:
+        if s not in (0, 102) or got != _oracle_stream(d, fl, finish, container, mode)[0]:
             bad += 1
             print("FLUSH MISMATCH", rd, mode, container, n, fl, finish, s)
     print("round", rd, "done, mismatches so far:", bad, flush=True)

@@ -58,6 +58,8 @@ fn statusToError(st: i32) Error!void {
         13 => error.WrongStoredBlockNlen,
         14 => error.InvalidDynamicBlockHeader,
         100 => error.OutputTooSmall,
+        // 102 (FLATE_HIP_ST_REFERENCE_Q1_STREAM) is not an error here: the bytes are the reference's own for this input
+        // (deflate.zig:227-230 flushes a full token block before :193 advances the window) -- runCompress counts them
         else => error.DeviceError,
     };
 }
@@ -93,6 +95,16 @@ const mode_store: c_int = 0;
 const gpa = std.heap.page_allocator;
 var g_handle: Handle = null;
 
+/// Streams written so far that are byte for byte the reference's and do not inflate to their input (quirk Q1: include/flate_hip.h,
+/// FLATE_HIP_ST_REFERENCE_Q1_STREAM).  `setRepairQ1(true)` makes every stream inflate to its input instead (bytes then differ
+/// from the reference's on exactly those inputs).
+pub var reference_q1_streams: u64 = 0;
+pub extern "c" fn flate_hip_set_flags(h: Handle, flags: u32) c_int;
+pub fn setRepairQ1(on: bool) Error!void {
+    const h = try engine();
+    if (flate_hip_set_flags(h, if (on) 1 else 0) != 0) return error.DeviceError;
+}
+
 /// One engine per process, created on first use.  There is no CPU fallback: without a usable
 /// MI355X every call fails with error.DeviceError.
 fn engine() Error!Handle {
@@ -125,6 +137,10 @@ fn runCompress(input: []const u8, flushes: []const u64, finish: bool, container:
     } else {
         if (flate_hip_compress_flush(h, in_ptr, input.len, if (flushes.len == 0) null else flushes.ptr, @intCast(flushes.len), @intFromBool(finish), container, mode, out.ptr, cap, &out_len, &status, 0) != 0)
             return error.DeviceError;
+    }
+    if (status == 102) {
+        reference_q1_streams += 1;
+        status = 0;
     }
     try statusToError(status);
     return out[0..@intCast(out_len)]; // caller frees the whole allocation via `gpa.free(slice.ptr[0 .. cap + 8])`: see CompressorImpl.emit
