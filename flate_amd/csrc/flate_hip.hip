@@ -326,6 +326,9 @@ uint64_t stream_pass_byte_limit(const flate_hip_ctx* h) { return h->knobs.stream
 
 // Levels 4..9, whole-stream pass: tokenizer kernels (kernels_stream.h).  Leaves tokens,
 // histograms and the block table for the shared back end.
+#ifndef FL_STREAM_FIX_MAX
+#define FL_STREAM_FIX_MAX 3u  // fix launches of a grouped whole-stream pass before it is handed to the sort / match tiles
+#endif
 int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params& prm, uint32_t nc, uint32_t nb,
                          const StreamTables& t, const fl_chunk* hch /* the pass's chunks, host copy */) {
     hipStream_t st = h->stream;
@@ -342,13 +345,21 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     if ((rc = ensure(h, h->nsorted, sizeof(uint32_t) * tiles_per_launch))) return rc;
     if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * tiles_per_launch))) return rc;
     if ((rc = ensure(h, h->S, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(h, h->NC, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(h, h->rec, npos * 2 * sizeof(uint32_t) + 64))) return rc;
     if ((rc = ensure(h, h->desc, npos * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(h, h->tokens, npos * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(h, h->jmp, npos * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(h, h->marks, npos / 8))) return rc;
-    if ((rc = ensure(h, h->exitmap, ((size_t)nseg + 1) * FL_SEG_ENTRIES * sizeof(uint16_t)))) return rc;
+    // what only the sort / match tiles and the stitch over records need (about 14 bytes per input byte): not reserved for a
+    // pass that takes the windows of k_lz_parse<true>
+    auto ensure_tile_workspace = [&]() -> int {
+        int r;
+        if ((r = ensure(h, h->NC, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint32_t)))) return r;
+        if ((r = ensure(h, h->rec, npos * 2 * sizeof(uint32_t) + 64))) return r;
+        if ((r = ensure(h, h->jmp, npos * sizeof(uint16_t)))) return r;
+        if ((r = ensure(h, h->exitmap, ((size_t)nseg + 1) * FL_SEG_ENTRIES * sizeof(uint16_t)))) return r;
+        // positions a flush keeps out of the hash table get no record from the match finder
+        if (t.any_flush && hipMemsetAsync(h->rec.p, 0, npos * 2 * sizeof(uint32_t), st) != hipSuccess) return FLATE_HIP_E_LAUNCH;
+        return 0;
+    };
     if ((rc = ensure(h, h->entry, sizeof(uint32_t) * (nseg + 1)))) return rc;
     if ((rc = ensure(h, h->segtok, sizeof(uint32_t) * (nseg + 1)))) return rc;
     if ((rc = ensure(h, h->tokbase, sizeof(uint32_t) * (nseg + 1)))) return rc;
@@ -363,8 +374,6 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         HIP_OK(h, hipMemcpyAsync(h->zones.p, t.zones.data(), sizeof(uint32_t) * t.zones.size(), hipMemcpyHostToDevice, st));
     HIP_OK(h, hipMemsetAsync(h->hist.p, 0, sizeof(uint32_t) * 320 * (size_t)nb, st));
     HIP_OK(h, hipMemsetAsync(h->marks.p, 0, npos / 8, st));
-    // positions a flush keeps out of the hash table get no record from the match finder
-    if (t.any_flush) HIP_OK(h, hipMemsetAsync(h->rec.p, 0, npos * 2 * sizeof(uint32_t), st));
     HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
 
     const fl_chunk* dch = (const fl_chunk*)h->chunks.p;
@@ -456,7 +465,11 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                                (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, 0u);
         }
         // the groups that were parsed from a guess: again from where the group before them leaves, until nothing moves any more
-        // (one launch in practice: a parse falls in step within a few bytes; the loop is what makes it exact)
+        // (one launch in practice: a parse falls in step within a few bytes; the loop is what makes it exact).  NOT on
+        // periodic data: in a stream of one repeated byte every anchor is a 258-byte match, a parse from a guessed entry never
+        // meets the true one, and every launch settles one more group (about ng launches).  After FL_STREAM_FIX_MAX
+        // launches the pass is given to the sort / match tiles, which cost the same whatever the data.
+        bool gave_up = false;
         for (uint32_t it = 0; grouped; it++) {
             HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
             {
@@ -469,14 +482,24 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             HIP_OK(h, hipMemcpyAsync(&flag, d_dirty, sizeof flag, hipMemcpyDeviceToHost, st));
             HIP_OK(h, hipStreamSynchronize(st));
             if (!flag) break;
-            if (it > ng) return FLATE_HIP_E_LAUNCH;  // (cannot happen: every launch settles at least one more group)
+            if (it + 1 >= FL_STREAM_FIX_MAX) {
+                gave_up = true;
+                break;
+            }
         }
-        {
+        if (gave_up) {
+            windows = false;  // the tiles below; the anchors marked so far go
+            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, npos / 8, st));
+            if ((rc = ensure(h, h->nsorted, sizeof(uint32_t) * tiles_per_launch))) return rc;
+            if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * tiles_per_launch))) return rc;
+            if ((rc = ensure(h, h->S, tiles_per_launch * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
+        } else {
             ProfScope ps(h, K_ST_PARSE);
             hipLaunchKernelGGL(k_st_count, dim3(nseg), dim3(FL_PARSE_THREADS), 0, st, dch, dpc, dsg, (const uint32_t*)h->desc.p,
                                (const uint32_t*)h->marks.p, (uint32_t*)h->segtok.p);
         }
     }
+    if (!windows && (rc = ensure_tile_workspace())) return rc;
     for (size_t t0 = 0; !windows && t0 < t.tiles.size(); t0 += tiles_per_launch) {
         const uint32_t nt = (uint32_t)std::min(tiles_per_launch, t.tiles.size() - t0);
         const fl_tile* dti = (const fl_tile*)h->tiles.p + t0;

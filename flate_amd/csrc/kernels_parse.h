@@ -490,10 +490,17 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         if (sck.skip) return;
         if (sw.prev != ~0u) {
             if (fix) {
-                // the true entry: where the group before leaves (absolute stream position)
-                const uint32_t e = __hip_atomic_load(&gexit[sw.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (e == gentry[blockIdx.x]) return;  // parsed from there already
-                __syncthreads();                      // (every thread has read the old entry)
+                // the true entry: where the group before leaves (absolute stream position).  ONE thread reads it: the group
+                // before may store a new exit in this very launch, and threads that saw different values would part ways here
+                // (some return, the others parse on with two different entries)
+                if (tid == 0) {
+                    sh_next_entry = __hip_atomic_load(&gexit[sw.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh_exit = gentry[blockIdx.x];
+                }
+                __syncthreads();
+                const uint32_t e = sh_next_entry, was = sh_exit;
+                __syncthreads();  // (both slots are written again further down)
+                if (e == was) return;  // parsed from there already
                 if (tid == 0) gentry[blockIdx.x] = e;
                 carry = e - FL_MAX_DIST * sw.wfirst;
             } else {

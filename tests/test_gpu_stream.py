@@ -253,6 +253,34 @@ def test_adversarial_long_streams_match_oracle():
             assert got == O.compress(d, O.GZIP, level), (level, len(d))
 
 
+def test_periodic_streams_do_not_loop_in_the_grouped_fix(monkeypatch):
+    # in a stream of one repeated byte (or any data of period 258 k) a group of windows parsed from a guessed entry
+    # never falls in step with the true parse, and every fix launch settles only one more group.  The pass gives up after
+    # FL_STREAM_FIX_MAX launches and takes the sort / match tiles: same bytes, a bounded number of launches.
+    monkeypatch.setenv("FLATE_HIP_STREAM_WINDOWS", "1")
+    monkeypatch.setenv("FLATE_HIP_STREAM_GROUP", "4")
+    eng = engine()
+    datas = [bytes(24 << 20), (b"ab" * 129) * 40000, bytes(3 << 20) + b"x" + bytes(5 << 20)]
+    for d in datas:
+        eng.profile_enable(True)
+        eng.profile_reset()
+        outs, st = eng.compress_many([d], O.GZIP, 6)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        assert st == [0] and outs[0] == O.compress(d, O.GZIP, 6), len(d)
+        assert prof.get("k_lz_parse", (0, 0))[1] <= 4, prof  # the first launch + FL_STREAM_FIX_MAX
+    # text does settle in the first fix launch and stays on the windows
+    from flate_amd import synth
+    d = synth.text(synth.SEED_TEXT, 6 << 20).tobytes()
+    eng.profile_enable(True)
+    eng.profile_reset()
+    outs, st = eng.compress_many([d], O.RAW, 6)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    assert st == [0] and outs[0] == O.compress(d, O.RAW, 6)
+    assert prof["k_lz_parse"][1] == 2 and "k_lz_match" not in prof, prof
+
+
 def test_whole_stream_tokens_match_the_independent_slide_fixtures():
     # tests/golden/slide: inputs of 150-300 KB with token lists from a pure-Python model of the reference that is
     # independent of the oracle (tests/golden/make_slide_fixtures.py): the GPU's whole-stream path against it directly
