@@ -579,6 +579,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #endif
 
     for (uint32_t sub = 0; sub < 2; sub++) {
+        // (STREAM: the window's fields anew in every sub-pass -- the kernel is short of SCALAR registers, 187 of them lived in
+        // vector registers and 35 vector registers in scratch: what the staging needs must not live through the automaton)
+        uint32_t c_l = c;
+        if (STREAM) asm volatile("" : "+s"(c_l));
+        const fl_chunk ckl = chunks[c_l];
+        const uint32_t N = ckl.in_len;
+        const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
+        const uint8_t* src = in + ckl.in_off;
+        const uint16_t* pvg = prev_all + (uint64_t)c_l * FL_CHUNK_STRIDE;
         const uint32_t t0 = sub ? max(PZ_TA, t_first) : t_first;
         const uint32_t end = min(t_last, sub ? 65536u : PZ_TA);  // targets [t0, end)
         if (t0 >= end) {  // (a window's first target lies below PZ_TA: sub-pass B never runs without A's staging)
