@@ -522,6 +522,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         enum { CS_MOVE = 0, CS_WALK = 1, CS_MEAS = 2, CS_RANK = 3, CS_IDLE = 4, CS_RUN = 5 };
         uint32_t g_link = 0, g_rp = 0, g_rq = 0;  // values of the gathers in flight
         const uint32_t RUNT = 0x80000000u;
+        const uint32_t PROBE_RUN = 0x40000000u;  // pend_l of a probe at the top of a run of p's own byte: within the budget, the run is looked at
         auto allsame8 = [&](uint32_t x, uint32_t& pat) {  // the 8 bytes at x are one repeated byte (pat = that byte, four times)
             uint32_t w0, w1;
             fl_lds_load8(win32, x, w0, w1);
@@ -577,6 +578,56 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
             st = ST_DONE;
         }
         uint32_t cs = st != ST_DONE ? CS_MOVE : CS_IDLE;
+        // The walk leaves a run of p's own byte (pattern bp) in which nothing (more) can help: on below what is known to be run,
+        // from position `from` down; what is skipped counts as looked at.  Round 6: on L8 with p itself at eight bytes of that
+        // byte the chain's next member below the run's start is the top of the run BEFORE it -- found in the window when at
+        // most eight other bytes lie between (sparse data: one), no link fetched: members of other strings with the same hash
+        // are left out, they share fewer than K bytes with p and K - 1 are in hand (tools/multilevel_model.c, `shortcuts`).
+        auto leave_run = [&](uint32_t from, uint32_t bp) {
+            const uint32_t t = scan_down(from, from > WK_RUNSKIP ? from - WK_RUNSKIP : 0u, bp);
+            cs = CS_WALK;
+            if (K == WK_L4) {
+                const uint32_t need = from - t;
+                if (cnt < need) cs = CS_MOVE;
+                cnt -= min(cnt, need);
+                last = t;
+            } else {
+                cnt = cnt > 2u ? cnt - 2u : 0u;  // (a candidate of p's bucket is asked for its rank every few runs)
+            }
+            if (cs != CS_WALK) return;
+            q = t;
+            constexpr uint32_t KB = 8u;  // (L8 only: the member found holds eight bytes of the run's byte, like every member (R) is handed)
+            if (K == WK_L8 && off == 0 && prun >= KB && t >= 2u) {
+                const uint8_t* wb = (const uint8_t*)win32;
+                const uint32_t b = bp & 0xffu;
+                if (wb[t - 1u] != b) {  // (the run starts at t: the scan did not end on its own limit)
+                    uint32_t e = t - 1u;
+                    while (e > 0u && t - e <= 8u && wb[e - 1u] != b) e--;
+                    if (e >= KB + lo && wb[e - 1u] == b) {
+                        uint32_t w0, w1;
+                        fl_lds_load8(win32, e - KB, w0, w1);
+                        if (w0 == bp && w1 == bp) {
+                            // the member e - KB, as if its link had arrived: (W)'s budget step, then the run or the ranks
+                            q = e - KB;
+                            if (cnt) cnt--;
+                            if (cnt == 0) {
+                                WK_CNT(c_gath, 2);
+                                pend_l = PROBE_RUN;
+                                g_rp = lk[(3u << 16) + p];
+                                g_rq = lk[(3u << 16) + q];
+                                cs = CS_RANK;
+                            } else {
+                                pend_l = 0;
+                                cs = CS_RUN;
+                            }
+                            return;
+                        }
+                    }
+                }
+            }
+            WK_CNT(c_gath, 1);
+            g_link = lk[(K << 16) + t];
+        };
         bool first_call = true;  // the next move is the first call of the parse (at a, nothing pending)
 #ifdef WK_PROF
         const uint64_t c_tl0 = __builtin_readcyclecounter();
@@ -766,7 +817,19 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                             pend_l = fresh ? 1u : 2u;
                             next = false;
                         } else if (fresh) {
-                            if (same) {
+                            if (same && K != WK_L4 && cnt == 0) {
+                                // Round 6: a walk on L6 / L8 that has just left a run of p's byte with nothing accepted (cnt = 0, see
+                                // (R)) asks the ranks BEFORE it enters the next one: the member lies in p's L4 bucket (at least four
+                                // bytes of the run's byte at both), and beyond the budget the call ends as the reference's does.
+                                // Without it such a walk was never counted down -- sparse zeros at level 9 crossed all 330 runs of
+                                // the window in every call where the reference looks at the nearest 10 to 42 (0.47 GB/s).
+                                WK_CNT(c_gath, 2);
+                                pend_l = PROBE_RUN;
+                                g_rp = lk[(3u << 16) + p];
+                                g_rq = lk[(3u << 16) + qc];
+                                cs = CS_RANK;
+                                next = false;
+                            } else if (same) {
                                 cs = CS_RUN;
                                 pend_l = 0;
                                 next = false;
@@ -857,22 +920,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                     hi = (int32_t)q;
                 }
                 if (target < 0) {
-                    // nothing here can help: on below what is known to be run; what is skipped counts as looked at
-                    const uint32_t t = scan_down(q, q > WK_RUNSKIP ? q - WK_RUNSKIP : 0u, bp);
-                    cs = CS_WALK;
-                    if (K == WK_L4) {
-                        const uint32_t need = q - t;
-                        if (cnt < need) cs = CS_MOVE;
-                        cnt -= min(cnt, need);
-                        last = t;
-                    } else {
-                        cnt = 0;  // (the next candidate of p's bucket is asked for its rank)
-                    }
-                    if (cs == CS_WALK) {
-                        q = t;
-                        WK_CNT(c_gath, 1);
-                        g_link = lk[(K << 16) + t];
-                    }
+                    // nothing here can help
+                    leave_run(q, bp);
                 } else {
                     if (target < (int32_t)lo) target = (int32_t)lo;  // (beyond the distance nothing is looked at)
                     if (K == WK_L4) {
@@ -893,14 +942,15 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
             // ---- (J) the exact length of the candidates in hand; ranks that have arrived
             if (cs == CS_RANK || cs == CS_MEAS) {
                 const uint32_t qc = q - off;
-                bool accept = false;
-                uint32_t l = pend_l & ~RUNT;
+                bool accept = false, left = false;  // left: leave_run has said where the walk goes on
+                uint32_t l = pend_l & ~(RUNT | PROBE_RUN);
                 if (cs == CS_RANK) {
                     WK_CNT(c_rank, 1);
                     const uint32_t dt = g_rp - g_rq;
                     cs = CS_WALK;
                     cnt = WK_PROBE;
                     if (dt <= budget) {
+                        if (pend_l == PROBE_RUN) cs = CS_RUN;  // within the budget: the run, in the next trip's (R)
                         accept = l != 0;  // (0: a probe)
                     } else {
                         cs = CS_MOVE;  // beyond what the reference looks at, and so is everything behind it
@@ -932,6 +982,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                             g_rq = lk[(3u << 16) + qc];
                             cs = CS_RANK;
                         }
+                    } else if (runt) {
+                        // (round 6) the run's best position did not beat what is in hand: below it every position of the run
+                        // matches exactly prun <= best bytes -- the walk leaves the run at once
+                        pend_l = 0;
+                        leave_run(qc, (win32[p >> 2] >> (8u * (p & 3u)) & 0xffu) * 0x01010101u);
+                        left = true;
                     } else {
                         pend_l = 0;
                         cs = CS_WALK;  // the walk goes on behind the candidate
@@ -957,7 +1013,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                         pref = pz_lds4(win32, p + fo);
                     }
                 }
-                if (cs == CS_WALK) {
+                if (cs == CS_WALK && !left) {
                     WK_CNT(c_gath, 1);
                     g_link = lk[(K << 16) + q];
                 }
@@ -996,6 +1052,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         atomicAdd((unsigned long long*)&g_fl_prof[53], (unsigned long long)c_tloop);
         atomicAdd((unsigned long long*)&g_fl_prof[54], (unsigned long long)c_tr0);
     }
-    (void)c_gath; (void)c_rank;
+    atomicAdd((unsigned long long*)&g_fl_prof[55], (unsigned long long)fl_wave_sum(c_gath));
+    atomicAdd((unsigned long long*)&g_fl_prof[56], (unsigned long long)fl_wave_sum(c_rank));
 #endif
 }

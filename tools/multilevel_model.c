@@ -17,7 +17,8 @@
 static uint8_t buf[65536 + 600];
 static uint16_t L4[65536], RK[65536], L6[65536], L8[65536], RS[65536];
 static int N, Mpos, good, lazy, nice, chainmax, offset_mode;
-static unsigned long long n_calls, n_top, n_step[3], n_skip, n_meas, n_rank, n_iter;
+static unsigned long long n_calls, n_top, n_step[3], n_skip, n_meas, n_rank, n_iter, n_short;
+static int shortcuts = 1;
 
 static uint32_t ld32(const uint8_t* b) { uint32_t v; memcpy(&v, b, 4); return v; }
 // the hashes of the upper levels (any function would do: the chains only have to contain what matches)
@@ -94,8 +95,15 @@ static int find_match_impl(int p, int len0, int* dist) {
             // q* = E - prun), so with c bytes in hand the only positions that can help are U = [max(s, q*), min(qc, max(E - c - 1, q*))]:
             // the walk would take every one of them in turn, each a byte longer than the last; it ends up at the lowest one
             // (or at the first that reaches `nice`), unless the budget or the distance ends it before.
+            // (round 6) a walk on L6 / L8 that left the run before this one with nothing accepted asks the ranks before it enters
+            // this one: beyond the budget the call ends, as the reference's does (the member lies in p's own bucket)
+            if (K != 4 && probe == 0) {
+                n_rank++; n_iter++; probe = PROBE;
+                if ((int)RK[p] - (int)RK[qc] > B) return found;
+            }
             n_runskip++; n_iter++;
             const uint8_t bb = buf[p];
+            int leave = 0;  // the walk leaves this run at its start s0
             const int c = len, r = prun, cap = (c > r ? c : r) + 1;
             int d = 8; while (d <= cap && buf[qc + d] == bb) d++;   // bytes b from qc on, counted up to cap + 1
             const int s0 = RS[qc];
@@ -114,8 +122,9 @@ static int find_match_impl(int p, int len0, int* dist) {
             if (target < 0 && len < prun && d > prun) { target = qc; hi = qc; }
             if (target < 0) {
                 // nothing in this run can help: on below its start; what is skipped counts as looked at
-                if (K == 4) { const int need = qc - s0; if (cnt < need) return found; cnt -= need; last = s0; } else probe = 0;
+                if (K == 4) { const int need = qc - s0; if (cnt < need) return found; cnt -= need; last = s0; } else probe = shortcuts ? (probe > 2 ? probe - 2 : 0) : 0;
                 next_from = s0;
+                leave = 1;
             } else {
                 if (target < lo) target = lo;            // (beyond the distance nothing is looked at)
                 if (K == 4) { if (cnt < qc - target) target = qc - cnt; cnt -= qc - target; }
@@ -125,6 +134,13 @@ static int find_match_impl(int p, int len0, int* dist) {
                 const int l = lcp(target, p, maxlen);
                 if (l > len) { accept_l = l; acc = target; }
                 next_from = target;
+                if (shortcuts && !(l > len)) {
+                    // (round 6) the run's best position did not beat what is in hand: below it every position of the run matches
+                    // exactly prun <= len bytes -- on below the run's start at once; what is skipped counts as looked at
+                    if (K == 4) { const int need = target - s0; if (cnt < need) return found; cnt -= need; last = s0; } else probe = probe > 2 ? probe - 2 : 0;
+                    next_from = s0;
+                    leave = 1;
+                }
                 if (K != 4 && l > len) {
                     n_rank++; n_iter++;
                     const int dt = (int)RK[p] - (int)RK[target];
@@ -141,6 +157,18 @@ static int find_match_impl(int p, int len0, int* dist) {
                     if (l >= nice || l >= maxlen) return found;
                     accept_l = 0;  // (done here)
                     if (level_of(len) != K || OFFSET_OF(len) != off) { K = level_of(len); off = OFFSET_OF(len); probe = PROBE; n_top++; n_iter++; q = chain_of(K)[p + off]; continue; }
+                }
+            }
+            if (shortcuts && leave && !accept_l && K == 8 && prun >= K && s0 >= 2) {
+                // (round 6) on L8 with p itself at K = 8 bytes b the chain's next member below s0 is the top of the run before --
+                // found in the window when at most 8 other bytes lie between (sparse data: one), no link fetched.  Members of
+                // other strings with the same hash are left out: they share fewer than K bytes with p and K - 1 are in hand.
+                int e = s0 - 1;                          // (buf[s0 - 1] != b: the run starts at s0)
+                while (e > 0 && s0 - e <= 8 && buf[e - 1] != bb) e--;
+                if (e >= K && buf[e - 1] == bb && all_b(e - K, K, bb) && e - K >= lo) {
+                    n_short++;
+                    q = e - K;
+                    continue;
                 }
             }
         } else {

@@ -26,3 +26,4 @@ c = eng.phase_cycles().astype(np.int64) - t0
 nw = max(int(c[42]), 1)
 print("%s L%d %d chunks: call %.1f ms; per wave: %.0f us, trips %.0f (max %d), walk steps %.0f, runs %.0f, measure iterations %.0f, moves %.0f; rounds per chunk %.1f; per wave us: path following %.0f, trip loops %.0f (round 0: %.0f)"
       % (kind, level, nc, dt * 1e3, c[41] / nw / 2100.0, c[40] / nw, c[51], c[49] / nw, c[47] / nw, c[48] / nw, c[50] / nw, c[43] / nc, c[52] / nw / 2100.0, c[53] / nw / 2100.0, c[54] / nw / 2100.0))
+print("gathers per wave (all lanes): %.0f, rank checks %.0f; per byte of input: %.2f gathers" % (c[55] / nw / 64, c[56] / nw / 64, c[55] / 64 / (nc * 65535.0)))
