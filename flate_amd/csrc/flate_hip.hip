@@ -97,6 +97,7 @@ struct fl_knobs {
     uint32_t stream_group = 0;            // FLATE_HIP_STREAM_GROUP: windows per group of the whole-stream path (0: by the number of streams; tuning / tests)
     int stream_windows = -1;              // FLATE_HIP_STREAM_WINDOWS: -1 unset (by estimate), 0 never, 1 whenever possible (kernels_parse.h, k_lz_parse<true>)
     bool simple_ck_inline = false;        // FLATE_HIP_SIMPLE_CK_INLINE: the simple modes' checksum on the compute stream (round 4's way)
+    bool one_stream = false;              // FLATE_HIP_ONE_COMPUTE_STREAM: the pinned path's sub-batches one after the other on the caller's stream (round 5's way; tuning)
     int rect = -1;                        // FLATE_HIP_RECT: 1 = half of every slot goes home by the DMA engine's rectangle copy (off by default: see there)
     int64_t inflate_par = -1;             // FLATE_HIP_INFLATE_PAR: -1 unset, 0 never, else the minimum stream size
     int64_t inflate_ring = -1;            // FLATE_HIP_INFLATE_RING: -1 unset
@@ -138,6 +139,8 @@ struct flate_hip_ctx {
     // k_offsets waits for it)
     hipStream_t s_ck = nullptr;
     hipEvent_t ck_ev0 = nullptr, ck_ev1 = nullptr;
+    hipStream_t s_c2 = nullptr;  // pinned path, round 6: every other sub-batch's kernels run here, beside the caller's stream (compress_impl)
+    hipEvent_t c2_ev0 = nullptr, c2_ev1 = nullptr;
     hipStream_t s_ms = nullptr;  // the output slots are cleared beside the tokenizer / the histograms (round 5)
     hipEvent_t ms_ev0 = nullptr, ms_ev1 = nullptr;
     bool ms_pending = false;
@@ -276,6 +279,7 @@ void read_knobs(fl_knobs& k, uint64_t span_default) {
     k.no_pin_mirror = getenv("FLATE_HIP_NO_PIN_MIRROR") != nullptr;
     k.no_ramp = getenv("FLATE_HIP_NO_RAMP") != nullptr;
     if ((e = getenv("FLATE_HIP_RECT"))) k.rect = atoi(e) != 0;
+    k.one_stream = getenv("FLATE_HIP_ONE_COMPUTE_STREAM") != nullptr;
     k.simple_ck_inline = getenv("FLATE_HIP_SIMPLE_CK_INLINE") != nullptr;
     if ((e = getenv("FLATE_HIP_SPAN_TWO_RUNS"))) k.span_two_runs = atoi(e) != 0;
     if ((e = getenv("FLATE_HIP_MEMSET_INLINE"))) k.memset_inline = atoi(e) != 0;
@@ -456,7 +460,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         {
             ProfScope ps(h, K_LZ_CHAIN);
             hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, (const fl_chunk*)h->wchunks.p,
-                               (uint16_t*)h->S.p, (uint32_t*)h->cflag.p);
+                               (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr);
         }
         {
             ProfScope ps(h, K_LZ_PARSE);
@@ -770,8 +774,8 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
     if (container != 0 && mode < 4 && !h->knobs.simple_ck_inline && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
     if (mode >= 4) {
         if ((rc = ensure_lz_workspace(h, nc, prm.chain))) return rc;
-        HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // the parse kernels OR / store the anchors in
         if (prm.chain >= FL_BULK_MIN_CHAIN) {
+            HIP_OK(h, hipMemsetAsync(h->marks.p, 0, (size_t)nc * FL_CHUNK_STRIDE / 8, st));  // k_lz_walk stores the anchors in (k_lz_chain clears its chunk's itself)
             // levels 8 and 9 (chains of 1024 / 4096 candidates): the reference's chain and two sparser ones in global
             // memory, the automaton over them (kernels_walk.h): a walk is 1.4 steps per byte instead of 14
             {
@@ -798,7 +802,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             {
                 ProfScope ps(h, K_LZ_CHAIN);
                 hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
-                                   (uint32_t*)h->cflag.p);
+                                   (uint32_t*)h->cflag.p, (uint32_t*)h->marks.p);
             }
             if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
             {
@@ -1317,6 +1321,9 @@ int flate_hip_destroy(flate_hip_handle h) {
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t e : h->free_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->xfer_events) (void)hipEventDestroy(e);
+    if (h->c2_ev0) (void)hipEventDestroy(h->c2_ev0);
+    if (h->c2_ev1) (void)hipEventDestroy(h->c2_ev1);
+    if (h->s_c2) (void)hipStreamDestroy(h->s_c2);
     if (h->ms_ev0) (void)hipEventDestroy(h->ms_ev0);
     if (h->ms_ev1) (void)hipEventDestroy(h->ms_ev1);
     if (h->s_ms) (void)hipStreamDestroy(h->s_ms);
@@ -1660,11 +1667,64 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         ~PassGuard() {
             if (on) {
                 if (h->s_in) (void)hipStreamSynchronize(h->s_in);
+                if (h->s_c2) (void)hipStreamSynchronize(h->s_c2);
                 (void)hipStreamSynchronize(h->stream);
             }
             h->ck_pending = false;  // (an error between the checksum launch and the back end must not leave a stale wait)
         }
     } pass_guard{h, pinned_passes};
+    // Round 6: TWO compute streams.  A sub-batch's six kernels each end in a tail that fills the chip less and less (1024 chunks are
+    // four per CU: 2.15 ms a sub-batch where a quarter of the whole batch's 6.6 ms would be 1.65) and the next sub-batch's first
+    // kernel waits behind the last one's tail.  The sub-batches alternate between the caller's stream and a second one -- every
+    // per-pass buffer is a slice of a batch-wide workspace, so two passes never touch the same bytes -- and the kernels of sub-batch
+    // k + 1 start as soon as its input is there and run into the tails of k's: 10.3 -> 10.0 ms per 256 MiB in one process, 11.7 ->
+    // 10.1 in another (bench e2e_host).  Levels 4-7, every input on the chunk path.  What lost (profiles/r06_host_path.txt): the
+    // tokenizers of all sub-batches in a row on one stream with the chains and the back ends on streams of higher priority beside
+    // them, 11.0 ms -- k_lz_parse takes a CU's whole LDS, a single small workgroup on a CU keeps the next tokenizer workgroup off it,
+    // and every kernel ran a quarter to a half longer than alone.
+    bool two = pinned_passes && mode >= 4 && !fs && !h->knobs.one_stream && (size_t)n_chunks > pass_limit;
+    for (uint32_t i = 0; two && i < n_chunks; i++) two = chunks[i].in_len <= FLATE_HIP_MAX_LZ_CHUNK;
+    if (two && !h->s_c2) {
+        hipStream_t s2 = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) {
+            h->s_c2 = s2;
+            h->c2_ev0 = e0;
+            h->c2_ev1 = e1;
+        } else {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (s2) (void)hipStreamDestroy(s2);
+            (void)hipGetLastError();
+            two = false;
+        }
+    }
+    if (two) {
+        // the batch-wide workspace (the passes' slices: c0 chunks / the blocks before the pass into every buffer)
+        if ((rc = ensure_lz_workspace(h, n_chunks, prm.chain))) return rc;
+        if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)blk_total))) return rc;
+        if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320 * (size_t)blk_total))) return rc;
+        if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)blk_total))) return rc;
+        // the second stream behind what the caller's stream holds so far (the cleared lengths and statuses)
+        HIP_OK(h, hipEventRecord(h->c2_ev0, st));
+        HIP_OK(h, hipStreamWaitEvent(h->s_c2, h->c2_ev0, 0));
+        if (h->ms_pending) HIP_OK(h, hipStreamWaitEvent(h->s_c2, h->ms_ev1, 0));  // ... and behind the clearing of the slots
+    }
+    struct WsShift {  // a pass's view of the batch-wide workspace: every buffer from its slice on (undone when the pass is enqueued)
+        std::vector<std::pair<DevBuf*, size_t>> undo;
+        void add(DevBuf& b, size_t bytes) {
+            b.p = (uint8_t*)b.p + bytes;
+            b.cap -= bytes;
+            undo.emplace_back(&b, bytes);
+        }
+        ~WsShift() {
+            for (auto& u : undo) {
+                u.first->p = (uint8_t*)u.first->p - u.second;
+                u.first->cap += u.second;
+            }
+        }
+    };
     std::vector<uint32_t> pass_c0;  // first chunk of every pass (mirror_out)
     const bool landing = pin_out && (bool)h->mirror_out;
     if (landing && h->pin_len_cap < sizeof(uint64_t) * (size_t)n_chunks) {
@@ -1800,7 +1860,9 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         }
         // the host vectors must outlive the async copies
         if (!(pin_in || pin_out) || stream || planning) HIP_OK(h, hipStreamSynchronize(st));
-        if (ev_in) HIP_OK(h, hipStreamWaitEvent(st, ev_in, 0));
+        const bool alt = two && (pass_index & 1u) != 0;  // every other sub-batch on the second compute stream
+        hipStream_t stp = alt ? h->s_c2 : st;
+        if (ev_in) HIP_OK(h, hipStreamWaitEvent(stp, ev_in, 0));
         if (planning) {
             // keep this pass's tables in the plan; size the workspace now so that planned calls never allocate
             flate_hip_plan::Pass pp;
@@ -1843,6 +1905,24 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 HIP_OK(h, hipEventRecord(ev_tab, st));
                 HIP_OK(h, hipStreamWaitEvent(h->s_in, ev_tab, 0));
             }
+        } else if (two) {
+            // this pass's slice of every per-pass buffer, its kernels on this pass's stream
+            WsShift ws;
+            const size_t pos0 = (size_t)c0 * FL_CHUNK_STRIDE, b0 = (size_t)(blk_base - nb);
+            ws.add(h->plans, sizeof(fl_block_plan) * b0);
+            ws.add(h->hist, sizeof(uint32_t) * 320 * b0);
+            ws.add(h->cks, sizeof(uint32_t) * 2 * b0);
+            if (prm.chain >= FL_BULK_MIN_CHAIN) ws.add(h->links, pos0 * 4 * sizeof(uint16_t)); else ws.add(h->S, pos0 * sizeof(uint16_t));
+            ws.add(h->desc, pos0 * sizeof(uint32_t));
+            ws.add(h->marks, pos0 / 8);
+            ws.add(h->tokens, pos0 * sizeof(uint32_t));
+            ws.add(h->ntok, sizeof(uint32_t) * c0);
+            ws.add(h->cflag, sizeof(uint32_t) * c0);
+            hipStream_t saved = h->stream;
+            h->stream = stp;
+            rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status);
+            h->stream = saved;
+            if (rc) return rc;
         } else {
             if ((rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
         }
@@ -1850,7 +1930,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
         if (pin_out) {  // this sub-batch's output slots go home while the next sub-batch is computed
             hipEvent_t ev_out;
             if ((rc = xfer_event(h, 4 * pass_index + 1, &ev_out))) return rc;
-            HIP_OK(h, hipEventRecord(ev_out, st));
+            HIP_OK(h, hipEventRecord(ev_out, stp));
             HIP_OK(h, hipStreamWaitEvent(h->s_out, ev_out, 0));
             const uint64_t a = hout[c0], b = hout[c0 + nc];
             bool len_by_kernel = false;
@@ -1899,6 +1979,10 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 HIP_OK(h, hipEventRecord(ev_done, h->s_out));
             }
         }
+    }
+    if (two) {  // the caller's stream behind the second one
+        HIP_OK(h, hipEventRecord(h->c2_ev1, h->s_c2));
+        HIP_OK(h, hipStreamWaitEvent(st, h->c2_ev1, 0));
     }
     if (landing) {
         // everything is enqueued: take the passes' output out of the mirror as they land

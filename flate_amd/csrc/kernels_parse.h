@@ -71,12 +71,18 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ prev_all,
-                                                                   uint32_t* __restrict__ cflag) {
+                                                                   uint32_t* __restrict__ cflag,
+                                                                   uint32_t* __restrict__ marks_all) {
     __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
     __shared__ uint32_t stg_all[FL_CHAIN_WAVES][FL_CHAIN_STG_DW];
     const uint32_t c = blockIdx.x;
     const fl_chunk ck = chunks[c];
     if (ck.skip) return;
+    if (marks_all) {
+        // the chunk's anchor bitmap (k_lz_parse ORs into it): cleared here, not by a memset between the passes of the host path
+        uint4* mk = (uint4*)(marks_all + (uint64_t)c * (FL_CHUNK_STRIDE / 32u));
+        for (uint32_t i = threadIdx.x; i < FL_CHUNK_STRIDE / 128u; i += 64 * FL_CHAIN_WAVES) mk[i] = make_uint4(0, 0, 0, 0);
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* sb = stg_all[wave];
     const uint32_t N = ck.in_len;
