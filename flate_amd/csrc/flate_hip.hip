@@ -1682,7 +1682,13 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
     // tokenizers of all sub-batches in a row on one stream with the chains and the back ends on streams of higher priority beside
     // them, 11.0 ms -- k_lz_parse takes a CU's whole LDS, a single small workgroup on a CU keeps the next tokenizer workgroup off it,
     // and every kernel ran a quarter to a half longer than alone.
-    bool two = pinned_passes && mode >= 4 && !fs && !h->knobs.one_stream && (size_t)n_chunks > pass_limit;
+    // (planned device batches of more than one pass take the same way: flate_hip_compress_planned)
+    const bool planned_run = pl && pl->ready;
+    if (planned_run) {
+        blk_total = 0;
+        for (const flate_hip_plan::Pass& pp : pl->passes) blk_total += pp.nb;
+    }
+    bool two = ((pinned_passes && (size_t)n_chunks > pass_limit) || (planned_run && pl->passes.size() > 1)) && mode >= 4 && !fs && !h->knobs.one_stream;
     for (uint32_t i = 0; two && i < n_chunks; i++) two = chunks[i].in_len <= FLATE_HIP_MAX_LZ_CHUNK;
     if (two && !h->s_c2) {
         hipStream_t s2 = nullptr;
@@ -1724,6 +1730,26 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 u.first->cap += u.second;
             }
         }
+    };
+    // a pass over its slice of every per-pass buffer (c0 chunks / b0 blocks into the batch-wide workspace), its kernels on `sq`
+    auto enqueue_sliced = [&](hipStream_t sq, uint32_t nc_, uint32_t nb_, uint32_t c0_, size_t b0, const fl_chunk* dch_, const uint32_t* dbc_,
+                              const fl_sblock* dsb_) -> int {
+        WsShift ws;
+        const size_t pos0 = (size_t)c0_ * FL_CHUNK_STRIDE;
+        ws.add(h->plans, sizeof(fl_block_plan) * b0);
+        ws.add(h->hist, sizeof(uint32_t) * 320 * b0);
+        ws.add(h->cks, sizeof(uint32_t) * 2 * b0);
+        if (prm.chain >= FL_BULK_MIN_CHAIN) ws.add(h->links, pos0 * 4 * sizeof(uint16_t)); else ws.add(h->S, pos0 * sizeof(uint16_t));
+        ws.add(h->desc, pos0 * sizeof(uint32_t));
+        ws.add(h->marks, pos0 / 8);
+        ws.add(h->tokens, pos0 * sizeof(uint32_t));
+        ws.add(h->ntok, sizeof(uint32_t) * c0_);
+        ws.add(h->cflag, sizeof(uint32_t) * c0_);
+        hipStream_t saved = h->stream;
+        h->stream = sq;
+        const int r = enqueue_pass(h, prm, nc_, nb_, c0_, dch_, dbc_, dsb_, d_in, d_out, d_outlen, d_status);
+        h->stream = saved;
+        return r;
     };
     std::vector<uint32_t> pass_c0;  // first chunk of every pass (mirror_out)
     const bool landing = pin_out && (bool)h->mirror_out;
@@ -1778,9 +1804,14 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
             if ((rc = ensure(h, h->plans, sizeof(fl_block_plan) * (size_t)nb))) return rc;
             if ((rc = ensure(h, h->hist, sizeof(uint32_t) * 320 * (size_t)nb))) return rc;
             if ((rc = ensure(h, h->cks, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
-            if ((rc = enqueue_pass(h, prm, nc, nb, c0, (const fl_chunk*)pp.chunks, (const uint32_t*)pp.blk_chunk, nullptr,
-                                   d_in, d_out, d_outlen, d_status)))
+            if (two) {
+                hipStream_t stq = (pass_index & 1u) ? h->s_c2 : st;
+                if ((rc = enqueue_sliced(stq, nc, nb, c0, (size_t)blk_base, (const fl_chunk*)pp.chunks, (const uint32_t*)pp.blk_chunk, nullptr))) return rc;
+                blk_base += nb;
+            } else if ((rc = enqueue_pass(h, prm, nc, nb, c0, (const fl_chunk*)pp.chunks, (const uint32_t*)pp.blk_chunk, nullptr,
+                                          d_in, d_out, d_outlen, d_status))) {
                 return rc;
+            }
             continue;
         }
         // block table of this pass (kept until the end of the call: on the pinned path the passes are enqueued without a
@@ -1906,23 +1937,7 @@ int compress_impl(flate_hip_handle h, const uint8_t* in, const uint64_t* in_off,
                 HIP_OK(h, hipStreamWaitEvent(h->s_in, ev_tab, 0));
             }
         } else if (two) {
-            // this pass's slice of every per-pass buffer, its kernels on this pass's stream
-            WsShift ws;
-            const size_t pos0 = (size_t)c0 * FL_CHUNK_STRIDE, b0 = (size_t)(blk_base - nb);
-            ws.add(h->plans, sizeof(fl_block_plan) * b0);
-            ws.add(h->hist, sizeof(uint32_t) * 320 * b0);
-            ws.add(h->cks, sizeof(uint32_t) * 2 * b0);
-            if (prm.chain >= FL_BULK_MIN_CHAIN) ws.add(h->links, pos0 * 4 * sizeof(uint16_t)); else ws.add(h->S, pos0 * sizeof(uint16_t));
-            ws.add(h->desc, pos0 * sizeof(uint32_t));
-            ws.add(h->marks, pos0 / 8);
-            ws.add(h->tokens, pos0 * sizeof(uint32_t));
-            ws.add(h->ntok, sizeof(uint32_t) * c0);
-            ws.add(h->cflag, sizeof(uint32_t) * c0);
-            hipStream_t saved = h->stream;
-            h->stream = stp;
-            rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status);
-            h->stream = saved;
-            if (rc) return rc;
+            if ((rc = enqueue_sliced(stp, nc, nb, c0, (size_t)(blk_base - nb), dch, dbc, dsb))) return rc;
         } else {
             if ((rc = enqueue_pass(h, prm, nc, nb, c0, dch, dbc, dsb, d_in, d_out, d_outlen, d_status))) return rc;
         }

@@ -558,6 +558,61 @@ def test_planned_batches_only_enqueue():
     eng.close()
 
 
+@pytest.mark.parametrize("mode,container", [(6, 1), (9, 0), (4, 2)])
+def test_planned_batches_of_several_passes_alternate_between_two_streams(mode, container, monkeypatch):
+    """Round 6: a batch of more than one pass (here: FLATE_HIP_MAX_PASS_CHUNKS=5) runs its passes alternately on the caller's
+    stream and a second one, each over its slice of a batch-wide workspace -- planned device batches and pinned host batches
+    alike.  Same bytes as the oracle, pass after pass, call after call; FLATE_HIP_ONE_COMPUTE_STREAM=1 is round 5's way."""
+    import torch
+    from flate_amd import Engine, synth
+    for one in (None, "1"):
+        monkeypatch.setenv("FLATE_HIP_MAX_PASS_CHUNKS", "5")
+        if one:
+            monkeypatch.setenv("FLATE_HIP_ONE_COMPUTE_STREAM", one)
+        else:
+            monkeypatch.delenv("FLATE_HIP_ONE_COMPUTE_STREAM", raising=False)
+        eng = Engine(0)
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(31)
+        text = synth.text(synth.SEED_TEXT + 5, 23 * 40000).tobytes()
+        chunks = [text[i * 40000:(i + 1) * 40000][:int(rng.integers(1, 40001))] for i in range(23)]
+        chunks[7] = bytes(30000)                       # (a constant chunk, an empty one, noise: every tokenizer path)
+        chunks[11] = b""
+        chunks[13] = rng.integers(0, 256, 33000, dtype=np.uint8).tobytes()
+        blob = b"".join(chunks)
+        off = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        np.cumsum([len(c) for c in chunks], out=off[1:])
+        caps = np.array([(eng.compress_bound(len(c), container, mode) + 7) & ~7 for c in chunks], dtype=np.uint64)
+        out_off = np.zeros(len(chunks) + 1, dtype=np.uint64)
+        np.cumsum(caps, out=out_off[1:])
+        d_in = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+        plan = eng.plan_compress(off, out_off, container, mode)
+        want = [O.compress(c, container, mode) for c in chunks]
+        for rep in range(3):
+            d_out = torch.full((int(out_off[-1]) + 8,), 0xA5, dtype=torch.uint8, device=dev)
+            d_len = torch.zeros(len(chunks), dtype=torch.int64, device=dev)
+            d_st = torch.full((len(chunks),), 77, dtype=torch.int32, device=dev)
+            eng.compress_planned(plan, d_in.data_ptr(), d_out.data_ptr(), d_len.data_ptr(), d_st.data_ptr())
+            torch.cuda.synchronize()
+            assert d_st.cpu().tolist() == [0] * len(chunks)
+            out = d_out.cpu().numpy()
+            for i, w in enumerate(want):
+                a, l = int(out_off[i]), int(d_len[i])
+                assert out[a:a + l].tobytes() == w, (one, rep, i)
+        eng.plan_destroy(plan)
+        # ... and host buffers (pageable here: pinned mirrors, sub-batches of 5 chunks)
+        monkeypatch.setenv("FLATE_HIP_HOST_PASS_CHUNKS", "5")
+        bigtext = synth.text(synth.SEED_TEXT + 9, 65535 * 160).tobytes()
+        big = [bigtext[i * 65535:(i + 1) * 65535] for i in range(160)]
+        outs, st = eng.compress_many(big, container, mode)
+        assert st == [0] * len(big)
+        for i in (0, 4, 5, 77, 159):
+            assert outs[i] == O.compress(big[i], container, mode), (one, i)
+        back, st2, _ = eng.decompress_many(outs, container, caps=[65536] * len(big))
+        assert st2 == [0] * len(big) and back == big
+        eng.close()
+
+
 @pytest.mark.parametrize("rect", [None, "1"])
 def test_pinned_output_slots_of_one_size_rectangle_copy_and_the_rest(rect, monkeypatch):
     """Pinned (and pageable: pinned mirrors) output with slots of one size: the produced bytes of every slot come home by the
