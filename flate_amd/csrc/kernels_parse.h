@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 #ifndef FL_CHAIN_TB
 #define FL_CHAIN_TB 1  // blocks per wave and turn
 #endif
-__global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ prev_all,
                                                                    uint32_t* __restrict__ cflag,
@@ -149,8 +149,12 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
     for (uint32_t u = 0; u < FL_CHAIN_TB; u++) load_block(FL_CHAIN_TB * wave + u, ga0[u], ga1[u]);
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += FL_CHAIN_TB * FL_CHAIN_WAVES) {  // (uniform trip count: every wave meets every barrier)
         const uint32_t bw = b0 + FL_CHAIN_TB * wave;  // this wave's first block of the turn
-        uint32_t hw[16 * FL_CHAIN_TB];   // word of the table, or the lane's dummy word for a position past the end
-        uint32_t odd[FL_CHAIN_TB], val[FL_CHAIN_TB];  // bit s: the hash of step s is odd (its head is the upper half of the word); the position exists
+        // Round 6: address, mask and value of every exchange are made HERE, while other waves have their turns -- a wave alone
+        // on its SIMD issues an instruction every eight cycles or so, and six ALU instructions per exchange inside the turn were
+        // most of a turn's 1.6 k cycles (profiles/r06_parse_experiments.txt item 6); the turn itself is sixteen DS instructions.
+        fl_lds_u32* am[16 * FL_CHAIN_TB];  // word of the table, or the lane's dummy word for a position past the end
+        uint32_t mk[16 * FL_CHAIN_TB];     // which half of the word: 0xffff / 0xffff0000 (0: no position)
+        uint32_t vl[16 * FL_CHAIN_TB];     // the position, in that half
 #pragma unroll
         for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
             const uint32_t b = bw + u;
@@ -158,8 +162,6 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
             if (lane < 2) ((uint4*)sb)[64 + lane] = ga1[u];
             load_block(b + FL_CHAIN_TB * FL_CHAIN_WAVES, ga0[u], ga1[u]);  // (nothing beyond the chunk: load_block clamps)
             fl_lds_order();
-            odd[u] = 0;
-            val[u] = 0;
 #pragma unroll
             for (uint32_t s = 0; s < 16; s++) {
                 const uint32_t p = (b << 10) + (s << 6) + lane;
@@ -167,9 +169,10 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
                 const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
                 const uint32_t h = fl_hash_le(v);
                 const bool valid = p < Mpos;
-                odd[u] |= (h & 1u) << s;
-                val[u] |= (valid ? 1u : 0u) << s;
-                hw[16 * u + s] = valid ? (h >> 1) : 16384u + lane;
+                const uint32_t hs = (h & 1u) << 4;
+                am[16 * u + s] = (fl_lds_u32*)&head32[valid ? (h >> 1) : 16384u + lane];
+                mk[16 * u + s] = valid ? (0xffffu << hs) : 0u;
+                vl[16 * u + s] = valid ? (p << hs) : 0u;
             }
             fl_lds_order();  // (the staging buffer is written again for the next block)
         }
@@ -179,15 +182,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
             if (t == wave) {
                 // all exchanges are issued before the first result is looked at (no branch around the instruction)
 #pragma unroll
-                for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
-#pragma unroll
-                    for (uint32_t s = 0; s < 16; s++) {
-                        const uint32_t p = ((bw + u) << 10) + (s << 6) + lane;
-                        const uint32_t hs = ((odd[u] >> s) & 1u) << 4;
-                        const bool valid = (val[u] >> s) & 1u;
-                        old[16 * u + s] = fl_lds_mskor_rtn(&head32[hw[16 * u + s]], valid ? (0xffffu << hs) : 0u, valid ? (p << hs) : 0u);
-                    }
-                }
+                for (uint32_t i = 0; i < 16 * FL_CHAIN_TB; i++)
+                    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(old[i]) : "v"(am[i]), "v"(mk[i]), "v"(vl[i]) : "memory");
                 // the results exist from here on (listed as operands so that no use of them is scheduled above the wait)
 #pragma unroll
                 for (uint32_t u = 0; u < FL_CHAIN_TB; u++) {
@@ -208,8 +204,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES) void k_lz_chain(const uint8_t*
 #pragma unroll
             for (uint32_t s = 0; s < 16; s++) {
                 const uint32_t p = ((bw + u) << 10) + (s << 6) + lane;
-                if ((val[u] >> s) & 1u) {
-                    const uint32_t o = ((odd[u] >> s) & 1u) ? (old[16 * u + s] >> 16) : (old[16 * u + s] & 0xffffu);
+                if (mk[16 * u + s]) {
+                    const uint32_t o = (mk[16 * u + s] >> 16) ? (old[16 * u + s] >> 16) : (old[16 * u + s] & 0xffffu);
                     overtaken = overtaken || o > p;
                     pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
                 }
