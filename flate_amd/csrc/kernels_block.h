@@ -864,20 +864,16 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode_wave(const uint8_t
     const uint32_t* toks = TOKENS ? tokens + ck.pos_off + plan->tok_start : nullptr;
     const uint8_t* hdr = plan->hdr;
 
-    const uint32_t i0 = 0, i1 = n_items;  // the whole block
+    (void)n_items;
     uint64_t cur = bit_off;
 
-    // pass 2: pack
+    // pack 64 items (one a lane, it.n = 0: none) behind `cur`: prefix sum of the lengths, ds_or into the staging window, whole
+    // dwords out; the block's first dword is shared with the block before it (an atomic OR into the cleared output)
     const uint64_t first_dw = cur >> 5;
     uint32_t* sw = stg[wave];
-    for (uint32_t ib = i0; ib < i1; ib += 64) {
-        const uint32_t i = ib + lane;
-        fl_item it;
-        it.v = 0;
-        it.n = 0;
-        if (i < i1) it = fl_block_item<TOKENS>(i, n_hdr, hdr_nbits, n_sym, hdr, bytes, toks, lit_lds, dist_lds);
+    auto pack = [&](const fl_item& it) {
         const uint32_t incl = fl_wave_incl_scan(it.n, lane);
-        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint64_t base_dw = cur >> 5;
         if (it.n) {
             const uint32_t rel = (uint32_t)(cur - (base_dw << 5)) + (incl - it.n);
@@ -890,23 +886,95 @@ __global__ __launch_bounds__(64 * FL_ENC_WAVES) void k_encode_wave(const uint8_t
         }
         fl_lds_order();
         const uint64_t end = cur + total;
-        const uint32_t nd = (uint32_t)((end >> 5) - base_dw);  // complete dwords
-        for (uint32_t k = lane; k < nd; k += 64) {
-            const uint32_t v = sw[k];
-            if (base_dw + k == first_dw) {
-                if (v) atomicOr(&out32[base_dw + k], v);
-            } else {
-                out32[base_dw + k] = v;
+        const uint32_t nd = (uint32_t)((end >> 5) - base_dw);  // complete dwords (at most 120: two rounds of the lanes)
+        {
+            const uint32_t v0 = lane < nd ? sw[lane] : 0u, v1 = lane + 64u < nd ? sw[lane + 64u] : 0u;
+            if (lane < nd) {
+                if (base_dw + lane == first_dw) {
+                    if (v0) atomicOr(&out32[base_dw + lane], v0);
+                } else {
+                    out32[base_dw + lane] = v0;
+                }
             }
+            if (lane + 64u < nd) out32[base_dw + lane + 64u] = v1;  // (never the block's first dword)
         }
         const uint32_t carry = sw[nd];
         fl_lds_order();
         // clear the window, keep the partial dword as the new first one
-        for (uint32_t k = lane; k <= nd + 2 && k < FL_STG_DW; k += 64) sw[k] = 0;
-        fl_lds_order();
-        if (lane == 0) sw[0] = carry;
+        if (lane <= nd + 2) sw[lane] = lane == 0 ? carry : 0u;
+        if (lane + 64u <= nd + 2 && lane + 64u < FL_STG_DW) sw[lane + 64u] = 0u;
         fl_lds_order();
         cur = end;
+    };
+    if (!TOKENS) {
+        // (huffman-only blocks of a batch this large: the generic items, 64 at a time)
+        for (uint32_t ib = 0; ib < n_items; ib += 64) {
+            fl_item it;
+            it.v = 0;
+            it.n = 0;
+            if (ib + lane < n_items) it = fl_block_item<TOKENS>(ib + lane, n_hdr, hdr_nbits, n_sym, hdr, bytes, toks, lit_lds, dist_lds);
+            pack(it);
+        }
+    } else {
+        // Round 6: three loops instead of one over "items" -- the header's bytes, the tokens, the end-of-block code -- so that the
+        // tokens' loop carries no branch for the other two, and a group's tokens are requested while the group before is packed
+        // (the load sat in the loop with its own wait: 1.08 -> see profiles/r06_config2_kernel_stats.csv).
+        for (uint32_t ib = 0; ib < n_hdr; ib += 64) {
+            fl_item it;
+            it.v = 0;
+            it.n = 0;
+            const uint32_t i = ib + lane;
+            if (i < n_hdr) {
+                const uint32_t rem = hdr_nbits - 8 * i;
+                it.n = rem < 8 ? rem : 8;
+                it.v = hdr[i] & ((1u << it.n) - 1);
+            }
+            pack(it);
+        }
+        const uint32_t eob = lit_lds[FL_EOB];
+        uint32_t t_next = lane < n_sym ? toks[lane] : 0u;
+        for (uint32_t k0 = 0; k0 < n_sym; k0 += 64) {
+            const uint32_t t = t_next;
+            t_next = k0 + 64 + lane < n_sym ? toks[k0 + 64 + lane] : 0u;
+            fl_item it;
+            it.v = 0;
+            it.n = 0;
+            const uint32_t k = k0 + lane;
+            if (k < n_sym) {
+                if (!FL_TOK_IS_MATCH(t)) {
+                    const uint32_t e = lit_lds[FL_TOK_LENLIT(t)];
+                    it.v = e & 0xffff;
+                    it.n = e >> 16;
+                } else {
+                    const uint32_t ll = FL_TOK_LENLIT(t);
+                    const uint32_t li = fl_len_index(ll);
+                    const uint32_t le = lit_lds[257 + li];
+                    uint64_t v = le & 0xffff;
+                    uint32_t n = le >> 16;
+                    v |= (uint64_t)(ll - fl_len_base_scaled(li)) << n;
+                    n += fl_len_extra_bits(li);
+                    const uint32_t d = FL_TOK_DIST0(t);
+                    const uint32_t dc = fl_dist_code(d);
+                    const uint32_t de = dist_lds[dc];
+                    v |= (uint64_t)(de & 0xffff) << n;
+                    n += de >> 16;
+                    v |= (uint64_t)(d - fl_dist_base_scaled(dc)) << n;
+                    n += fl_dist_extra_bits(dc);
+                    it.v = v;
+                    it.n = n;
+                }
+            } else if (k == n_sym) {  // the end-of-block code rides in the last group when a lane is free
+                it.v = eob & 0xffff;
+                it.n = eob >> 16;
+            }
+            pack(it);
+        }
+        if ((n_sym & 63u) == 0) {  // every lane of the last group held a token (or there was none): a group of its own
+            fl_item it;
+            it.v = lane == 0 ? (eob & 0xffff) : 0u;
+            it.n = lane == 0 ? (eob >> 16) : 0u;
+            pack(it);
+        }
     }
     if ((cur & 31) && lane == 0) {
         const uint32_t v = sw[0];

@@ -1592,8 +1592,19 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
         // the part's bytes (+ lookahead for the literals of its last anchors), zero padded
         {
             const uint32_t nb = min(N - h0, FL_TOK_PART + FL_TOK_LOOK);
-            for (uint32_t i = tid; i < FL_TOK_WIN_DW; i += FL_EMITZ_THREADS)
-                winp[i] = 4 * i < nb ? fl_load_u32_clamped(src + h0, 4 * i, nb) : 0u;
+            // (all of a thread's loads first, then the stores: one round of memory latency, not three)
+            constexpr uint32_t WR = (FL_TOK_WIN_DW + FL_EMITZ_THREADS - 1) / FL_EMITZ_THREADS;
+            uint32_t wv[WR];
+#pragma unroll
+            for (uint32_t u = 0; u < WR; u++) {
+                const uint32_t i = u * FL_EMITZ_THREADS + tid;
+                wv[u] = 4 * i < nb ? fl_load_u32_clamped(src + h0, 4 * i, nb) : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < WR; u++) {
+                const uint32_t i = u * FL_EMITZ_THREADS + tid;
+                if (i < FL_TOK_WIN_DW) winp[i] = wv[u];
+            }
         }
         uint32_t cnt = 0;
 #pragma unroll
