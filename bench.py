@@ -455,7 +455,7 @@ def measured_traffic(args, n_in, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, two separate
     rocprofv3 --pmc runs of this very command; profiles/r0N_hbm_traffic_1gib.json), when the workload matches;
     PMC counters cannot be read from inside an un-profiled run, so otherwise null."""
-    for name in ("r05_hbm_traffic_1gib.json", "r04_hbm_traffic_1gib.json", "r03_hbm_traffic_1gib.json"):
+    for name in ("r06_hbm_traffic_1gib.json", "r05_hbm_traffic_1gib.json", "r04_hbm_traffic_1gib.json", "r03_hbm_traffic_1gib.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
