@@ -1577,8 +1577,10 @@ __global__ __launch_bounds__(FL_EMITZ_THREADS, 8) void k_lz_emit(const uint8_t* 
             const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r);
             const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)tw, 2 * r + 1);
             const uint64_t m64 = (uint64_t)wlo | ((uint64_t)whi << 32);  // (no bit is set beyond the end of the input)
-            const uint64_t below = lane ? (m64 & (~0ull >> (64 - lane))) : 0ull;
-            if ((m64 >> lane) & 1ull) alist[wave][na + (uint32_t)__popcll(below)] = (uint16_t)(r * 64 + lane);
+            // (the anchors below this lane: two v_mbcnt; the lane's own bit: the mask itself as the predicate -- the kernel is bound
+            // by instruction issue, the shifts and masks of a 64-bit `below` were a third of this loop)
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+            if (__builtin_amdgcn_inverse_ballot_w64(m64)) alist[wave][na + below] = (uint16_t)(r * 64 + lane);
             na += (uint32_t)__popcll(m64);
         }
         fl_lds_order();
