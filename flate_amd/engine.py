@@ -48,7 +48,7 @@ class Engine:
     # ---- configuration ----
     _KNOBS = ("FLATE_HIP_MAX_PASS_CHUNKS", "FLATE_HIP_HOST_PASS_CHUNKS", "FLATE_HIP_MAX_STREAM_PASS_MIB",
               "FLATE_HIP_INFLATE_SPANS", "FLATE_HIP_SPAN_DEBUG", "FLATE_HIP_SPAN_TWIN", "FLATE_HIP_NO_PIN_MIRROR",
-              "FLATE_HIP_NO_RAMP", "FLATE_HIP_INFLATE_PAR", "FLATE_HIP_INFLATE_RING", "FLATE_HIP_RECT", "FLATE_HIP_STREAM_WINDOWS", "FLATE_HIP_SIMPLE_CK_INLINE", "FLATE_HIP_STREAM_GROUP", "FLATE_HIP_SPAN_TWO_RUNS", "FLATE_HIP_MEMSET_INLINE")
+              "FLATE_HIP_NO_RAMP", "FLATE_HIP_INFLATE_PAR", "FLATE_HIP_INFLATE_RING", "FLATE_HIP_RECT", "FLATE_HIP_STREAM_WINDOWS", "FLATE_HIP_SIMPLE_CK_INLINE", "FLATE_HIP_STREAM_GROUP", "FLATE_HIP_SPAN_TWO_RUNS", "FLATE_HIP_MEMSET_INLINE", "FLATE_HIP_ONE_COMPUTE_STREAM")
 
     def _sync_env(self):
         """The library reads its FLATE_HIP_* tuning variables once, when the handle is made.  Tests and probes change them
