@@ -164,6 +164,41 @@ static void sched_dyn_blocks(int n, res_t* r) {
     r->wg_max += mx;
 }
 
+// helpers (round 6, the item that is left): a lane that is done takes over the second half of what the lane with the most left
+// still has to parse; `levels` = how often one segment's rest may be split (1: one helper a segment); OV trips for the helper's
+// own synchronisation and the hand-over
+static void sched_help(int n, int levels, int OV, int T, res_t* r) {
+    double sum = 0, mx = 0;
+    int nw = 0;
+    for (int w = 0; w < n; w += 64, nw++) {
+        int rem[64], help[64], busy[64];
+        int cnt = 0;
+        for (int k = w; k < n && k < w + 64; k++, cnt++) { rem[cnt] = (int)(spec[k] + fixc[k]); help[cnt] = 0; busy[cnt] = 0; }
+        int t = 0;
+        for (;; t++) {
+            int alive = 0;
+            for (int l = 0; l < cnt; l++) alive |= rem[l] > 0 || busy[l] > 0;
+            if (!alive) break;
+            for (int b = 0; b < cnt; b++) {
+                if (rem[b] > 0 || busy[b] > 0) continue;
+                int best = -1;
+                for (int a = 0; a < cnt; a++) if (rem[a] >= T && help[a] < levels && (best < 0 || rem[a] > rem[best])) best = a;
+                if (best < 0) break;
+                const int half = rem[best] / 2;
+                rem[best] = rem[best] - half + OV;  // (the owner waits for the helper in the end: the later of the two)
+                busy[b] = half + OV;
+                if (busy[b] > rem[best]) rem[best] = busy[b];
+                help[best]++;
+            }
+            for (int l = 0; l < cnt; l++) { if (rem[l] > 0) rem[l]--; if (busy[l] > 0) busy[l]--; }
+        }
+        sum += t;
+        if (t > mx) mx = t;
+    }
+    r->wave_mean += sum / nw;
+    r->wg_max += mx;
+}
+
 int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     const int level = argc > 2 ? atoi(argv[2]) : 6;
@@ -171,7 +206,7 @@ int main(int argc, char** argv) {
     const level_args_t la = level_args(level);
     good = la.good; lazy = la.lazy; nice = la.nice; chainmax = la.chain;
     static uint16_t head[32768];
-    res_t st48 = {0}, st32 = {0}, st24 = {0}, dw24 = {0}, dw16 = {0}, dw12 = {0}, db24 = {0}, db16 = {0}, db32 = {0}, bst32 = {0}, bdw16 = {0}, bdw8 = {0}, bst16 = {0};
+    res_t h1 = {0}, h2 = {0}, h3 = {0}, hb1 = {0}, hb3 = {0}, st48 = {0}, st32 = {0}, st24 = {0}, dw24 = {0}, dw16 = {0}, dw12 = {0}, db24 = {0}, db16 = {0}, db32 = {0}, bst32 = {0}, bdw16 = {0}, bdw8 = {0}, bst16 = {0};
     int c;
     for (c = 0; c < nchunks; c++) {
         N = (int)fread(buf, 1, 65535, f);
@@ -183,18 +218,21 @@ int main(int argc, char** argv) {
             else prv[p] = 0;
         }
         int n;
-        n = costs(0, 49152, 48); sched_static(n, &st48);
+        n = costs(0, 49152, 48); sched_static(n, &st48); sched_help(n, 1, 3, 8, &h1); sched_help(n, 2, 3, 8, &h2); sched_help(n, 3, 3, 8, &h3);
         n = costs(0, 49152, 32); sched_static(n, &st32); sched_dyn_blocks(n, &db32);
         n = costs(0, 49152, 24); sched_static(n, &st24); sched_dyn_wave(n, 2, &dw24); sched_dyn_blocks(n, &db24);
         n = costs(0, 49152, 16); sched_dyn_wave(n, 3, &dw16); sched_dyn_blocks(n, &db16);
         n = costs(0, 49152, 12); sched_dyn_wave(n, 4, &dw12);
-        n = costs(49152, 65536, 32); sched_static(n, &bst32);
+        n = costs(49152, 65536, 32); sched_static(n, &bst32); sched_help(n, 1, 3, 8, &hb1); sched_help(n, 3, 3, 8, &hb3);
         n = costs(49152, 65536, 16); sched_static(n, &bst16); sched_dyn_wave(n, 2, &bdw16);
         n = costs(49152, 65536, 8); sched_dyn_wave(n, 4, &bdw8);
     }
     printf("level %d, %d chunks; trips of a wave's loop, mean over the chunks (sub-pass A, targets [0, 49152))\n", level, c);
 #define ROW(name, r) printf("  %-58s mean wave %7.1f   slowest wave %7.1f   mean lane %6.1f\n", name, r.wave_mean / c, r.wg_max / c, r.lane_mean / c)
     ROW("static, 48-byte segments, 16 waves (today)", st48);
+    ROW("... + a lane that is done takes half of the longest rest (once a segment, 3 trips of overhead)", h1);
+    ROW("... twice a segment", h2);
+    ROW("... three times a segment", h3);
     ROW("static, 32-byte segments, 24 blocks", st32);
     ROW("static, 24-byte segments, 32 blocks", st24);
     ROW("blocks of 64 x 32 bytes to the waves as they come free", db32);
@@ -205,6 +243,8 @@ int main(int argc, char** argv) {
     ROW("a wave's 3072 bytes as 256 x 12, lanes take them in order", dw12);
     printf("sub-pass B, targets [49152, 65536)\n");
     ROW("static, 32-byte segments, 8 waves (today)", bst32);
+    ROW("... + helpers, once a segment", hb1);
+    ROW("... + helpers, three times a segment", hb3);
     ROW("static, 16-byte segments, 16 waves", bst16);
     ROW("16 waves, a wave's 1024 bytes as 128 x 16, lanes take them", bdw16);
     ROW("16 waves, a wave's 1024 bytes as 256 x 8, lanes take them", bdw8);
