@@ -1,7 +1,9 @@
 cd /root/repo
-( timeout 900 python tools/span_sweep.py 31 150 2>/dev/null | tail -1
-  timeout 600 python tools/span_sweep.py 32 40 big 2>/dev/null | tail -1
-  timeout 600 python tools/span_sweep.py 33 100 many 2>/dev/null | tail -1
-  timeout 1800 python tools/parity_sweep.py 91 8 2>/dev/null | tail -1
-  FLATE_HIP_STREAM_WINDOWS=1 timeout 1800 python tools/parity_sweep.py 92 4 2>/dev/null | tail -1
-  FLATE_HIP_STREAM_WINDOWS=1 FLATE_HIP_STREAM_GROUP=3 timeout 1800 python tools/parity_sweep.py 93 4 2>/dev/null | tail -1 ) | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tee gpurun_out/r05_sweeps3.txt
+mkdir -p gpurun_out/r06
+( timeout 1500 python tools/parity_sweep.py 621 24 2>/dev/null | tail -2
+  timeout 900 python tools/inflate_fuzz.py 622 20 2>/dev/null | tail -2
+  timeout 600 python tools/span_sweep.py 623 150 2>&1 | tail -2
+  timeout 600 python tools/span_sweep.py 624 40 big 2>&1 | tail -1
+  timeout 600 python tools/span_sweep.py 625 60 many 2>&1 | tail -1
+  timeout 600 python tools/runny_sweep.py 626 2>/dev/null | tail -2
+  timeout 900 python tools/big_batch_sweep.py 627 2>/dev/null | tail -2 ) | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tee gpurun_out/r06/final_sweeps2.txt

@@ -52,7 +52,9 @@ def make():
     else:
         mode = int(rng.choice([0, 1, 4, 5, 6, 7, 8, 9]))
         c, st = eng.compress_many([data], container, mode)
-        assert st == [0]
+        assert st[0] in (0, 102), st
+        if st[0] == 102:  # (the reference's own Q1 stream does not inflate to the input: DESIGN.md section 3 -- another one)
+            return make()
         comp = c[0]
     return data, comp, container
 
