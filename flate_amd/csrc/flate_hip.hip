@@ -387,7 +387,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     // Round 5: many streams, none of them with flush points, levels 4-7: the demand-driven tokenizer of the chunk path walks
     // every stream's windows in order, a workgroup per stream (kernels_parse.h, k_lz_parse<true>) -- no sort, no records for
     // every position.  A window costs a workgroup about 0.28 ms, the sort / match pair about 0.061 ms per MiB of all CUs.
-    bool windows = !t.any_flush && prm.chain < FL_BULK_MIN_CHAIN && h->knobs.stream_windows != 0 && nseg;
+    // Round 6: levels 8 and 9 the same way on k_lz_links / k_lz_walk<true, true> (kernels_walk.h).
+    const bool deep_walk = prm.chain >= FL_BULK_MIN_CHAIN;
+    bool windows = !t.any_flush && h->knobs.stream_windows != 0 && nseg;
     std::vector<fl_chunk> wch;
     std::vector<fl_swin> sws;
     bool grouped = false;  // some stream is split into groups of windows: a fix launch follows (kernels_parse.h)
@@ -406,6 +408,8 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         // CU, at least four windows each (the fix launch parses one sub-pass per group again: an eighth of the work at G = 4).
         uint32_t G = ~0u;
         if (nc < h->n_cu) G = (uint32_t)std::max<uint64_t>(4, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
+        // (levels 8-9: two workgroups of k_lz_walk share a CU, and the fix launch parses a whole window per group again: groups of 8 at least)
+        if (deep_walk && nc < 4 * h->n_cu) G = (uint32_t)std::max<uint64_t>(8, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
         if (h->knobs.stream_group) G = h->knobs.stream_group;
         for (uint32_t i = 0; i < nc; i++) {
             const fl_chunk& c = hch[i];
@@ -415,6 +419,8 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                 w.in_off = c.in_off + (uint64_t)FL_SEG * j;
                 w.in_len = (uint32_t)std::min<uint64_t>(65536u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j);
                 w.pad_ = 1u;  // (a window: k_lz_chain builds its chains whatever it holds)
+                // (levels 8-9: + the bytes behind the window that the lazy calls of its last anchor look at, kernels_walk.h)
+                if (deep_walk) w.pad_ |= (uint32_t)std::min<uint64_t>(264u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j - w.in_len) << 8;
                 wch.push_back(w);
             }
             uint32_t prev = ~0u;
@@ -438,8 +444,10 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         (void)gmax;
         // a window costs a workgroup about 0.28 ms; sort / match cost about 0.061 ms per MiB on all CUs (and about a millisecond
         // of kernel latencies whatever the size)
-        const double est_new = (double)((ng + h->n_cu - 1) / h->n_cu) * max_win * 0.28 + (grouped ? 0.5 : 0.0);
-        const double est_old = (double)bytes / 1048576.0 * 0.061 + 1.0;
+        // (levels 8-9: two workgroups of k_lz_walk share a CU, a window costs one about WK_WIN_MS; sort / match cost 0.19 ms per MiB there)
+        const double est_new = deep_walk ? (double)((ng + 2 * h->n_cu - 1) / (2 * h->n_cu)) * max_win * 1.2 + (grouped ? 1.0 : 0.0)
+                                         : (double)((ng + h->n_cu - 1) / h->n_cu) * max_win * 0.28 + (grouped ? 0.5 : 0.0);
+        const double est_old = (double)bytes / 1048576.0 * (deep_walk ? 0.19 : 0.061) + 1.0;
         if (h->knobs.stream_windows < 0 && est_new >= est_old) windows = false;
         if (wch.size() > tile_limit) windows = false;  // (the chain links of all windows at once: 128 KiB each)
     }
@@ -447,7 +455,11 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         const uint32_t nw = (uint32_t)wch.size(), ng = (uint32_t)sws.size();
         if ((rc = ensure(h, h->wchunks, sizeof(fl_chunk) * nw))) return rc;
         if ((rc = ensure(h, h->swins, sizeof(fl_swin) * ng))) return rc;
-        if ((rc = ensure(h, h->S, (size_t)nw * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
+        if (deep_walk) {
+            if ((rc = ensure(h, h->links, (size_t)nw * FL_CHUNK_STRIDE * 4 * sizeof(uint16_t)))) return rc;
+        } else {
+            if ((rc = ensure(h, h->S, (size_t)nw * FL_CHUNK_STRIDE * sizeof(uint16_t)))) return rc;
+        }
         if ((rc = ensure(h, h->cflag, sizeof(uint32_t) * nw))) return rc;
         if ((rc = ensure(h, h->wexit, sizeof(uint32_t) * (2 * (size_t)nw + 2 * (size_t)ng + 4)))) return rc;
         uint32_t* d_wexit = (uint32_t*)h->wexit.p;
@@ -457,17 +469,33 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         HIP_OK(h, hipMemcpyAsync(h->wchunks.p, wch.data(), sizeof(fl_chunk) * nw, hipMemcpyHostToDevice, st));
         HIP_OK(h, hipMemcpyAsync(h->swins.p, sws.data(), sizeof(fl_swin) * ng, hipMemcpyHostToDevice, st));
         HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
-        {
+        const fl_chunk* dwc = (const fl_chunk*)h->wchunks.p;
+        // the tokenizer over the groups of windows: the first launch (fix = 0), or one from the groups' true entries (fix = 1)
+        auto launch_tokenizer = [&](uint32_t fix) {
+            if (deep_walk) {
+                ProfScope ps(h, K_LZ_WALK);
+                wk_stream sp{(const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, fix};
+                hipLaunchKernelGGL((k_lz_walk<true, true>), dim3(ng), dim3(WK_THREADS), 0, st, d_in, dwc, prm, (const uint16_t*)h->links.p,
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p, sp);
+            } else {
+                ProfScope ps(h, K_LZ_PARSE);
+                hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, dwc, prm,
+                                   (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
+                                   (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, fix);
+            }
+        };
+        if (deep_walk) {
+            ProfScope ps(h, K_LZ_LINKS);
+            hipLaunchKernelGGL(k_lz_links<0>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc, (uint16_t*)h->links.p, (uint32_t*)h->cflag.p);
+            hipLaunchKernelGGL(k_lz_links<1>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc, (uint16_t*)h->links.p, (uint32_t*)h->cflag.p);
+            hipLaunchKernelGGL(k_lz_links<2>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc, (uint16_t*)h->links.p, (uint32_t*)h->cflag.p);
+            hipLaunchKernelGGL(k_lz_links<3>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc, (uint16_t*)h->links.p, (uint32_t*)h->cflag.p);
+        } else {
             ProfScope ps(h, K_LZ_CHAIN);
-            hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, (const fl_chunk*)h->wchunks.p,
+            hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc,
                                (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr);
         }
-        {
-            ProfScope ps(h, K_LZ_PARSE);
-            hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
-                               (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
-                               (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, 0u);
-        }
+        launch_tokenizer(0u);
         // the groups that were parsed from a guess: again from where the group before them leaves, until nothing moves any more
         // (one launch in practice: a parse falls in step within a few bytes; the loop is what makes it exact).  NOT on
         // periodic data: in a stream of one repeated byte every anchor is a 258-byte match, a parse from a guessed entry never
@@ -476,12 +504,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         bool gave_up = false;
         for (uint32_t it = 0; grouped; it++) {
             HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
-            {
-                ProfScope ps(h, K_LZ_PARSE);
-                hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, (const fl_chunk*)h->wchunks.p, prm,
-                                   (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
-                                   (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, 1u);
-            }
+            launch_tokenizer(1u);
             uint32_t flag = 0;
             HIP_OK(h, hipMemcpyAsync(&flag, d_dirty, sizeof flag, hipMemcpyDeviceToHost, st));
             HIP_OK(h, hipStreamSynchronize(st));
@@ -792,10 +815,10 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             {
                 ProfScope ps(h, K_LZ_WALK);
                 hipLaunchKernelGGL(k_lz_walk<false>, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
-                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p, wk_stream{});
                 // the chunks k_lz_links<0> found a run of one byte in (workgroups of the other kind return at once)
                 hipLaunchKernelGGL(k_lz_walk<true>, dim3(nc), dim3(WK_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->links.p,
-                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p);
+                                   (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p, wk_stream{});
             }
         } else {
             // levels 4..7: the reference's chain in LDS, the automaton per segment (kernels_parse.h)

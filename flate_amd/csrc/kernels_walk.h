@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
     if (WHICH == 0) {
         // A chunk of ONE repeated byte needs no chains: k_lz_walk writes its anchors directly.
-        if (N >= 64) {
+        if (N >= 64 && !ck.pad_) {  // (pad_ != 0: a WINDOW of a long stream -- k_lz_walk<true, true> enters it anywhere: chains always)
             const uint32_t b0 = src[0] * 0x01010101u;
             bool same = true;
             for (uint32_t g0 = 0; g0 < n_gran; g0 += 64 * FL_CHAIN_WAVES) {
@@ -259,6 +259,9 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
 #ifndef WK_WAVES_PER_SIMD
 #define WK_WAVES_PER_SIMD 8  // two workgroups per CU (64 VGPRs); 4: one (128 VGPRs, nothing spilled)
 #endif
+#ifndef WK_STREAM_WAVES_PER_SIMD
+#define WK_STREAM_WAVES_PER_SIMD 8  // k_lz_walk<true, true>: two workgroups a CU, as the chunks' (one 256 MiB stream of text, level 9: 20.5 ms against 29.6 with one)
+#endif
 #ifndef WK_BURST
 #define WK_BURST 4        // chain steps per trip, at most
 #endif
@@ -278,32 +281,121 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
 #define WK_CNT(var, v)
 #endif
 
+// STREAM (round 6): the whole-stream path of levels 8 and 9 on this tokenizer, as k_lz_parse<true> is for levels 4-7 (see there:
+// the reference's window after slide j is a chunk, `chunks` holds one fl_chunk per WINDOW, a workgroup walks a group of
+// consecutive windows of one stream, the anchor the path leaves a window at is where it enters the next; a second launch
+// (fix = 1) parses the groups that started from a guess again from their true entry until a window is left where it was left
+// before).  A window's fl_chunk says in pad_ >> 8 how many bytes of the stream lie behind its 65536 (at most 264): the lazy calls
+// of the window's last anchor are made AFTER the next slide, with the whole lookahead (deflate.zig:304-321).  Always the DEEP
+// instantiation: a stream's windows are not sorted by kind.
+struct wk_stream {
+    const fl_swin* swins;
+    const fl_chunk* schunks;
+    const uint32_t* zones;
+    uint32_t* gexit;
+    uint32_t* gentry;
+    uint32_t* wexit;
+    uint32_t* dirty;
+    uint32_t fix;
+};
+#define WK_TERM 0xffffu  // pointer jumping: the path has left the chunk / the window's targets
+
 // lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
-template <bool DEEP>
-__global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const uint8_t* __restrict__ in,
+template <bool DEEP, bool STREAM = false>
+__global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_WAVES_PER_SIMD) void k_lz_walk(const uint8_t* __restrict__ in,
                                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                                            const uint16_t* __restrict__ lnk,
                                                                            const uint32_t* __restrict__ cflag,
                                                                            uint32_t* __restrict__ desc_all,
-                                                                           uint32_t* __restrict__ true_all) {
+                                                                           uint32_t* __restrict__ true_all, wk_stream sp) {
     __shared__ uint32_t win32[WK_WIN_DW];
+    __shared__ uint32_t sh_a, sh_b;           // STREAM: the group's entry / a window's exit
     __shared__ uint16_t tX[WK_THREADS];       // exit of a lane's own parse as soon as it is known, complemented (0xffff: not yet)
     __shared__ uint16_t tExg[WK_THREADS];     // exit the path is assumed to take out of a segment
     __shared__ uint16_t tNxt[2][WK_THREADS];  // segment that exit lands in (pointer jumping, double buffered)
     __shared__ uint16_t tEnt[WK_THREADS];     // position at which the path enters a segment
     __shared__ uint16_t tMark[WK_THREADS];    // segment is on the path
-    const uint32_t c = blockIdx.x;
-    const fl_chunk ck = chunks[c];
-    if (ck.skip) return;
     const uint32_t tid = threadIdx.x;
-    const uint32_t N = ck.in_len;
+    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    constexpr uint32_t LITD = STREAM ? 0u : PZ_DESC_LIT;  // descriptor of an anchor that emits one literal (k_st_emit: 0)
+    fl_swin sw;
+    sw.chunk = 0;
+    sw.win0 = blockIdx.x;
+    sw.nwin = 1;
+    sw.wfirst = 0;
+    sw.prev = ~0u;
+    fl_chunk sck = chunks[0];
+    uint32_t carry = 0;  // STREAM: the anchor at which the path enters the window (window-relative)
+    bool guessed = false;
+    if (STREAM) {
+        sw = sp.swins[blockIdx.x];
+        sck = sp.schunks[sw.chunk];
+        if (sck.skip) return;
+        if (sw.prev != ~0u) {
+            if (sp.fix) {
+                // the true entry: where the group before leaves (absolute stream position), read by ONE thread (k_lz_parse<true>)
+                if (tid == 0) {
+                    sh_a = __hip_atomic_load(&sp.gexit[sw.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh_b = sp.gentry[blockIdx.x];
+                }
+                __syncthreads();
+                const uint32_t e = sh_a, was = sh_b;
+                __syncthreads();
+                if (e == was) return;  // parsed from there already
+                if (tid == 0) sp.gentry[blockIdx.x] = e;
+                carry = e - FL_MAX_DIST * sw.wfirst;
+            } else {
+                guessed = true;  // (the first window's first target: set below)
+            }
+        } else if (sp.fix) {
+            return;  // a stream's first group starts at the stream's start
+        }
+    }
+    for (uint32_t wi = 0; wi < sw.nwin; wi++) {
+    const uint32_t ws = sw.wfirst + wi;  // STREAM: the window's number in its stream
+    const uint32_t c = sw.win0 + wi;
+    const fl_chunk ck = chunks[c];
+    if (!STREAM && ck.skip) return;
+    const uint32_t N = ck.in_len;                           // positions below N have links
+    const uint32_t NB = STREAM ? N + (ck.pad_ >> 8) : N;    // bytes of the window that exist
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
     const uint8_t* src = in + ck.in_off;
-    uint32_t* descg = desc_all + ck.pos_off;
-    uint32_t* trueg = true_all + (ck.pos_off >> 5);
-    const uint32_t chain = prm.chain, good = prm.good, lazy = prm.lazy, nice = prm.nice;
+    const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * ws : ck.pos_off;
+    uint32_t* descg = desc_all + pos_off;
+    uint32_t* trueg = true_all + (pos_off >> 5);
     if (N == 0) return;
-    const uint32_t kind = cflag[c];
+    // the window's targets [t_first, t_last); the path enters at `carry`
+    uint32_t t_first = 0, t_last = N;
+    if (STREAM) {
+        const uint32_t* zone = sp.zones + sck.zone_off;
+        if (ws) t_first = zone[ws - 1] - FL_MAX_DIST * ws;
+        if (ws < sck.n_slides) t_last = zone[ws] - FL_MAX_DIST * ws;
+        if (wi) __syncthreads();  // the window before is done with the LDS tables
+        if (guessed && wi == 0) {
+            carry = t_first;
+            if (tid == 0) sp.gentry[blockIdx.x] = t_first + FL_MAX_DIST * ws;
+        }
+        if (t_first >= t_last) {
+            if (tid == 0) sp.wexit[2 * c] = sp.wexit[2 * c + 1] = ~0u;
+            continue;
+        }
+        if (sp.fix) {
+            // the anchors the first launch left in this window's targets go: bit by bit at the ends (the words there are shared
+            // with the windows next to it, which other workgroups may be writing), whole words in between
+            const uint64_t b0 = pos_off + t_first, b1 = pos_off + t_last;  // absolute bits [b0, b1)
+            for (uint64_t w = (b0 >> 5) + tid; w <= ((b1 - 1) >> 5); w += WK_THREADS) {
+                uint32_t keep = 0;
+                if (w == (b0 >> 5) && (b0 & 31)) keep |= (1u << (b0 & 31)) - 1u;
+                if (w == ((b1 - 1) >> 5) && (b1 & 31)) keep |= ~((1u << (b1 & 31)) - 1u);
+                if (keep) atomicAnd(&true_all[w], keep); else true_all[w] = 0u;
+            }
+            __threadfence();
+        }
+    }
+    // STREAM: a position at or beyond the window's last target is visited AFTER the next slide: the reference has dropped every
+    // candidate at or below the next window's start by then (Lookup.zig:43-51) -- relative to this window: at or below 32768
+    const uint32_t zt = (STREAM && ws < sck.n_slides) ? t_last : ~0u;
+    const uint32_t kind = STREAM ? 2u : cflag[c];
     if (kind != 1u && (kind == 2u) != DEEP) return;  // (the other instantiation's chunk)
     if (kind == 1u && DEEP) return;
     if (kind == 1u) {
@@ -342,7 +434,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
     {
         const uint32_t ash = (uint32_t)((uintptr_t)src & 3);
         const uint32_t* a32 = (const uint32_t*)(src - ash);
-        const uint32_t ndw = (N + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
+        const uint32_t ndw = (NB + ash + 3) >> 2;  // aligned dwords that hold at least one byte of the input
         constexpr uint32_t WB = (WK_WIN_DW + WK_THREADS - 1) / WK_THREADS;
         uint32_t lo[WB], hi[WB];
 #pragma unroll
@@ -355,14 +447,19 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         for (uint32_t u = 0; u < WB; u++) {
             const uint32_t i = u * WK_THREADS + tid;
             uint32_t v = __builtin_amdgcn_alignbyte(hi[u], lo[u], ash);
-            if (4 * i + 4 > N) v = 4 * i < N ? (v & ((1u << (8 * (N - 4 * i))) - 1u)) : 0u;
+            if (4 * i + 4 > NB) v = 4 * i < NB ? (v & ((1u << (8 * (NB - 4 * i))) - 1u)) : 0u;
             if (i < WK_WIN_DW) win32[i] = v;
         }
     }
-    const uint32_t nseg = (N + WK_SEG - 1) >> 6;
+    // the segments [64 m, 64 m + 64) that hold targets from the path's entry on: m0 (parsed from the entry itself) .. m0 + nseg - 1
+    const uint32_t t_end = STREAM ? t_last : N;
+    const uint32_t m0 = STREAM ? carry >> 6 : 0u;
+    const uint32_t nseg = ((t_end + WK_SEG - 1) >> 6) - m0;
     const uint32_t m = tid;  // this lane's segment
+    const bool active = m >= m0 && m - m0 < nseg;
     const uint32_t seg0 = m * WK_SEG;
-    const uint32_t seg_end = min(seg0 + WK_SEG, N);
+    const uint32_t seg_lo = (STREAM && m == m0) ? carry : seg0;
+    const uint32_t seg_end = min(seg0 + WK_SEG, t_end);
     uint64_t A = 0, F = 0;  // anchors of the lane's own parse; of the parse from the entry
     uint32_t X = seg_end;   // exit of the lane's own parse
     uint32_t res_entry = PZ_NONE, res_exit = 0, Z = PZ_NONE;
@@ -374,7 +471,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
     // chain and matches 258 bytes >= nice >= lazy) and goes on at e + 258.  Such segments cost no trips, and a change of the
     // path's phase crosses a whole run of them inside ONE round of the stitch (4 KiB of padding took 16 rounds).
     bool deep = false;
-    if (DEEP && m >= 1 && seg0 + WK_SEG + FL_MAX_MATCH <= N) {
+    if (DEEP && m >= 1 && m > m0 && seg0 + WK_SEG + FL_MAX_MATCH <= N && seg0 + WK_SEG <= t_end) {
         const uint32_t x0 = seg0 - 1u, x1 = seg0 + WK_SEG + FL_MAX_MATCH;
         const uint32_t bp = (win32[x0 >> 2] >> (8u * (x0 & 3u)) & 0xffu) * 0x01010101u;
         deep = true;
@@ -412,9 +509,9 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         uint32_t ex_used = 0;  // ... and this is the exit the round's path assumed for it
         bool moved = false;  // a deep segment got another entry in this round: the path has changed
         if (round == 0) {
-            if (m < nseg) {
+            if (active) {
                 st = ST_SPEC;
-                a = seg0;
+                a = seg_lo;
             }
             if (DEEP && deep) {  // the own parse in closed form; what is left is the wait for the lane before
                 descg[seg0] = DEEP_DESC;
@@ -428,33 +525,33 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
             const uint64_t c_ts0 = __builtin_readcyclecounter();
 #endif
             // the path, assuming every segment not resolved yet leaves through its own exit
-            if (m < nseg) {
+            if (active) {
                 const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
                 ex_used = ex;
                 tExg[m] = (uint16_t)ex;
-                tNxt[0][m] = (uint16_t)(ex >= N ? nseg : (ex >> 6));
-                tMark[m] = m == 0 ? 1 : 0;
-                tEnt[m] = m == 0 ? (uint16_t)0 : (uint16_t)PZ_NONE;
+                tNxt[0][m] = (uint16_t)(ex >= t_end ? WK_TERM : (ex >> 6));
+                tMark[m] = m == m0 ? 1 : 0;
+                tEnt[m] = m == m0 ? (uint16_t)seg_lo : (uint16_t)PZ_NONE;
             }
             __syncthreads();
             uint32_t cur = 0;
             for (uint32_t step = 0; (1u << step) < nseg; step++) {
-                if (m < nseg) {
+                if (active) {
                     const uint32_t n = tNxt[cur][m];
-                    if (n < nseg) {
+                    if (n != WK_TERM) {
                         if (tMark[m]) tMark[n] = 1;
                         tNxt[cur ^ 1][m] = tNxt[cur][n];
                     } else {
-                        tNxt[cur ^ 1][m] = (uint16_t)nseg;
+                        tNxt[cur ^ 1][m] = (uint16_t)WK_TERM;
                     }
                 }
                 __syncthreads();
                 cur ^= 1;
             }
-            marked = m < nseg && tMark[m] != 0;
+            marked = active && tMark[m] != 0;
             if (marked) {
                 const uint32_t ex = tExg[m];
-                if (ex < N) {
+                if (ex < t_end) {
                     tEnt[ex >> 6] = (uint16_t)ex;
                     tNxt[0][ex >> 6] = (uint16_t)m;  // (the segment the path comes from; the jump tables are free now)
                 }
@@ -471,14 +568,16 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                         Z = PZ_NONE;
                         res_entry = y_in;
                         res_exit = y_in + FL_MAX_MATCH;  // (< N: the segment is deep)
-                        tEnt[res_exit >> 6] = (uint16_t)res_exit;
-                        tNxt[0][res_exit >> 6] = (uint16_t)m;
+                        if (res_exit < t_end) {
+                            tEnt[res_exit >> 6] = (uint16_t)res_exit;
+                            tNxt[0][res_exit >> 6] = (uint16_t)m;
+                        }
                         upd = true;
                         moved = true;
                     }
                     if (!__syncthreads_or(upd ? 1 : 0)) break;
                     const uint32_t e2 = tEnt[m];
-                    if (m < nseg && e2 != PZ_NONE && e2 != y_in) {  // (handed on by a deep segment: on the path now)
+                    if (active && e2 != PZ_NONE && e2 != y_in) {  // (handed on by a deep segment: on the path now)
                         y_in = e2;
                         marked = true;
                     }
@@ -491,7 +590,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
             // round, 16 rounds for 4 KiB of padding: everything behind the run was parsed again in every one of them.)
             tMark[m] = need ? 0 : 1;
             __syncthreads();
-            const bool work = need && (m == 0 || tMark[tNxt[0][m]] != 0);
+            const bool work = need && (m == m0 || tMark[tNxt[0][m]] != 0);
             deferred = need && !work;
 #ifdef WK_PROF
             c_tstitch += __builtin_readcyclecounter() - c_ts0;
@@ -531,6 +630,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         };
         auto offset_of = [&](uint32_t len) -> uint32_t {
             if (len < 8u || prun != 0) return 0u;
+            if (STREAM && p + len + 1u > N) return 0u;  // (p + off + 8 <= N: a position whose 8-byte hash was made of the window's own bytes)
             uint32_t pat;
             return allsame8(p + len - 7u, pat) ? 0u : len - 7u;  // (a chain of run positions is the worst there is)
         };
@@ -698,7 +798,7 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                         emit = plen >= lazy;  // deflate.zig:171-173
                     }
                     if (emit) {
-                        uint32_t desc = PZ_DESC_LIT, next = a + 1;
+                        uint32_t desc = LITD, next = a + 1;
                         if (plen) {
                             desc = 0x80000000u | (j << 23) | ((plen - 3u) << 15) | (pdist - 1u);
                             next = a + j + plen;
@@ -716,10 +816,10 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                                 X = a;
                                 __hip_atomic_store(&tX[m], (uint16_t)~a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 amask = 0;
-                                if (m == 0) {  // the first segment's own parse is the true one
-                                    res_entry = 0;
+                                if (m == m0) {  // the first segment's own parse is the true one
+                                    res_entry = seg_lo;
                                     res_exit = a;
-                                    Z = 0;
+                                    Z = seg_lo;
                                     st = ST_DONE;
                                     cs = CS_IDLE;
                                 } else {
@@ -749,10 +849,12 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                     p = sp;
                     best = sl;
                     bdist = 0;
-                    maxlen = min(N - p, (uint32_t)FL_MAX_MATCH);
+                    maxlen = min(NB - p, (uint32_t)FL_MAX_MATCH);
                     lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;
+                    if (STREAM && p >= zt) lo = max(lo, (uint32_t)FL_MAX_DIST + 1u);
                     budget = sl >= good ? (chain >> 2) : chain;
                     K = sl < 5u ? WK_L4 : (sl < 7u ? WK_L6 : WK_L8);
+                    if (STREAM && p + 8u > N) K = WK_L4;  // (the hashes of 6 and 8 bytes of a window's last positions were made of zeros)
                     cnt = K == WK_L4 ? budget : WK_PROBE;
                     last = p;
                     prun = 0;
@@ -1001,7 +1103,8 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
                     if (l >= nice || l >= maxlen) {
                         cs = CS_MOVE;  // good enough / nothing longer is possible
                     } else {
-                        const uint32_t K2 = l < 5u ? WK_L4 : (l < 7u ? WK_L6 : WK_L8);
+                        uint32_t K2 = l < 5u ? WK_L4 : (l < 7u ? WK_L6 : WK_L8);
+                        if (STREAM && p + 8u > N) K2 = WK_L4;
                         const uint32_t off2 = offset_of(l);
                         if (K2 != K || off2 != off) {  // on to another chain, from its top (what is done is skipped there)
                             K = K2;
@@ -1028,15 +1131,41 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
         if (round >= 1 && !__syncthreads_or(((fixing && res_exit != ex_used) || deferred || moved) ? 1 : 0)) break;
     }
     // ---- the true anchors
-    if (m < nseg) {
+    if (active) {
         uint64_t T = 0;
         if (marked) {
             T = F;
             if (Z != PZ_NONE) T |= A & (~0ull << (Z - seg0));
         }
-        // (segments are 64 positions: two whole words of the bitmap the host has cleared)
-        if ((uint32_t)T) trueg[seg0 >> 5] = (uint32_t)T;
-        if ((uint32_t)(T >> 32)) trueg[(seg0 >> 5) + 1] = (uint32_t)(T >> 32);
+        // (segments are 64 positions: two whole words of the bitmap the host has cleared; STREAM: the words at the ends of the
+        // window's targets are shared with the windows next to it)
+        if (STREAM) {
+            if ((uint32_t)T) atomicOr(&trueg[seg0 >> 5], (uint32_t)T);
+            if ((uint32_t)(T >> 32)) atomicOr(&trueg[(seg0 >> 5) + 1], (uint32_t)(T >> 32));
+        } else {
+            if ((uint32_t)T) trueg[seg0 >> 5] = (uint32_t)T;
+            if ((uint32_t)(T >> 32)) trueg[(seg0 >> 5) + 1] = (uint32_t)(T >> 32);
+        }
+    }
+    if (STREAM) {
+        // where the path leaves the window: the exit of the one segment on the path that leaves the targets
+        __syncthreads();
+        if (marked && res_exit >= t_end) sh_b = res_exit;
+        __syncthreads();
+        const uint32_t ex = sh_b;
+        const uint32_t was = sp.wexit[2 * c];
+        __syncthreads();
+        if (tid == 0) {
+            sp.wexit[2 * c] = ex;
+            sp.wexit[2 * c + 1] = ~0u;
+        }
+        if (sp.fix && was == ex) return;  // from here on the first launch's anchors stand
+        carry = ex - FL_MAX_DIST;  // (a window that is not the stream's last is left at or beyond 65274)
+        if (wi + 1 == sw.nwin && tid == 0) {
+            // the group's exit; in a fix launch: a NEW one -- the group behind has to be parsed again from it
+            __hip_atomic_store(&sp.gexit[blockIdx.x], ex + FL_MAX_DIST * ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sp.fix) atomicOr(sp.dirty, 1u);
+        }
     }
 #ifdef WK_PROF
     if ((tid & 63) == 0) {
@@ -1055,4 +1184,5 @@ __global__ __launch_bounds__(WK_THREADS, WK_WAVES_PER_SIMD) void k_lz_walk(const
     atomicAdd((unsigned long long*)&g_fl_prof[55], (unsigned long long)fl_wave_sum(c_gath));
     atomicAdd((unsigned long long*)&g_fl_prof[56], (unsigned long long)fl_wave_sum(c_rank));
 #endif
+    }  // windows
 }
