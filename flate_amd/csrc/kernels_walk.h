@@ -451,15 +451,23 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             if (i < WK_WIN_DW) win32[i] = v;
         }
     }
-    // the segments [64 m, 64 m + 64) that hold targets from the path's entry on: m0 (parsed from the entry itself) .. m0 + nseg - 1
+    // A chunk: the segments [64 m, 64 m + 64).  STREAM: the targets from the path's entry on, [carry, t_last), in segments of 32
+    // positions when they are at most 32768 (every window but a stream's first and last: all 1024 lanes have one), else of 64;
+    // segment m starts at sbase + (m << sg).
     const uint32_t t_end = STREAM ? t_last : N;
-    const uint32_t m0 = STREAM ? carry >> 6 : 0u;
-    const uint32_t nseg = ((t_end + WK_SEG - 1) >> 6) - m0;
+    const uint32_t sbase = STREAM ? carry : 0u;
+#ifdef WK_STREAM_SG6
+    const uint32_t sg = 6u;
+#else
+    const uint32_t sg = (STREAM && t_end - sbase <= 32768u) ? 5u : 6u;
+#endif
+    const uint32_t SEGN = 1u << sg;
+    const uint32_t nseg = (t_end - sbase + SEGN - 1) >> sg;
     const uint32_t m = tid;  // this lane's segment
-    const bool active = m >= m0 && m - m0 < nseg;
-    const uint32_t seg0 = m * WK_SEG;
-    const uint32_t seg_lo = (STREAM && m == m0) ? carry : seg0;
-    const uint32_t seg_end = min(seg0 + WK_SEG, t_end);
+    const bool active = m < nseg;
+    const uint32_t seg0 = sbase + (m << sg);
+    const uint32_t seg_end = min(seg0 + SEGN, t_end);
+#define WK_SEG_OF(x) (((x) - sbase) >> sg)
     uint64_t A = 0, F = 0;  // anchors of the lane's own parse; of the parse from the entry
     uint32_t X = seg_end;   // exit of the lane's own parse
     uint32_t res_entry = PZ_NONE, res_exit = 0, Z = PZ_NONE;
@@ -471,8 +479,12 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
     // chain and matches 258 bytes >= nice >= lazy) and goes on at e + 258.  Such segments cost no trips, and a change of the
     // path's phase crosses a whole run of them inside ONE round of the stitch (4 KiB of padding took 16 rounds).
     bool deep = false;
-    if (DEEP && m >= 1 && m > m0 && seg0 + WK_SEG + FL_MAX_MATCH <= N && seg0 + WK_SEG <= t_end) {
-        const uint32_t x0 = seg0 - 1u, x1 = seg0 + WK_SEG + FL_MAX_MATCH;
+#ifdef WK_STREAM_NODEEP
+    if (DEEP && !STREAM && m >= 1 && seg0 + SEGN + FL_MAX_MATCH <= N && seg0 + SEGN <= t_end) {
+#else
+    if (DEEP && m >= 1 && seg0 + SEGN + FL_MAX_MATCH <= N && seg0 + SEGN <= t_end) {
+#endif
+        const uint32_t x0 = seg0 - 1u, x1 = seg0 + SEGN + FL_MAX_MATCH;
         const uint32_t bp = (win32[x0 >> 2] >> (8u * (x0 & 3u)) & 0xffu) * 0x01010101u;
         deep = true;
         for (uint32_t x = x0; x < x1; x += 8) {
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         if (round == 0) {
             if (active) {
                 st = ST_SPEC;
-                a = seg_lo;
+                a = seg0;
             }
             if (DEEP && deep) {  // the own parse in closed form; what is left is the wait for the lane before
                 descg[seg0] = DEEP_DESC;
@@ -529,9 +541,9 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                 const uint32_t ex = res_entry != PZ_NONE ? res_exit : X;
                 ex_used = ex;
                 tExg[m] = (uint16_t)ex;
-                tNxt[0][m] = (uint16_t)(ex >= t_end ? WK_TERM : (ex >> 6));
-                tMark[m] = m == m0 ? 1 : 0;
-                tEnt[m] = m == m0 ? (uint16_t)seg_lo : (uint16_t)PZ_NONE;
+                tNxt[0][m] = (uint16_t)(ex >= t_end ? WK_TERM : WK_SEG_OF(ex));
+                tMark[m] = m == 0 ? 1 : 0;
+                tEnt[m] = m == 0 ? (uint16_t)seg0 : (uint16_t)PZ_NONE;
             }
             __syncthreads();
             uint32_t cur = 0;
@@ -552,8 +564,8 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             if (marked) {
                 const uint32_t ex = tExg[m];
                 if (ex < t_end) {
-                    tEnt[ex >> 6] = (uint16_t)ex;
-                    tNxt[0][ex >> 6] = (uint16_t)m;  // (the segment the path comes from; the jump tables are free now)
+                    tEnt[WK_SEG_OF(ex)] = (uint16_t)ex;
+                    tNxt[0][WK_SEG_OF(ex)] = (uint16_t)m;  // (the segment the path comes from; the jump tables are free now)
                 }
             }
             __syncthreads();
@@ -569,8 +581,8 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                         res_entry = y_in;
                         res_exit = y_in + FL_MAX_MATCH;  // (< N: the segment is deep)
                         if (res_exit < t_end) {
-                            tEnt[res_exit >> 6] = (uint16_t)res_exit;
-                            tNxt[0][res_exit >> 6] = (uint16_t)m;
+                            tEnt[WK_SEG_OF(res_exit)] = (uint16_t)res_exit;
+                            tNxt[0][WK_SEG_OF(res_exit)] = (uint16_t)m;
                         }
                         upd = true;
                         moved = true;
@@ -590,12 +602,14 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             // round, 16 rounds for 4 KiB of padding: everything behind the run was parsed again in every one of them.)
             tMark[m] = need ? 0 : 1;
             __syncthreads();
-            const bool work = need && (m == m0 || tMark[tNxt[0][m]] != 0);
+            const bool work = need && (m == 0 || tMark[tNxt[0][m]] != 0);
             deferred = need && !work;
 #ifdef WK_PROF
             c_tstitch += __builtin_readcyclecounter() - c_ts0;
 #endif
-            if (!__syncthreads_or(need ? 1 : 0)) break;
+            // (moved: a deep segment has taken another entry than the path above assumed -- the marks of what lay behind its old
+            // exit are stale; in a window that is one run to its end nobody else asks for the next round)
+            if (!__syncthreads_or((need || moved) ? 1 : 0)) break;
             if (work) {
                 st = ST_FIX;
                 a = y_in;
@@ -816,10 +830,10 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                                 X = a;
                                 __hip_atomic_store(&tX[m], (uint16_t)~a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 amask = 0;
-                                if (m == m0) {  // the first segment's own parse is the true one
-                                    res_entry = seg_lo;
+                                if (m == 0) {  // the first segment's own parse is the true one
+                                    res_entry = seg0;
                                     res_exit = a;
-                                    Z = seg_lo;
+                                    Z = seg0;
                                     st = ST_DONE;
                                     cs = CS_IDLE;
                                 } else {
@@ -1139,9 +1153,13 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         }
         // (segments are 64 positions: two whole words of the bitmap the host has cleared; STREAM: the words at the ends of the
         // window's targets are shared with the windows next to it)
-        if (STREAM) {
-            if ((uint32_t)T) atomicOr(&trueg[seg0 >> 5], (uint32_t)T);
-            if ((uint32_t)(T >> 32)) atomicOr(&trueg[(seg0 >> 5) + 1], (uint32_t)(T >> 32));
+        if (STREAM) {  // (a segment need not start on a word boundary)
+            const uint32_t sh = seg0 & 31u;
+            const uint64_t lo64 = T << sh;
+            const uint32_t w0 = (uint32_t)lo64, w1 = (uint32_t)(lo64 >> 32), w2 = sh ? (uint32_t)(T >> (64u - sh)) : 0u;
+            if (w0) atomicOr(&trueg[seg0 >> 5], w0);
+            if (w1) atomicOr(&trueg[(seg0 >> 5) + 1], w1);
+            if (w2) atomicOr(&trueg[(seg0 >> 5) + 2], w2);
         } else {
             if ((uint32_t)T) trueg[seg0 >> 5] = (uint32_t)T;
             if ((uint32_t)(T >> 32)) trueg[(seg0 >> 5) + 1] = (uint32_t)(T >> 32);
@@ -1153,6 +1171,14 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         if (marked && res_exit >= t_end) sh_b = res_exit;
         __syncthreads();
         const uint32_t ex = sh_b;
+#ifdef WK_STREAM_DEBUG
+        if (tid == 0) printf("[walk] group %u window %u (ws %u): N %u NB %u targets [%u, %u) carry %u sg %u nseg %u exit %u wg_deep %d\n", blockIdx.x, c, ws, N, NB, t_first, t_last, carry, sg, nseg, ex, (int)wg_deep);
+        {
+            uint32_t nmark = __syncthreads_count(marked ? 1 : 0), ndeep = __syncthreads_count(deep ? 1 : 0);
+            if (tid == 0) printf("[walk]    marked %u deep %u\n", nmark, ndeep);
+            if (marked && (m < 3 || m + 3 >= nseg)) printf("[walk]    lane %u seg0 %u entry %u exit %u Z %u A %llx F %llx deep %d\n", m, seg0, res_entry, res_exit, Z, (unsigned long long)A, (unsigned long long)F, (int)deep);
+        }
+#endif
         const uint32_t was = sp.wexit[2 * c];
         __syncthreads();
         if (tid == 0) {
@@ -1184,5 +1210,6 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
     atomicAdd((unsigned long long*)&g_fl_prof[55], (unsigned long long)fl_wave_sum(c_gath));
     atomicAdd((unsigned long long*)&g_fl_prof[56], (unsigned long long)fl_wave_sum(c_rank));
 #endif
+#undef WK_SEG_OF
     }  // windows
 }
