@@ -409,7 +409,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         uint32_t G = ~0u;
         if (nc < h->n_cu) G = (uint32_t)std::max<uint64_t>(4, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
         // (levels 8-9: two workgroups of k_lz_walk share a CU, and the fix launch parses a whole window per group again: groups of 8 at least)
-        if (deep_walk && nc < 4 * h->n_cu) G = (uint32_t)std::max<uint64_t>(8, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
+        // -- and as many groups as the chip holds at a time (two a CU), so that they all end together: one 177 MB stream as 675
+        // groups of 8 windows took 2 x 8 window times + 2 for the fix launch, as 491 groups of 11 it takes 11 + 1
+        if (deep_walk && nc < 2 * h->n_cu) G = (uint32_t)std::max<uint64_t>(8, (total_win + 2ull * h->n_cu - 1) / (2ull * h->n_cu));
         if (h->knobs.stream_group) G = h->knobs.stream_group;
         for (uint32_t i = 0; i < nc; i++) {
             const fl_chunk& c = hch[i];

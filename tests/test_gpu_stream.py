@@ -281,6 +281,42 @@ def test_periodic_streams_do_not_loop_in_the_grouped_fix(monkeypatch):
     assert prof["k_lz_parse"][1] == 2 and "k_lz_match" not in prof, prof
 
 
+def test_long_streams_of_levels_8_and_9_take_the_windows_of_the_sparse_chain_tokenizer(monkeypatch):
+    """Round 6: whole streams of levels 8-9 (no flush points) on k_lz_links / k_lz_walk<true, true> -- the windows of
+    k_lz_parse<true> for the sparse-chain tokenizer -- by the library's own estimate: no k_lz_sort / k_lz_match launch, bytes ==
+    oracle; groups of windows parsed from a guess and again from their true entry (FLATE_HIP_STREAM_GROUP forces small groups);
+    periodic data, where a guessed parse never meets the true one, goes to the tiles after FL_STREAM_FIX_MAX fix launches."""
+    from flate_amd import synth
+    text = synth.text(synth.SEED_TEXT + 5, 40 << 20).tobytes()
+    tar = synth.tar_like(synth.SEED_TAR, 64 << 20).tobytes()
+    sil = synth.silesia_like(synth.SEED_SILESIA + 9, 3 << 20).tobytes()
+    eng = engine()
+    # (the estimate takes the windows when the streams fill the chip: from about 50 MiB a pass)
+    for level, datas in ((9, [tar]), (8, [text, tar[:30_000_001]])):
+        eng.profile_enable(True)
+        eng.profile_reset()
+        outs, st = eng.compress_many(datas, O.GZIP, level)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        assert st == [0] * len(datas)
+        for d, o in zip(datas, outs):
+            assert o == O.compress(d, O.GZIP, level), (level, len(d))
+        assert "k_lz_walk" in prof and "k_lz_match" not in prof and "k_lz_sort" not in prof, prof
+    monkeypatch.setenv("FLATE_HIP_STREAM_WINDOWS", "1")
+    monkeypatch.setenv("FLATE_HIP_STREAM_GROUP", "2")
+    for level in (8, 9):
+        datas = [sil, text[:900_000], bytes(400_000) + text[:300_000] + bytes(300_000), (b"ab" * 129) * 3000, tar[:65_536 * 3 + 17]]
+        eng.profile_enable(True)
+        eng.profile_reset()
+        outs, st = eng.compress_many(datas, O.ZLIB, level)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        assert st == [0] * len(datas)
+        for d, o in zip(datas, outs):
+            assert o == O.compress(d, O.ZLIB, level), (level, len(d))
+        assert prof["k_lz_walk"][1] <= 4, prof  # the first launch + FL_STREAM_FIX_MAX
+
+
 def test_whole_stream_tokens_match_the_independent_slide_fixtures():
     # tests/golden/slide: inputs of 150-300 KB with token lists from a pure-Python model of the reference that is
     # independent of the oracle (tests/golden/make_slide_fixtures.py): the GPU's whole-stream path against it directly
