@@ -393,6 +393,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     std::vector<fl_chunk> wch;
     std::vector<fl_swin> sws;
     bool grouped = false;  // some stream is split into groups of windows: a fix launch follows (kernels_parse.h)
+    uint32_t round_cap = 0;  // rounds of a window's stitch after which the pass is given to the tiles (0: never)
     if (windows) {
         if (h->n_cu == 0) {
             int v = 0;
@@ -404,14 +405,15 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             bytes += hch[i].in_len;
             total_win += hch[i].n_slides + 1u;
         }
-        // Many streams: a workgroup walks a whole stream (no guess, no fix).  Few: groups of G windows, about four groups per
-        // CU, at least four windows each (the fix launch parses one sub-pass per group again: an eighth of the work at G = 4).
+        // Many streams: a workgroup walks a whole stream (no guess, no fix).  Fewer than the chip holds workgroups at a time (one a
+        // CU; levels 8-9: two): groups of G windows, as many groups as it holds, so that they all end together and the fix launch
+        // -- which parses one window (a sub-pass) per group again -- is one round: G + 1 window times.  (Round 5 took four groups
+        // per CU of at least four windows: one 1 MiB stream at level 6 cost 1.9 ms against 1.05 as 32 groups of one window, and
+        // 1.34 on the sort / match tiles; one 177 MB stream at level 9 as 675 groups of 8 took 2 x 8 + 2 window times, as 491
+        // groups of 11 it takes 11 + 1.  tools/small_stream_round.sh)
+        const uint64_t slots = deep_walk ? 2ull * h->n_cu : (uint64_t)h->n_cu;
         uint32_t G = ~0u;
-        if (nc < h->n_cu) G = (uint32_t)std::max<uint64_t>(4, (total_win + 4ull * h->n_cu - 1) / (4ull * h->n_cu));
-        // (levels 8-9: two workgroups of k_lz_walk share a CU, and the fix launch parses a whole window per group again: groups of 8 at least)
-        // -- and as many groups as the chip holds at a time (two a CU), so that they all end together: one 177 MB stream as 675
-        // groups of 8 windows took 2 x 8 window times + 2 for the fix launch, as 491 groups of 11 it takes 11 + 1
-        if (deep_walk && nc < 2 * h->n_cu) G = (uint32_t)std::max<uint64_t>(8, (total_win + 2ull * h->n_cu - 1) / (2ull * h->n_cu));
+        if (nc < slots) G = (uint32_t)std::max<uint64_t>(1, (total_win + slots - 1) / slots);
         if (h->knobs.stream_group) G = h->knobs.stream_group;
         for (uint32_t i = 0; i < nc; i++) {
             const fl_chunk& c = hch[i];
@@ -444,12 +446,14 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         uint32_t max_win = 0;
         for (const fl_swin& sw : sws) max_win = std::max(max_win, sw.nwin);
         (void)gmax;
-        // a window costs a workgroup about 0.28 ms; sort / match cost about 0.061 ms per MiB on all CUs (and about a millisecond
-        // of kernel latencies whatever the size)
-        // (levels 8-9: two workgroups of k_lz_walk share a CU, a window costs one about WK_WIN_MS; sort / match cost 0.19 ms per MiB there)
-        const double est_new = deep_walk ? (double)((ng + 2 * h->n_cu - 1) / (2 * h->n_cu)) * max_win * 1.2 + (grouped ? 1.0 : 0.0)
-                                         : (double)((ng + h->n_cu - 1) / h->n_cu) * max_win * 0.28 + (grouped ? 0.5 : 0.0);
-        const double est_old = (double)bytes / 1048576.0 * (deep_walk ? 0.19 : 0.061) + 1.0;
+        // A window costs a workgroup about 0.28 ms (levels 8-9: 1.2, text 1.1, TAR-like 1.6), the fix launch one more per round and
+        // a host wait; sort / match cost about 0.061 ms per MiB on all CUs (levels 8-9: 0.11 text, 0.20 TAR-like) and 0.8 (1.3) ms
+        // of kernel latencies whatever the size.
+        if (bytes < (64ull << 20) && nc < slots) round_cap = 24u;
+        const uint64_t rounds = (ng + slots - 1) / slots;
+        const double win_ms = deep_walk ? 1.5 : 0.28;
+        const double est_new = (double)rounds * max_win * win_ms + (grouped ? (double)rounds * win_ms + 0.1 : 0.0);
+        const double est_old = (double)bytes / 1048576.0 * (deep_walk ? 0.11 : 0.061) + (deep_walk ? 1.3 : 0.8);
         if (h->knobs.stream_windows < 0 && est_new >= est_old) windows = false;
         if (wch.size() > tile_limit) windows = false;  // (the chain links of all windows at once: 128 KiB each)
     }
@@ -473,7 +477,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         HIP_OK(h, hipStreamSynchronize(st));  // the host vectors must outlive the async copies
         const fl_chunk* dwc = (const fl_chunk*)h->wchunks.p;
         // the tokenizer over the groups of windows: the first launch (fix = 0), or one from the groups' true entries (fix = 1)
+        // (a small pass of few streams -- where round 5 took the tiles -- gives a window up after 24 rounds of its stitch: periodic data)
         auto launch_tokenizer = [&](uint32_t fix) {
+            fix |= round_cap << 8;
             if (deep_walk) {
                 ProfScope ps(h, K_LZ_WALK);
                 wk_stream sp{(const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, fix};
@@ -497,6 +503,7 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc,
                                (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr);
         }
+        HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
         launch_tokenizer(0u);
         // the groups that were parsed from a guess: again from where the group before them leaves, until nothing moves any more
         // (one launch in practice: a parse falls in step within a few bytes; the loop is what makes it exact).  NOT on
@@ -504,14 +511,23 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         // meets the true one, and every launch settles one more group (about ng launches).  After FL_STREAM_FIX_MAX
         // launches the pass is given to the sort / match tiles, which cost the same whatever the data.
         bool gave_up = false;
-        for (uint32_t it = 0; grouped; it++) {
+        {
+            // (bit 31: some window's stitch did not settle within the round cap -- periodic data -- and its workgroup has stopped)
+            uint32_t flag = 0;
+            HIP_OK(h, hipMemcpyAsync(&flag, d_dirty, sizeof flag, hipMemcpyDeviceToHost, st));
+            HIP_OK(h, hipStreamSynchronize(st));
+            gave_up = (flag & 0x80000000u) != 0;
+        }
+        for (uint32_t it = 0; grouped && !gave_up; it++) {
             HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
             launch_tokenizer(1u);
             uint32_t flag = 0;
             HIP_OK(h, hipMemcpyAsync(&flag, d_dirty, sizeof flag, hipMemcpyDeviceToHost, st));
             HIP_OK(h, hipStreamSynchronize(st));
             if (!flag) break;
-            if (it + 1 >= FL_STREAM_FIX_MAX) {
+            // (`flag` = the groups that were parsed to their end with a new exit.  Text: none after the first fix launch.  More than
+            // an eighth of them: periodic data -- every launch settles one group per stream -- and no reason to try twice more)
+            if (it + 1 >= FL_STREAM_FIX_MAX || flag > ng / 8 + 1) {  // (incl. bit 31: a window that does not settle)
                 gave_up = true;
                 break;
             }

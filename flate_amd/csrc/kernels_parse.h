@@ -433,7 +433,9 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                                            const fl_chunk* __restrict__ schunks,
                                                            const uint32_t* __restrict__ zones,
                                                            uint32_t* gexit, uint32_t* gentry, uint32_t* wexit,
-                                                           uint32_t* dirty, uint32_t fix) {
+                                                           uint32_t* dirty, uint32_t fix_cap) {
+    const uint32_t fix = fix_cap & 1u;         // STREAM: the launch from the groups' true entries
+    const uint32_t round_cap = fix_cap >> 8;   // STREAM: rounds of the stitch after which a window is given up (0: never)
     // One block of LDS in this order: the window at address 0 (a window byte's LDS address is its position: no base to add),
     // the links behind it (their base, 49680, fits the offset field of the LDS instructions).
     struct pz_lds {
@@ -790,6 +792,15 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         // Later rounds: FIX from the entry the stitch has found, for the few segments where that guess was wrong.
         enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
         for (uint32_t round = 0;; round++) {
+            // STREAM: a window whose stitch does not settle -- PERIODIC data: paths from different entries never meet, every round
+            // settles one more segment (1.65 ms a window where text takes 0.28) -- is given up: the host takes the sort / match
+            // tiles for the pass (bit 31 of `dirty`; text settles in 4 rounds on average).  Only where the host says so: passes small
+            // enough that the tiles cost little -- a run of 10 KiB of zeros inside a window takes 40 rounds and is no reason to send a
+            // large pass there.
+            if (STREAM && round_cap && round >= round_cap) {
+                if (tid == 0) atomicOr(dirty, 0x80000000u);
+                return;
+            }
             PZ_CNT(c_rounds, 1);
 #ifdef PZ_PROF
             const uint64_t c_tr0 = __builtin_readcyclecounter();
@@ -1477,7 +1488,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             // the group's exit; in a fix launch: a NEW one (no sub-pass left where it left before): the group behind has to be
             // parsed again from it
             __hip_atomic_store(&gexit[blockIdx.x], sh_exit + FL_MAX_DIST * ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (fix) atomicOr(dirty, 1u);
+            if (fix) atomicAdd(dirty, 1u);
         }
     }
 #ifdef PZ_PROF

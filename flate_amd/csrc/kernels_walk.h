@@ -299,7 +299,7 @@ struct wk_stream {
     uint32_t* gentry;
     uint32_t* wexit;
     uint32_t* dirty;
-    uint32_t fix;
+    uint32_t fix;  // bit 0: the launch from the groups' true entries; >> 8: rounds of the stitch after which a window is given up (0: never)
 };
 #define WK_TERM 0xffffu  // pointer jumping: the path has left the chunk / the window's targets
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         sck = sp.schunks[sw.chunk];
         if (sck.skip) return;
         if (sw.prev != ~0u) {
-            if (sp.fix) {
+            if (sp.fix & 1u) {
                 // the true entry: where the group before leaves (absolute stream position), read by ONE thread (k_lz_parse<true>)
                 if (tid == 0) {
                     sh_a = __hip_atomic_load(&sp.gexit[sw.prev], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             } else {
                 guessed = true;  // (the first window's first target: set below)
             }
-        } else if (sp.fix) {
+        } else if (sp.fix & 1u) {
             return;  // a stream's first group starts at the stream's start
         }
     }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             if (tid == 0) sp.wexit[2 * c] = sp.wexit[2 * c + 1] = ~0u;
             continue;
         }
-        if (sp.fix) {
+        if (sp.fix & 1u) {
             // the anchors the first launch left in this window's targets go: bit by bit at the ends (the words there are shared
             // with the windows next to it, which other workgroups may be writing), whole words in between
             const uint64_t b0 = pos_off + t_first, b1 = pos_off + t_last;  // absolute bits [b0, b1)
@@ -506,6 +506,11 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
 
     enum { ST_SPEC = 0, ST_WAIT = 1, ST_FIX = 2, ST_DONE = 3 };
     for (uint32_t round = 0;; round++) {
+        // (STREAM: a window whose stitch does not settle is given up -- periodic data; see k_lz_parse<true>)
+        if (STREAM && (sp.fix >> 8) && round >= (sp.fix >> 8)) {
+            if (tid == 0) atomicOr(sp.dirty, 0x80000000u);
+            return;
+        }
 #ifdef WK_PROF
         if (tid == 0) atomicAdd((unsigned long long*)&g_fl_prof[43], 1ull);
 #ifdef WK_ROUND_CAP
@@ -1188,12 +1193,12 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             sp.wexit[2 * c] = ex;
             sp.wexit[2 * c + 1] = ~0u;
         }
-        if (sp.fix && was == ex) return;  // from here on the first launch's anchors stand
+        if ((sp.fix & 1u) && was == ex) return;  // from here on the first launch's anchors stand
         carry = ex - FL_MAX_DIST;  // (a window that is not the stream's last is left at or beyond 65274)
         if (wi + 1 == sw.nwin && tid == 0) {
             // the group's exit; in a fix launch: a NEW one -- the group behind has to be parsed again from it
             __hip_atomic_store(&sp.gexit[blockIdx.x], ex + FL_MAX_DIST * ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sp.fix) atomicOr(sp.dirty, 1u);
+            if (sp.fix & 1u) atomicAdd(sp.dirty, 1u);
         }
     }
 #ifdef WK_PROF

@@ -292,7 +292,7 @@ def test_long_streams_of_levels_8_and_9_take_the_windows_of_the_sparse_chain_tok
     sil = synth.silesia_like(synth.SEED_SILESIA + 9, 3 << 20).tobytes()
     eng = engine()
     # (the estimate takes the windows when the streams fill the chip: from about 50 MiB a pass)
-    for level, datas in ((9, [tar]), (8, [text, tar[:30_000_001]])):
+    for level, datas in ((9, [tar]), (8, [text, tar[:(24 << 20) + 1]])):
         eng.profile_enable(True)
         eng.profile_reset()
         outs, st = eng.compress_many(datas, O.GZIP, level)
