@@ -423,8 +423,8 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                 w.in_off = c.in_off + (uint64_t)FL_SEG * j;
                 w.in_len = (uint32_t)std::min<uint64_t>(65536u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j);
                 w.pad_ = 1u;  // (a window: k_lz_chain builds its chains whatever it holds)
-                // (levels 8-9: + the bytes behind the window that the lazy calls of its last anchor look at, kernels_walk.h)
-                if (deep_walk) w.pad_ |= (uint32_t)std::min<uint64_t>(264u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j - w.in_len) << 8;
+                // (+ the bytes behind the window that the lazy calls of its last anchor look at: kernels_parse.h, kernels_walk.h)
+                w.pad_ |= (uint32_t)std::min<uint64_t>(264u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j - w.in_len) << 8;
                 wch.push_back(w);
             }
             uint32_t prev = ~0u;

@@ -620,6 +620,10 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
 #define PZ_SEG_OF(D) (sub ? (STREAM ? PZ_SEG_BS_OF(D) : PZ_SEG_B_OF(D)) : (small ? PZ_SEG_AS_OF(D) : (vary ? pz_vseg(lds.vt, D) : (PZ_SEG_A == 64u ? ((D) >> 6) : (((D) * 43691u) >> 21)))))
         const uint32_t nseg = vary ? pz_vseg(lds.vt, end - t0 - 1u) + 1u : PZ_SEG_OF(end - t0 + S - 1);
         const uint32_t Nr = N - r0;            // end of the input
+        // (STREAM: + the bytes of the stream behind the window, at most 264 (pad_ >> 8): the lazy calls of a window's last anchor are
+        // made after the next slide, with the whole lookahead -- deflate.zig:304-321; 65536 - 65279 = 257 bytes are not all such a
+        // call may look at: tests/test_gpu_stream.py::test_lazy_chain_across_a_slide_sees_the_whole_lookahead)
+        const uint32_t NBr = STREAM ? Nr + (ckl.pad_ >> 8) : Nr;
         const uint32_t endr = end - r0, t0r = t0 - r0;
         // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
         // last anchor gets there): the reference has dropped every candidate at or below the next window's start by then
@@ -644,13 +648,13 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             const uint32_t sh16 = (uint32_t)((uintptr_t)(src + r0) & 15);
             const uint32_t ash = sh16 & 3u, dshift = sh16 >> 2;
             const uint4* src16 = (const uint4*)(src + r0 - sh16);
-            const uint32_t ngran = (Nr + sh16 + 15) >> 4;  // granules that hold at least one byte of the input
+            const uint32_t ngran = (NBr + sh16 + 15) >> 4;  // granules that hold at least one byte of the input
             const uint32_t nb_pos = min(Nr, (uint32_t)PZ_PRV_N);  // positions whose links are staged
             const uint4* pv4 = (const uint4*)(pvg + r0);         // (r0 * 2 bytes is a multiple of 16)
             uint32_t* prv2 = (uint32_t*)prv;
             auto put_win = [&](uint32_t i, uint32_t lo, uint32_t hi) {
                 uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, ash);
-                if (4 * i + 4 > Nr) v = 4 * i < Nr ? (v & ((1u << (8 * (Nr - 4 * i))) - 1u)) : 0u;  // zero padding
+                if (4 * i + 4 > NBr) v = 4 * i < NBr ? (v & ((1u << (8 * (NBr - 4 * i))) - 1u)) : 0u;  // zero padding
                 if (i < PZ_WIN_DW) win32[i] = v;
             };
             auto put_prv = [&](uint32_t i, uint32_t v) {  // two links per dword; relative to r0, 0 = none (also everything below r0)
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         p = (PP);                                                              \
         best = (LL);                                                           \
         bdist = 0;                                                             \
-        maxlen = min(Nr - p, (uint32_t)FL_MAX_MATCH);                          \
+        maxlen = min(NBr - p, (uint32_t)FL_MAX_MATCH);                         \
         q = prv[p];                                                            \
         lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
         if (STREAM && p >= zt) lo = max(lo, zlo);                              \

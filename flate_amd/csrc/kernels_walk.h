@@ -570,7 +570,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             }
             marked = active && tMark[m] != 0;
             if (marked) {
-                const uint32_t ex = tExg[m];
+                const uint32_t ex = ex_used;  // (the lane's own, in 32 bits: STREAM exits reach 65536 + 264, tExg holds 16)
                 if (ex < t_end) {
                     tEnt[WK_SEG_OF(ex)] = (uint16_t)ex;
                     tNxt[0][WK_SEG_OF(ex)] = (uint16_t)m;  // (the segment the path comes from; the jump tables are free now)
@@ -836,7 +836,9 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                             if (st == ST_SPEC) {
                                 A = amask;
                                 X = a;
-                                __hip_atomic_store(&tX[m], (uint16_t)~a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                // (STREAM: an exit beyond 65535 -- a match of the window's last anchors that ends in the bytes behind
+                                // the window -- is handed on as 1: no segment but the first holds that, and 65536 would read "not yet")
+                                __hip_atomic_store(&tX[m], (uint16_t)~((STREAM && a > 0xffffu) ? 1u : a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 amask = 0;
                                 if (m == 0) {  // the first segment's own parse is the true one
                                     res_entry = seg0;
