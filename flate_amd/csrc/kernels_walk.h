@@ -459,11 +459,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
     // segment m starts at sbase + (m << sg).
     const uint32_t t_end = STREAM ? t_last : N;
     const uint32_t sbase = STREAM ? carry : 0u;
-#ifdef WK_STREAM_SG6
-    const uint32_t sg = 6u;
-#else
     const uint32_t sg = (STREAM && t_end - sbase <= 32768u) ? 5u : 6u;
-#endif
     const uint32_t SEGN = 1u << sg;
     const uint32_t nseg = (t_end - sbase + SEGN - 1) >> sg;
     const uint32_t m = tid;  // this lane's segment
@@ -482,11 +478,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
     // chain and matches 258 bytes >= nice >= lazy) and goes on at e + 258.  Such segments cost no trips, and a change of the
     // path's phase crosses a whole run of them inside ONE round of the stitch (4 KiB of padding took 16 rounds).
     bool deep = false;
-#ifdef WK_STREAM_NODEEP
-    if (DEEP && !STREAM && m >= 1 && seg0 + SEGN + FL_MAX_MATCH <= N && seg0 + SEGN <= t_end) {
-#else
     if (DEEP && m >= 1 && seg0 + SEGN + FL_MAX_MATCH <= N && seg0 + SEGN <= t_end) {
-#endif
         const uint32_t x0 = seg0 - 1u, x1 = seg0 + SEGN + FL_MAX_MATCH;
         const uint32_t bp = (win32[x0 >> 2] >> (8u * (x0 & 3u)) & 0xffu) * 0x01010101u;
         deep = true;
@@ -1181,14 +1173,6 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         if (marked && res_exit >= t_end) sh_b = res_exit;
         __syncthreads();
         const uint32_t ex = sh_b;
-#ifdef WK_STREAM_DEBUG
-        if (tid == 0) printf("[walk] group %u window %u (ws %u): N %u NB %u targets [%u, %u) carry %u sg %u nseg %u exit %u wg_deep %d\n", blockIdx.x, c, ws, N, NB, t_first, t_last, carry, sg, nseg, ex, (int)wg_deep);
-        {
-            uint32_t nmark = __syncthreads_count(marked ? 1 : 0), ndeep = __syncthreads_count(deep ? 1 : 0);
-            if (tid == 0) printf("[walk]    marked %u deep %u\n", nmark, ndeep);
-            if (marked && (m < 3 || m + 3 >= nseg)) printf("[walk]    lane %u seg0 %u entry %u exit %u Z %u A %llx F %llx deep %d\n", m, seg0, res_entry, res_exit, Z, (unsigned long long)A, (unsigned long long)F, (int)deep);
-        }
-#endif
         const uint32_t was = sp.wexit[2 * c];
         __syncthreads();
         if (tid == 0) {

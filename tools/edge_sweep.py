@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""One-off sweep of the slide edge (tests/test_gpu_stream.py::_edge_stream): lazy chains of improving matches that start at one of a
+window's last targets and end in a long match found after the slide; random start, chain length, window number and stream length;
+levels 4-9 through the library's own choice of path.  usage: edge_sweep.py [seed] [cases]"""
+import os, sys
+os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import _oracle as O
+from flate_amd import Engine
+from test_gpu_stream import _edge_stream
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = np.random.default_rng(seed)
+eng = Engine(0)
+bad = 0
+for i in range(cases):
+    steps = int(rng.integers(1, 70))
+    a = int(rng.integers(65150, 65274))
+    k = int(rng.integers(0, 3))  # the window whose edge it is
+    total = int(rng.choice([a + steps + 258, a + steps + 258 + int(rng.integers(1, 400)), 65536 + 32768 * (k + 1), int(rng.integers(140000, 260000))]))
+    d = _edge_stream(seed=int(rng.integers(1, 1 << 30)), steps=steps, a=a, total=max(total, a + steps + 258))
+    if k:  # the same edge one or two windows later: junk of bytes that T does not hold in front
+        d = rng.integers(128, 256, 32768 * k, dtype=np.uint8).tobytes() + d
+    datas = [d, d[:len(d) - int(rng.integers(0, 300))]]
+    for level in (4, 5, 6, 7, 8, 9):
+        c = int(rng.integers(0, 3))
+        outs, st = eng.compress_many(datas, c, level)
+        for x, o, s in zip(datas, outs, st):
+            if s != 0 or o != O.compress(x, c, level):
+                bad += 1
+                print("EDGE MISMATCH case", i, "steps", steps, "a", a, "k", k, "len", len(x), "level", level, "container", c, "status", s, flush=True)
+print("EDGE SWEEP", "FAILED" if bad else "OK", bad)
