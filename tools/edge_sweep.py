@@ -20,7 +20,8 @@ for i in range(cases):
     a = int(rng.integers(65150, 65274))
     k = int(rng.integers(0, 3))  # the window whose edge it is
     total = int(rng.choice([a + steps + 258, a + steps + 258 + int(rng.integers(1, 400)), 65536 + 32768 * (k + 1), int(rng.integers(140000, 260000))]))
-    d = _edge_stream(seed=int(rng.integers(1, 1 << 30)), steps=steps, a=a, total=max(total, a + steps + 258))
+    base = int(rng.choice([34000, int(rng.integers(500, 40000)), int(rng.integers(32000, 33200))]))
+    d = _edge_stream(seed=int(rng.integers(1, 1 << 30)), steps=steps, a=a, total=max(total, a + steps + 258), base=base)
     if k:  # the same edge one or two windows later: junk of bytes that T does not hold in front
         d = rng.integers(128, 256, 32768 * k, dtype=np.uint8).tobytes() + d
     datas = [d, d[:len(d) - int(rng.integers(0, 300))]]
