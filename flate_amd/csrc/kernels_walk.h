@@ -262,9 +262,6 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, FL_CHAIN_WAVES / 2) void k_lz_
 #ifndef WK_STREAM_WAVES_PER_SIMD
 #define WK_STREAM_WAVES_PER_SIMD 8  // k_lz_walk<true, true>: two workgroups a CU, as the chunks' (one 256 MiB stream of text, level 9: 20.5 ms against 29.6 with one)
 #endif
-#ifndef WK_SGPR_ATTR
-#define WK_SGPR_ATTR
-#endif
 #ifndef WK_BURST
 #define WK_BURST 4        // chain steps per trip, at most
 #endif
@@ -305,7 +302,7 @@ struct wk_stream {
 
 // lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
 template <bool DEEP, bool STREAM = false>
-__global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_WAVES_PER_SIMD) WK_SGPR_ATTR void k_lz_walk(const uint8_t* __restrict__ in,
+__global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_WAVES_PER_SIMD) void k_lz_walk(const uint8_t* __restrict__ in,
                                                                            const fl_chunk* __restrict__ chunks, fl_params prm,
                                                                            const uint16_t* __restrict__ lnk,
                                                                            const uint32_t* __restrict__ cflag,

@@ -327,7 +327,7 @@ def _edge_stream(seed=7, a=65273, steps=6, total=140000, base=34000):
         return rng.integers(128, 256, n, dtype=np.uint8).tobytes()
     T = rng.integers(0, 128, steps + 258 + 8, dtype=np.uint8).tobytes()
     pieces = [T[k:2 * k + 4] for k in range(steps)] + [T[steps:steps + 258]]  # 4 + k bytes that match at a + k; 258 at a + steps
-    pre = bytearray(junk(max(40000, base + 4000 + 50 * steps)))
+    pre = bytearray(junk(min(a, max(40000, base + 4000 + 50 * steps))))
     pos = base  # (copies at or below 32768 are gone when the calls behind the slide look for them: Lookup.zig:43-51)
     for pc in pieces:
         pre[pos:pos + len(pc)] = pc
