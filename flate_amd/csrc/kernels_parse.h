@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
     // A chunk of ONE repeated byte (a run of zeros, say) needs no chains: k_lz_parse writes its anchors directly
     // (every position matches its predecessor over the whole lookahead).  Looked for granule by granule; the
     // scan of an ordinary chunk ends in its first step.
-    if (N >= 64 && !ck.pad_) {  // (pad_ != 0: a WINDOW of a long stream -- k_lz_parse<true> enters it anywhere: chains always)
+    if (N >= 64) {  // (pad_ != 0: a WINDOW of a long stream -- k_lz_parse<true> enters it anywhere: chains always, and cflag 3)
         const uint32_t b0 = src[0] * 0x01010101u;
         bool same = true;
         for (uint32_t g0 = 0; g0 < n_gran; g0 += 64 * FL_CHAIN_WAVES) {
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
             }
         }
         if (same) {  // (the same verdict in every thread)
-            if (threadIdx.x == 0) cflag[c] = 1u;
-            return;
+            if (threadIdx.x == 0) cflag[c] = ck.pad_ ? 3u : 1u;
+            if (!ck.pad_) return;
         }
     }
     {
@@ -541,6 +541,11 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
             if (tid == 0) wexit[2 * c] = wexit[2 * c + 1] = ~0u;
             continue;
         }
+    }
+    if (STREAM && round_cap && cflag[c] == 3u) {
+        // a window of one repeated byte in a pass that gives up on periodic data (see the round loop): at once
+        if (tid == 0) atomicOr(dirty, 0x80000000u);
+        return;
     }
     if (cflag[c] == 1u) {
         // The chunk is one repeated byte (k_lz_chain saw it and built no chains).  Positions 0 and 1 are
