@@ -299,6 +299,9 @@ struct wk_stream {
     uint32_t fix;  // bit 0: the launch from the groups' true entries; >> 8: rounds of the stitch after which a window is given up (0: never)
 };
 #define WK_TERM 0xffffu  // pointer jumping: the path has left the chunk / the window's targets
+// a value every lane holds alike, into a scalar register (what comes out of LDS or a struct in memory lives in a vector register per
+// lane otherwise -- and everything computed from it: the window's geometry cost k_lz_walk<true, true> 34 vector registers in scratch)
+#define WK_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 // lnk: per chunk a block of 4 x 65536 entries, [L4 | L6 | L8 | RK]
 template <bool DEEP, bool STREAM = false>
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                     sh_b = sp.gentry[blockIdx.x];
                 }
                 __syncthreads();
-                const uint32_t e = sh_a, was = sh_b;
+                const uint32_t e = WK_UNI(sh_a), was = WK_UNI(sh_b);
                 __syncthreads();
                 if (e == was) return;  // parsed from there already
                 if (tid == 0) sp.gentry[blockIdx.x] = e;
@@ -352,12 +355,12 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         }
     }
     for (uint32_t wi = 0; wi < sw.nwin; wi++) {
-    const uint32_t ws = sw.wfirst + wi;  // STREAM: the window's number in its stream
-    const uint32_t c = sw.win0 + wi;
+    const uint32_t ws = WK_UNI(sw.wfirst + wi);  // STREAM: the window's number in its stream
+    const uint32_t c = WK_UNI(sw.win0 + wi);
     const fl_chunk ck = chunks[c];
     if (!STREAM && ck.skip) return;
-    const uint32_t N = ck.in_len;                           // positions below N have links
-    const uint32_t NB = STREAM ? N + (ck.pad_ >> 8) : N;    // bytes of the window that exist
+    const uint32_t N = WK_UNI(ck.in_len);                           // positions below N have links
+    const uint32_t NB = STREAM ? WK_UNI(N + (ck.pad_ >> 8)) : N;    // bytes of the window that exist
     const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
     const uint8_t* src = in + ck.in_off;
     const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * ws : ck.pos_off;
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
     uint32_t t_first = 0, t_last = N;
     if (STREAM) {
         const uint32_t* zone = sp.zones + sck.zone_off;
-        if (ws) t_first = zone[ws - 1] - FL_MAX_DIST * ws;
-        if (ws < sck.n_slides) t_last = zone[ws] - FL_MAX_DIST * ws;
+        if (ws) t_first = WK_UNI(zone[ws - 1] - FL_MAX_DIST * ws);
+        if (ws < sck.n_slides) t_last = WK_UNI(zone[ws] - FL_MAX_DIST * ws);
         if (wi) __syncthreads();  // the window before is done with the LDS tables
         if (guessed && wi == 0) {
             carry = t_first;
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         __syncthreads();
         if (marked && res_exit >= t_end) sh_b = res_exit;
         __syncthreads();
-        const uint32_t ex = sh_b;
+        const uint32_t ex = WK_UNI(sh_b);
         const uint32_t was = sp.wexit[2 * c];
         __syncthreads();
         if (tid == 0) {
