@@ -187,6 +187,25 @@ def test_long_streams(inflate_path):
                 assert o == want and u == wused
 
 
+@pytest.mark.parametrize("ring", ["", "2048", "32768"])
+def test_directed_streams_that_fuzzing_rarely_builds(ring, monkeypatch):
+    """tests/_inflate_edge_cases.py: fixed-block symbols 286 / 287, distance codes 30 / 31, a distance equal to / one more than what
+    has been written, matches at the rings' edges, stored blocks of 0 and 65535 bytes, a wrong NLEN, zlib's long code-length runs.
+    Status, bytes and consumed count of every decoder == the oracle's (which agrees with puff.c on them: test_oracle_inflate_pins)."""
+    from _inflate_edge_cases import CASES
+    if ring:
+        monkeypatch.setenv("FLATE_HIP_INFLATE_RING", ring)
+    eng = engine()
+    names = sorted(CASES)
+    streams = [CASES[n] for n in names]
+    back, st, used = eng.decompress_many(streams, O.RAW, caps=[80000] * len(streams))
+    for n, s, b, stt, u in zip(names, streams, back, st, used):
+        name, want, wused = O.decompress(s, O.RAW, 0, cap=80000)
+        assert O.STATUS[stt] == name, (n, O.STATUS[stt], name)
+        if name == "Ok":
+            assert b == want and u == wused, n
+
+
 @pytest.mark.parametrize("ring", ["2048", "32768"])
 def test_fast_round_edges(ring, monkeypatch):
     """(k_inflate itself, both ring sizes: the long-stream kernels are switched off.)  What the fast rounds of k_inflate decide on (kernels_inflate.h): matches at the distances where the source moves

@@ -201,3 +201,18 @@ def test_differential_vs_puff_and_zlib_random_streams():
             co = pyzlib.compressobj(lvl, pyzlib.DEFLATED, -15)
             c = co.compress(data) + co.flush()
             assert O.decompress(c, O.RAW, cap=len(data) + 16)[:2] == ("Ok", data)
+
+
+def test_directed_edge_streams_agree_with_puff():
+    """tests/_inflate_edge_cases.py (what the GPU decoders are checked on under -m gpu): the oracle's success / failure and bytes ==
+    the reference's own differential inflater (bin/puff/puff.c, oracle/_ref)."""
+    import pytest
+    from _inflate_edge_cases import CASES
+    if not O.puff_available():
+        pytest.skip("oracle/_ref/libpuff.so is built from /root/reference, which is not here")
+    for n, s in sorted(CASES.items()):
+        name, out, _ = O.decompress(s, O.RAW, 0, cap=80000)
+        rc, pout = O.puff(s, cap=80000)
+        assert (name == "Ok") == (rc == 0), (n, name, rc)
+        if rc == 0:
+            assert pout == out, n
