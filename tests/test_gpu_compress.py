@@ -943,3 +943,49 @@ def test_runny_inputs_match_oracle():
         assert st == [0] * len(datas)
         for i, d in enumerate(datas):
             assert outs[i] == O.compress(d, O.RAW, level), (i, level)
+
+
+def test_inputs_on_the_match_finders_thresholds():
+    """tests/_adversarial.py: candidates exactly at, before and behind the chain budget and its quarter (deflate.zig:241-245), matches
+    of exactly good / lazy / nice bytes and one less / more, longer ones behind them, better ones at the next positions -- what
+    random data does not hold.  As chunks and as whole streams (the call in a window's interior, at its edge, in the next window):
+    bytes == oracle at every level.  tools/threshold_sweep.py runs hundreds of these through every path."""
+    import _adversarial as A
+    rng = np.random.default_rng(2024)
+    eng = engine()
+    for i in range(6):
+        for level in (4, 5, 6, 7, 8, 9):
+            d = A.threshold_input(rng, level, int(rng.choice([20000, 50000, 65535])))[-65535:]
+            s1 = A.junk(rng, int(rng.integers(0, 400))) + d + A.junk(rng, int(rng.integers(70000, 90000)))
+            edge = 65274 + int(rng.integers(-300, 20)) - (len(d) - 200)
+            s2 = (A.junk(rng, max(0, edge)) + d + A.junk(rng, 80000)) if edge > 0 else s1
+            datas = [d, s1, s2, A.junk(rng, 32768 + int(rng.integers(0, 3000))) + s2]
+            c = int(rng.integers(0, 3))
+            outs, st = eng.compress_many(datas, c, level)
+            assert st == [0] * 4, (i, level, st)
+            for j, (x, o) in enumerate(zip(datas, outs)):
+                assert o == O.compress(x, c, level), (i, level, j, len(x))
+
+
+def test_symbol_frequencies_that_need_the_length_limits():
+    """tests/_adversarial.py: literal, match-length / distance and code-length frequencies that grow like Fibonacci numbers or powers
+    of two: Huffman trees deeper than 15 (7) bits, which the builder has to flatten the way the reference does
+    (huffman_encoder.zig).  Modes 1 and 4-9, chunks and streams: bytes == oracle, and back through the GPU inflater."""
+    import _adversarial as A
+    rng = np.random.default_rng(77)
+    eng = engine()
+    for i in range(8):
+        growth = float(rng.choice([1.618, 2.0, 1.5, 3.0]))
+        nsym = int(rng.integers(12, 60))
+        n = int(rng.choice([3000, 20000, 65535, 150000]))
+        datas = [A.skewed(rng, n, growth, nsym), A.match_skew(rng, min(n, 100000), float(rng.choice([1.2, 1.618, 2.0]))),
+                 A.skewed(rng, n // 2, growth, nsym) + A.match_skew(rng, min(n, 60000) // 2 + 4100, 1.618)]
+        for mode in (1, 4, 6, 9):
+            c = int(rng.integers(0, 3))
+            outs, st = eng.compress_many(datas, c, mode)
+            for x, o, s in zip(datas, outs, st):
+                assert s in (0, 102) and o == O.compress(x, c, mode), (i, mode, len(x), growth, nsym, s)
+            back, st2, _ = eng.decompress_many(outs, c, caps=[len(x) + 8 for x in datas])
+            for x, o, b, s in zip(datas, outs, back, st2):
+                w = O.decompress(o, c, 0, cap=(len(x) + 8 + 7) & ~7)
+                assert O.STATUS[s] == w[0] and (w[0] != "Ok" or b == w[1]), (i, mode, len(x))

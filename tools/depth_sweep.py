@@ -16,31 +16,15 @@ rng = np.random.default_rng(seed)
 eng = Engine(0)
 
 
+from _adversarial import skewed as _skewed, match_skew as _match_skew
+
+
 def skewed(total, growth, nsym):
-    """bytes with symbol k about growth^k times (capped by total), shuffled"""
-    w = np.array([growth ** k for k in range(nsym)], dtype=np.float64)
-    cnt = np.maximum(1, np.floor(w / w.sum() * total)).astype(np.int64)
-    syms = rng.permutation(256)[:nsym]
-    a = np.repeat(syms.astype(np.uint8), cnt)
-    rng.shuffle(a)
-    return a[:total].tobytes()
+    return _skewed(rng, total, growth, nsym)
 
 
 def match_skew(total, growth):
-    """match lengths / distances with skewed frequencies: copies of earlier stretches at chosen lengths and distances"""
-    base = rng.integers(0, 256, 4000, dtype=np.uint8).tobytes()
-    out = bytearray(base)
-    lens = [3 + k for k in range(0, 255, 9)]
-    w = np.array([growth ** k for k in range(len(lens))]); w /= w.sum()
-    while len(out) < total:
-        L = int(rng.choice(lens, p=w))
-        dist = int(2 ** rng.integers(2, 15)) + int(rng.integers(0, 3))
-        dist = min(dist, len(out))
-        s = len(out) - dist
-        for i in range(L):
-            out.append(out[s + i])
-        out += rng.integers(0, 256, int(rng.integers(1, 3)), dtype=np.uint8).tobytes()
-    return bytes(out[:total])
+    return _match_skew(rng, total, growth)
 
 
 bad = 0

@@ -15,43 +15,15 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rng = np.random.default_rng(seed)
 eng = Engine(0)
-LV = {4: (4, 4, 16, 16), 5: (8, 16, 32, 32), 6: (8, 16, 128, 128), 7: (8, 32, 128, 256), 8: (32, 128, 258, 1024), 9: (32, 258, 258, 4096)}  # good, lazy, nice, chain
+from _adversarial import LV, junk as _junk, threshold_input
 
 
 def junk(n):
-    return rng.integers(128, 256, n, dtype=np.uint8).tobytes()
-
-
-def near(v):
-    return max(3, int(v) + int(rng.integers(-2, 3)))
+    return _junk(rng, n)
 
 
 def make(level, total):
-    good, lazy, nice, chain = LV[level]
-    S = rng.integers(0, 64, 600, dtype=np.uint8).tobytes()
-    copies = []  # farthest first
-    # a long candidate, far
-    copies.append(S[:near(rng.choice([nice + 4, 258, lazy + 3, 40]))])
-    # fillers that share the first 4 (or good + 1) bytes: around the budget
-    share = int(rng.choice([4, good, good + 1, 6]))
-    budget = int(rng.choice([chain, chain // 4, chain // 4 + 1, chain // 2]))
-    k = max(0, budget + int(rng.integers(-4, 3)))
-    k = min(k, (30000 - 2000) // (share + 3))
-    fill = [S[:share] + junk(3)[: 1 + int(rng.integers(0, 3))] for _ in range(k)]
-    # candidates at the thresholds, nearest
-    nearc = [S[:near(rng.choice([good, lazy, nice, good - 1, lazy - 1, nice - 1, 5, 7]))] for _ in range(int(rng.integers(0, 4)))]
-    # better matches at the next positions (lazy evaluation)
-    nextc = [S[o:o + near(rng.choice([good, lazy, nice, 9, 33, 258]))] for o in (1, 2, 3) if rng.random() < 0.5]
-    parts = copies + fill + nearc
-    order = list(range(len(nextc)))
-    body = bytearray()
-    for pc in nextc:
-        body += pc + junk(5)
-    for pc in parts:
-        body += pc + junk(2 + int(rng.integers(0, 3)))
-    body = bytes(body)
-    lead = junk(max(0, total - len(body) - len(S) - 200))
-    return lead + body + S + junk(200 - int(rng.integers(0, 150)))
+    return threshold_input(rng, level, total)
 
 
 bad = 0
