@@ -211,6 +211,24 @@ def splitmix(seed, n):
     return bytes(out[:n])
 
 
+def slide_edge(seed, steps, a=65273, total=140000, base=34000):
+    """The window's LAST target before a slide (position a < 65274 = 65536 - min_lookahead) starts a lazy chain of `steps` improving
+    matches -- 4 bytes at a, 5 at a + 1, ... -- that ends in a 258-byte match at a + steps >= 65279: tokenize leaves the loop at a
+    (SlidingWindow.zig:56-60 gives no lookahead any more), the window slides, and the calls at a + 1 ... are made with the refilled
+    window: the match at a + steps has all its 258 bytes, not the 65536 - (a + steps) the window held before the slide."""
+    r = splitmix(seed, total + 4000)
+    junk = bytes(b | 0x80 for b in r[:total])          # never part of T
+    T = bytes(b & 0x7F for b in r[total:total + steps + 258 + 8])
+    pieces = [T[k:2 * k + 4] for k in range(steps)] + [T[steps:steps + 258]]
+    d = bytearray(junk)
+    pos = base
+    for pc in pieces:
+        d[pos:pos + len(pc)] = pc
+        pos += len(pc) + 40
+    d[a:a + len(T)] = T
+    return bytes(d)
+
+
 def inputs():
     """Inputs of 100-300 KB whose matches reach across the slide boundaries."""
     r = splitmix(1, 400000)
@@ -231,6 +249,8 @@ def inputs():
         "far_copies": (far + splitmix(4, 2768 - 5) + far + splitmix(5, 2768 + 3) + far + splitmix(6, 40000) + far)[:180000],
         "zeros_then_text": bytes(70000) + text[:60000] + bytes(33000) + text[1000:20000],
         "noise_with_runs": b"".join(splitmix(10 + k, 900) + bytes([k % 3]) * (300 + 17 * (k % 40)) for k in range(110))[:150000],
+        "slide_edge6": slide_edge(21, 6),      # round 6: the defect of k_lz_parse<true> (a match of 257 instead of 258 bytes at 65279)
+        "slide_edge30": slide_edge(22, 30, total=100000 + 65536),
     }
 
 
