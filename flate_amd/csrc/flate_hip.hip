@@ -456,6 +456,11 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
         const double est_old = (double)bytes / 1048576.0 * (deep_walk ? 0.11 : 0.061) + (deep_walk ? 1.3 : 0.8);
         if (h->knobs.stream_windows < 0 && est_new >= est_old) windows = false;
         if (wch.size() > tile_limit) windows = false;  // (the chain links of all windows at once: 128 KiB each)
+        // (levels 8-9: 512 KiB of links a window -- 16 GiB for a 1 GiB stream; a device that cannot give them: the tiles)
+        if (windows && deep_walk && ensure(h, h->links, wch.size() * FL_CHUNK_STRIDE * 4 * sizeof(uint16_t))) {
+            (void)hipGetLastError();
+            windows = false;
+        }
     }
     if (windows) {
         const uint32_t nw = (uint32_t)wch.size(), ng = (uint32_t)sws.size();
