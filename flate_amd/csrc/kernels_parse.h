@@ -519,10 +519,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
     const uint32_t c = sw.win0 + wi;
     const fl_chunk ck = chunks[c];
     if (!STREAM && ck.skip) return;
-    const uint32_t N = ck.in_len;
-    const uint32_t Mpos = N >= 4 ? N - 3 : 0u;
-    const uint8_t* src = in + ck.in_off;
-    const uint16_t* pvg = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    const uint32_t N = ck.in_len;  // (the sub-passes read the chunk's fields again: see there)
     const uint64_t pos_off = STREAM ? sck.pos_off + (uint64_t)FL_MAX_DIST * ws : ck.pos_off;
     uint32_t* descg = desc_all + pos_off;
     uint32_t* trueg = true_all + (pos_off >> 5);
