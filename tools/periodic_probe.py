@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Small whole streams of periodic data (zeros, `ab`, counters in text) at level 6: ms per call through the library's own choice of
+path and with the sort / match tiles forced (FLATE_HIP_STREAM_WINDOWS=0); bytes == oracle."""
 import os, sys, time
 os.environ.setdefault("FLATE_HIP_PRELOAD_TORCH_HIP", "1")
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
