@@ -389,7 +389,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
     // every position.  A window costs a workgroup about 0.28 ms, the sort / match pair about 0.061 ms per MiB of all CUs.
     // Round 6: levels 8 and 9 the same way on k_lz_links / k_lz_walk<true, true> (kernels_walk.h).
     const bool deep_walk = prm.chain >= FL_BULK_MIN_CHAIN;
-    bool windows = !t.any_flush && h->knobs.stream_windows != 0 && nseg;
+    // (sync-flush points: levels 4-7 only -- k_lz_chain keeps the three positions before a flush point out of the table and
+    // k_lz_parse<true> ends every match there; the run logic of k_lz_walk counts on runs whose every position is in the table)
+    bool windows = !(t.any_flush && deep_walk) && h->knobs.stream_windows != 0 && nseg;
     std::vector<fl_chunk> wch;
     std::vector<fl_swin> sws;
     bool grouped = false;  // some stream is split into groups of windows: a fix launch follows (kernels_parse.h)
@@ -423,6 +425,9 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                 w.in_off = c.in_off + (uint64_t)FL_SEG * j;
                 w.in_len = (uint32_t)std::min<uint64_t>(65536u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j);
                 w.pad_ = 1u;  // (a window: k_lz_chain builds its chains whatever it holds)
+                w.piece0 = FL_SEG * j;  // the window's position in its stream, and the stream's flush points (k_lz_chain)
+                w.flush_off = c.flush_off;
+                w.n_flush = c.n_flush;
                 // (+ the bytes behind the window that the lazy calls of its last anchor look at: kernels_parse.h, kernels_walk.h)
                 w.pad_ |= (uint32_t)std::min<uint64_t>(264u, (uint64_t)c.in_len - (uint64_t)FL_SEG * j - w.in_len) << 8;
                 wch.push_back(w);
@@ -494,7 +499,8 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
                 ProfScope ps(h, K_LZ_PARSE);
                 hipLaunchKernelGGL(k_lz_parse<true>, dim3(ng), dim3(PZ_THREADS), 0, st, d_in, dwc, prm,
                                    (const uint16_t*)h->S.p, (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
-                                   (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, fix);
+                                   (const fl_swin*)h->swins.p, dch, (const uint32_t*)h->zones.p, d_gexit, d_gentry, d_wexit, d_dirty, fix,
+                                   t.any_flush ? dfp : (const uint32_t*)nullptr);
             }
         };
         if (deep_walk) {
@@ -505,8 +511,12 @@ int compress_stream_pass(flate_hip_ctx* h, const uint8_t* d_in, const fl_params&
             hipLaunchKernelGGL(k_lz_links<3>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc, (uint16_t*)h->links.p, (uint32_t*)h->cflag.p);
         } else {
             ProfScope ps(h, K_LZ_CHAIN);
-            hipLaunchKernelGGL(k_lz_chain, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc,
-                               (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr);
+            if (t.any_flush)
+                hipLaunchKernelGGL(k_lz_chain<true>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc,
+                                   (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr, dfp);
+            else
+                hipLaunchKernelGGL(k_lz_chain<false>, dim3(nw), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dwc,
+                                   (uint16_t*)h->S.p, (uint32_t*)h->cflag.p, (uint32_t*)nullptr, (const uint32_t*)nullptr);
         }
         HIP_OK(h, hipMemsetAsync(d_dirty, 0, sizeof(uint32_t), st));
         launch_tokenizer(0u);
@@ -847,8 +857,8 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
             // levels 4..7: the reference's chain in LDS, the automaton per segment (kernels_parse.h)
             {
                 ProfScope ps(h, K_LZ_CHAIN);
-                hipLaunchKernelGGL(k_lz_chain, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
-                                   (uint32_t*)h->cflag.p, (uint32_t*)h->marks.p);
+                hipLaunchKernelGGL(k_lz_chain<false>, dim3(nc), dim3(64 * FL_CHAIN_WAVES), 0, st, d_in, dch, (uint16_t*)h->S.p,
+                                   (uint32_t*)h->cflag.p, (uint32_t*)h->marks.p, (const uint32_t*)nullptr);
             }
             if (container != 0 && (rc = launch_checksum_side(h, nb, d_in, dch, dbc, dsb, prm))) return rc;
             {
@@ -856,7 +866,7 @@ int enqueue_pass(flate_hip_ctx* h, const fl_params& prm, uint32_t nc, uint32_t n
                 hipLaunchKernelGGL(k_lz_parse<false>, dim3(nc), dim3(PZ_THREADS), 0, st, d_in, dch, prm, (const uint16_t*)h->S.p,
                                    (const uint32_t*)h->cflag.p, (uint32_t*)h->desc.p, (uint32_t*)h->marks.p,
                                    (const fl_swin*)nullptr, (const fl_chunk*)nullptr, (const uint32_t*)nullptr,
-                                   (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+                                   (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
             }
         }
         {

@@ -68,11 +68,13 @@ __device__ __forceinline__ uint32_t fl_lds_mskor_rtn(uint32_t* lds_word, uint32_
 #ifndef FL_CHAIN_TB
 #define FL_CHAIN_TB 1  // blocks per wave and turn
 #endif
+template <bool FLUSH = false>  // FLUSH: windows of a stream with sync-flush points (the other instantiation pays nothing for them)
 __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8_t* __restrict__ in,
                                                                    const fl_chunk* __restrict__ chunks,
                                                                    uint16_t* __restrict__ prev_all,
                                                                    uint32_t* __restrict__ cflag,
-                                                                   uint32_t* __restrict__ marks_all) {
+                                                                   uint32_t* __restrict__ marks_all,
+                                                                   const uint32_t* __restrict__ fpts) {
     __shared__ uint32_t head32[16384 + 64];  // (+ one word per lane for the exchanges of positions past the end)
     __shared__ uint32_t stg_all[FL_CHAIN_WAVES][FL_CHAIN_STG_DW];
     const uint32_t c = blockIdx.x;
@@ -91,6 +93,12 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
     if (Mpos == 0) return;
     const uint8_t* src = in + ck.in_off;
     uint16_t* pv = prev_all + (uint64_t)c * FL_CHUNK_STRIDE;
+    // A WINDOW of a stream with sync-flush points (round 6; the window's fl_chunk carries the stream's flush table and, in piece0,
+    // the window's own position in the stream): the three positions before a flush point never enter the hash table
+    // (deflate.zig:196-203 runs the tokenizer dry there, Lookup.zig:23-27 needs four bytes) and get no link themselves.
+    const uint32_t* fp = fpts ? fpts + ck.flush_off : nullptr;
+    const uint32_t wabs = ck.piece0;
+    const bool has_fl = FLUSH && ck.pad_ && fp && ck.n_flush && fl_next_flush(fp, ck.n_flush, wabs, 0xffffffffu) <= wabs + N + 2u;
     const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
     const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
                 const uint32_t off = (s << 6) + lane + sh;
                 const uint32_t v = __builtin_amdgcn_alignbyte(sb[(off >> 2) + 1], sb[off >> 2], off & 3);
                 const uint32_t h = fl_hash_le(v);
-                const bool valid = p < Mpos;
+                const bool valid = p < Mpos && (!FLUSH || !has_fl || fl_next_flush(fp, ck.n_flush, wabs + p, 0xffffffffu) - (wabs + p) >= 4u);
                 const uint32_t hs = (h & 1u) << 4;
                 am[16 * u + s] = (fl_lds_u32*)&head32[valid ? (h >> 1) : 16384u + lane];
                 mk[16 * u + s] = valid ? (0xffffu << hs) : 0u;
@@ -208,6 +216,8 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
                     const uint32_t o = (mk[16 * u + s] >> 16) ? (old[16 * u + s] >> 16) : (old[16 * u + s] & 0xffffu);
                     overtaken = overtaken || o > p;
                     pv[p] = (uint16_t)o;  // 0 = none: position 0 is the chain's null (deflate.zig:248)
+                } else if (FLUSH && has_fl && p < Mpos) {
+                    pv[p] = 0;  // (kept out of the table by a flush point: a call there finds nothing)
                 }
             }
         }
@@ -225,6 +235,10 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
         __syncthreads();
         if (threadIdx.x == 0) {
             for (uint32_t p = 0; p < Mpos; p++) {
+                if (FLUSH && has_fl && fl_next_flush(fp, ck.n_flush, wabs + p, 0xffffffffu) - (wabs + p) < 4u) {
+                    pv[p] = 0;
+                    continue;
+                }
                 const uint32_t h = fl_hash_le(fl_load_u32_clamped(src, p, N));
                 pv[p] = head16[h];
                 head16[h] = (uint16_t)p;
@@ -433,7 +447,8 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                                                            const fl_chunk* __restrict__ schunks,
                                                            const uint32_t* __restrict__ zones,
                                                            uint32_t* gexit, uint32_t* gentry, uint32_t* wexit,
-                                                           uint32_t* dirty, uint32_t fix_cap) {
+                                                           uint32_t* dirty, uint32_t fix_cap,
+                                                           const uint32_t* __restrict__ fpts) {
     const uint32_t fix = fix_cap & 1u;         // STREAM: the launch from the groups' true entries
     const uint32_t round_cap = fix_cap >> 8;   // STREAM: rounds of the stitch after which a window is given up (0: never)
     // One block of LDS in this order: the window at address 0 (a window byte's LDS address is its position: no base to add),
@@ -626,6 +641,12 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         // made after the next slide, with the whole lookahead -- deflate.zig:304-321; 65536 - 65279 = 257 bytes are not all such a
         // call may look at: tests/test_gpu_stream.py::test_lazy_chain_across_a_slide_sees_the_whole_lookahead)
         const uint32_t NBr = STREAM ? Nr + (ckl.pad_ >> 8) : Nr;
+        // (STREAM, round 6: sync-flush points -- a flush at F ends the lookahead of everything before it: no match crosses F
+        // (deflate.zig:196-203); k_lz_chain has kept F - 3 .. F - 1 out of the table)
+        const uint32_t* fpl = (STREAM && fpts) ? fpts + sck.flush_off : nullptr;
+        const uint32_t nfl = STREAM ? sck.n_flush : 0u;
+        const uint32_t wabs_r = FL_MAX_DIST * ws + r0;  // stream position of relative position 0
+        const bool has_fl = STREAM && fpl && nfl && fl_next_flush(fpl, nfl, FL_MAX_DIST * ws, 0xffffffffu) <= FL_MAX_DIST * ws + 65536u + 300u;
         const uint32_t endr = end - r0, t0r = t0 - r0;
         // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
         // last anchor gets there): the reference has dropped every candidate at or below the next window's start by then
@@ -905,6 +926,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         best = (LL);                                                           \
         bdist = 0;                                                             \
         maxlen = min(NBr - p, (uint32_t)FL_MAX_MATCH);                         \
+        if (STREAM && has_fl) maxlen = min(maxlen, fl_next_flush(fpl, nfl, wabs_r + p, 0xffffffffu) - (wabs_r + p)); \
         q = prv[p];                                                            \
         lo = p > FL_MAX_DIST ? p - FL_MAX_DIST : 1u;                           \
         if (STREAM && p >= zt) lo = max(lo, zlo);                              \

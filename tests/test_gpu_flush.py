@@ -2,6 +2,7 @@
 the stream with its flush markers is byte-identical to the oracle's streaming compressor fed the
 same calls, LZ history across the flushes included."""
 import io
+import os
 import zlib as pyzlib
 
 import numpy as np
@@ -226,3 +227,47 @@ def test_flush_cost_does_not_grow_with_the_stream():
     assert late < 2.0 * early, (early, late)
     import zlib as pyzlib
     assert pyzlib.decompress(c._wrt.getvalue(), 31) == data
+
+
+def test_flush_streams_take_the_windows_at_levels_4_to_7_and_both_ways_agree():
+    """Round 6: streams with sync-flush points at levels 4-7 on k_lz_chain<true> / k_lz_parse<true> (the three positions before a
+    flush point stay out of the hash table, no match crosses one): no k_lz_sort / k_lz_match launch by the library's own choice, bytes
+    == the oracle's Deflate object fed the same writes and flushes; flush points inside matches and runs, at the slide table's edges,
+    several in a row.  The sort / match tiles (FLATE_HIP_STREAM_WINDOWS=0, and levels 8-9) are held to the same streams: this file's
+    parity tests again in a process with the knob set."""
+    import subprocess
+    import sys
+    from flate_amd import synth
+    eng = engine()
+    rng = np.random.default_rng(31)
+    text = synth.text(synth.SEED_TEXT + 3, 500000).tobytes()
+    z = 65536 - 262
+    inputs = [
+        (text[:300000], [5, 100, z - 1, z, z + 1, z + 32768, 131072 - 2, 200000, 200001, 200002, 200003]),
+        (bytes(150000), [1, 2, 3, 70000, z + 3]),
+        ((text[:89] * 4000)[:250000], [44, z - 4, z + 32768 + 2, 249999]),
+        (b"".join(text[k * 300:k * 300 + 120] + bytes(int(rng.integers(4, 2000))) for k in range(200)), [1000, 65274, 65278, 98040, 150000]),
+        (text[:70000], [69997, 69998, 69999, 70000]),
+    ]
+    for level in (4, 5, 6, 7):
+        for data, fl in inputs:
+            fl = sorted(f for f in fl if f <= len(data))
+            for finish in (True, False):
+                f2 = fl if finish else [f for f in fl if f < len(data)] + [len(data)]
+                eng.profile_enable(True)
+                eng.profile_reset()
+                got, st = eng.compress_flush(data, f2, finish, O.GZIP, level)
+                prof = eng.profile_read()
+                eng.profile_enable(False)
+                assert st in (0, 102) and got == _oracle_stream(data, f2, finish, O.GZIP, level)[0], (level, len(data), f2, finish)
+                # (periodic data -- the zeros, the period of 89 -- is handed to the tiles by the windows themselves: DESIGN 4b)
+                if data is not inputs[1][0] and data is not inputs[2][0]:
+                    assert "k_lz_parse" in prof and "k_lz_match" not in prof, (level, len(data), prof)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    me = os.path.abspath(__file__)
+    env = dict(os.environ, FLATE_HIP_STREAM_WINDOWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", me + "::test_flush_streams_match_oracle",
+                        me + "::test_flush_with_containers", me + "::test_flush_fuzz_against_oracle",
+                        me + "::test_incremental_compressor_object_matches_streaming_oracle"],
+                       env=env, capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -24,7 +24,7 @@ int main() {
     hipMalloc(&d_in, in.size()); hipMalloc(&d_ch, sizeof(fl_chunk) * NCH); hipMalloc(&d_prev, 2 * 65536 * NCH);
     hipMemcpy(d_in, in.data(), in.size(), hipMemcpyHostToDevice); hipMemcpy(d_ch, ch.data(), sizeof(fl_chunk) * NCH, hipMemcpyHostToDevice);
     hipMemset(d_prev, 0xee, 2 * 65536 * NCH);
-    hipLaunchKernelGGL(k_lz_chain, dim3(NCH), dim3(64 * FL_CHAIN_WAVES), 0, 0, d_in, d_ch, d_prev, d_cf);
+    hipLaunchKernelGGL(k_lz_chain<false>, dim3(NCH), dim3(64 * FL_CHAIN_WAVES), 0, 0, d_in, d_ch, d_prev, d_cf, (uint32_t*)nullptr, (const uint32_t*)nullptr);
     hipError_t e = hipDeviceSynchronize();
     printf("kernel: %s\n", hipGetErrorString(e));
     std::vector<uint16_t> prev(65536 * NCH);
