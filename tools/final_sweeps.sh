@@ -14,6 +14,8 @@ mkdir -p gpurun_out/r06
   timeout 600 python tools/threshold_sweep.py 661 150 2>/dev/null | tail -1
   FLATE_HIP_STREAM_WINDOWS=1 timeout 600 python tools/threshold_sweep.py 662 100 2>/dev/null | tail -1
   timeout 600 python tools/depth_sweep.py 663 40 2>/dev/null | tail -1
+  timeout 600 python tools/flush_sweep.py 667 150 2>/dev/null | tail -1
+  FLATE_HIP_STREAM_WINDOWS=0 timeout 600 python tools/flush_sweep.py 668 100 2>/dev/null | tail -1
   timeout 600 python tools/inflate_edges.py 2>/dev/null | tail -1
   timeout 900 python tools/inflate_fuzz.py 664 12 2>/dev/null | tail -1
   timeout 600 python tools/span_sweep.py 665 100 2>/dev/null | tail -1
