@@ -652,12 +652,21 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
             uint32_t l = 0;
             for (;;) {
                 WK_CNT(c_meas, 1);
-                uint32_t a0, a1, b0, b1;
+                uint32_t a0, a1, b0, b1, a2, a3, b2, b3;
                 fl_lds_load8(win32, p + l, a0, a1);
                 fl_lds_load8(win32, cand + l, b0, b1);
+                fl_lds_load8(win32, p + l + 8u, a2, a3);  // (four loads in flight: 16 bytes a step)
+                fl_lds_load8(win32, cand + l + 8u, b2, b3);
                 const uint64_t x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                const uint64_t y = (uint64_t)(a2 ^ b2) | ((uint64_t)(a3 ^ b3) << 32);
                 if (x) {
                     l += (uint32_t)__builtin_ctzll(x) >> 3;
+                    break;
+                }
+                l += 8;
+                if (l >= maxlen) break;
+                if (y) {
+                    l += (uint32_t)__builtin_ctzll(y) >> 3;
                     break;
                 }
                 l += 8;
@@ -669,6 +678,33 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
         // with [t, from) all that byte
         auto scan_down = [&](uint32_t from, uint32_t floor, uint32_t bp) -> uint32_t {
             uint32_t t = from;
+            // (16 bytes a step while that many are left: two loads in flight -- a scan is a chain of LDS round trips)
+            while (t >= floor + 32u) {
+                uint32_t a0, a1, b0, b1, c0, c1, d0, d1;
+                fl_lds_load8(win32, t - 8u, a0, a1);
+                fl_lds_load8(win32, t - 16u, b0, b1);
+                fl_lds_load8(win32, t - 24u, c0, c1);
+                fl_lds_load8(win32, t - 32u, d0, d1);
+                const uint64_t xa = (uint64_t)(a0 ^ bp) | ((uint64_t)(a1 ^ bp) << 32);
+                const uint64_t xb = (uint64_t)(b0 ^ bp) | ((uint64_t)(b1 ^ bp) << 32);
+                const uint64_t xc = (uint64_t)(c0 ^ bp) | ((uint64_t)(c1 ^ bp) << 32);
+                const uint64_t xd = (uint64_t)(d0 ^ bp) | ((uint64_t)(d1 ^ bp) << 32);
+                if (xa) return t - ((uint32_t)__builtin_clzll(xa) >> 3);
+                if (xb) return t - 8u - ((uint32_t)__builtin_clzll(xb) >> 3);
+                if (xc) return t - 16u - ((uint32_t)__builtin_clzll(xc) >> 3);
+                if (xd) return t - 24u - ((uint32_t)__builtin_clzll(xd) >> 3);
+                t -= 32u;
+            }
+            while (t >= floor + 16u) {
+                uint32_t a0, a1, b0, b1;
+                fl_lds_load8(win32, t - 8u, a0, a1);
+                fl_lds_load8(win32, t - 16u, b0, b1);
+                const uint64_t xa = (uint64_t)(a0 ^ bp) | ((uint64_t)(a1 ^ bp) << 32);
+                const uint64_t xb = (uint64_t)(b0 ^ bp) | ((uint64_t)(b1 ^ bp) << 32);
+                if (xa) return t - ((uint32_t)__builtin_clzll(xa) >> 3);
+                if (xb) return t - 8u - ((uint32_t)__builtin_clzll(xb) >> 3);
+                t -= 16u;
+            }
             while (t > floor) {
                 const uint32_t step = min(8u, t - floor);
                 uint32_t w0, w1;
@@ -887,10 +923,19 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                                 r += x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
                             }
                             while (r >= 8u && r < maxlen) {  // (r < 8: the run has ended; else r is a multiple of 8 here)
+                                uint32_t w2, w3;
                                 fl_lds_load8(win32, p + r, w0, w1);
+                                fl_lds_load8(win32, p + r + 8u, w2, w3);  // (two loads in flight: 16 bytes a step)
                                 const uint64_t x = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                                const uint64_t y = (uint64_t)(w2 ^ bp) | ((uint64_t)(w3 ^ bp) << 32);
                                 if (x) {
                                     r += (uint32_t)__builtin_ctzll(x) >> 3;
+                                    break;
+                                }
+                                r += 8;
+                                if (r >= maxlen) break;
+                                if (y) {
+                                    r += (uint32_t)__builtin_ctzll(y) >> 3;
                                     break;
                                 }
                                 r += 8;
@@ -1013,11 +1058,19 @@ __global__ __launch_bounds__(WK_THREADS, STREAM ? WK_STREAM_WAVES_PER_SIMD : WK_
                 const uint32_t c = best, r = prun, cap = max(c, r) + 1u;
                 uint32_t d = 8;  // bytes b from q on, counted up to cap + 1
                 while (d <= cap) {
-                    uint32_t w0, w1;
+                    uint32_t w0, w1, w2, w3;
                     fl_lds_load8(win32, q + d, w0, w1);
+                    fl_lds_load8(win32, q + d + 8u, w2, w3);
                     const uint64_t x = (uint64_t)(w0 ^ bp) | ((uint64_t)(w1 ^ bp) << 32);
+                    const uint64_t y = (uint64_t)(w2 ^ bp) | ((uint64_t)(w3 ^ bp) << 32);
                     if (x) {
                         d += (uint32_t)__builtin_ctzll(x) >> 3;
+                        break;
+                    }
+                    d += 8;
+                    if (d > cap) break;
+                    if (y) {
+                        d += (uint32_t)__builtin_ctzll(y) >> 3;
                         break;
                     }
                     d += 8;
