@@ -1294,12 +1294,18 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
                         for (;;) {
                             PZ_EV(4);
                             PZ_CNT(c_meas, 1);
-                            uint32_t a0, a1, b0, b1;
+                            uint32_t a0, a1, b0, b1, a2, a3, b2, b3;
                             fl_lds_load8(win32, p + l, a0, a1);
                             fl_lds_load8(win32, qh + l, b0, b1);
-                            // (one 64-bit test: all six dwords are loaded together, one LDS round trip per 8 bytes -- with
-                            // two tests the compiler loads the second half only after the first has compared equal)
+                            fl_lds_load8(win32, p + l + 8u, a2, a3);
+                            fl_lds_load8(win32, qh + l + 8u, b2, b3);
+                            // (64-bit tests: all the dwords of 16 bytes are loaded together, one LDS round trip per 16 bytes -- round 6:
+                            // 1.85 trips a compare at 8)
                             x = (uint64_t)(a0 ^ b0) | ((uint64_t)(a1 ^ b1) << 32);
+                            const uint64_t y = (uint64_t)(a2 ^ b2) | ((uint64_t)(a3 ^ b3) << 32);
+                            if (x || l + 8 >= maxlen) break;
+                            l += 8;
+                            x = y;
                             if (x || l + 8 >= maxlen) break;
                             l += 8;
                         }
