@@ -1,5 +1,6 @@
 // kernels_walk.h -- the LZ77 match finder + lazy-matching automaton of the chunk path (levels 4..9, inputs of at most
-// 65535 bytes), round 4: SPARSE CHAINS.
+// 65535 bytes), round 4: SPARSE CHAINS.  Round 6: the same kernel over the WINDOWS of long streams at levels 8 and 9
+// (k_lz_walk<true, true>, `wk_stream`: see there and k_lz_parse<true> in kernels_parse.h).
 //
 // The reference's findMatch (deflate.zig:233-266) walks the chain of the positions that share a 15-bit hash of four
 // bytes with p, nearest first, at most `chain` of them, and keeps a candidate only if it is LONGER than the match in
