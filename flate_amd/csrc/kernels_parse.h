@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * FL_CHAIN_WAVES, 4) void k_lz_chain(const uint8
     // (deflate.zig:196-203 runs the tokenizer dry there, Lookup.zig:23-27 needs four bytes) and get no link themselves.
     const uint32_t* fp = fpts ? fpts + ck.flush_off : nullptr;
     const uint32_t wabs = ck.piece0;
-    const bool has_fl = FLUSH && ck.pad_ && fp && ck.n_flush && fl_next_flush(fp, ck.n_flush, wabs, 0xffffffffu) <= wabs + N + 2u;
+    const bool has_fl = FLUSH && ck.pad_ && fp && ck.n_flush && (uint64_t)fl_next_flush(fp, ck.n_flush, wabs, 0xffffffffu) <= (uint64_t)wabs + N + 2u;
     const uint32_t sh = (uint32_t)((uintptr_t)src & 15);
     const uint4* src16 = (const uint4*)(src - sh);  // 16-byte granules; granule g covers chunk bytes 16 g - sh ..
     const uint32_t n_gran = (N + sh + 15) >> 4;     // granules holding at least one byte of the chunk
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(PZ_THREADS, PZ_THREADS / 256) void k_lz_parse(const
         const uint32_t* fpl = (STREAM && fpts) ? fpts + sck.flush_off : nullptr;
         const uint32_t nfl = STREAM ? sck.n_flush : 0u;
         const uint32_t wabs_r = FL_MAX_DIST * ws + r0;  // stream position of relative position 0
-        const bool has_fl = STREAM && fpl && nfl && fl_next_flush(fpl, nfl, FL_MAX_DIST * ws, 0xffffffffu) <= FL_MAX_DIST * ws + 65536u + 300u;
+        const bool has_fl = STREAM && fpl && nfl && (uint64_t)fl_next_flush(fpl, nfl, FL_MAX_DIST * ws, 0xffffffffu) <= (uint64_t)FL_MAX_DIST * ws + 65536u + 300u;
         const uint32_t endr = end - r0, t0r = t0 - r0;
         // STREAM: a position at or beyond the window's last target is visited AFTER the next slide (a lazy call of the window's
         // last anchor gets there): the reference has dropped every candidate at or below the next window's start by then
